@@ -1,0 +1,190 @@
+/*
+ * waveverify_hip.h — C ABI of libwaveverify_hip.so: the MI355X (gfx950) embed/detect hot path
+ * of WaveVerify.  Plain pointers and sizes only; no torch / HIP types in the signatures
+ * (`stream` is a hipStream_t passed as void*, NULL = the default stream).
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference):
+ *   wv_generator_forward  Generator.forward            model/generator.py:360-423
+ *                         (+ the `wm = delta + x` of AudioWatermarking._forward_audio_sample,
+ *                          model/watermarking.py:423-441, when add_input != 0, and the message
+ *                          batch broadcast of watermarking.py:320-329 through msg_rows)
+ *   wv_detector_forward   Detector.forward             model/detector.py:366-391
+ *                         (+ sigmoid/mean-over-time of waveverify/core.py:577-580 when
+ *                          mean_prob != NULL, so the [B,nbits,T] logits need not be stored)
+ *   wv_locator_forward    Locator.forward              model/locator.py:268-299
+ *   wv_model_set_param*   nn.Module.load_state_dict on the stripped / parametrized key layouts
+ *                         waveverify/core.py:324-426, scripts/train.py:1589-1676
+ *   wv_op_*               the fused units of modules/seanet.py + modules/conv.py, exported one by
+ *                         one so that parity tests can pin each kernel separately.
+ *
+ * Tensors are float32, contiguous, [B, C, T] with time innermost, in DEVICE memory unless the
+ * parameter is documented as host memory.  The caller owns every buffer; the library owns only
+ * the packed weights inside a wv_model.  Every function returns 0 on success or a negative
+ * WV_E* code; wv_last_error() gives the message (thread-local).
+ */
+#ifndef WAVEVERIFY_HIP_H
+#define WAVEVERIFY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WV_OK 0
+#define WV_EINVAL (-1)   /* bad argument / shape */
+#define WV_ENOKEY (-2)   /* unknown or missing parameter name */
+#define WV_EHIP (-3)     /* HIP runtime error */
+#define WV_ESTATE (-4)   /* call order (e.g. forward before finalize) */
+#define WV_ENOMEM (-5)   /* workspace too small */
+
+#define WV_KIND_GENERATOR 0
+#define WV_KIND_DETECTOR 1
+#define WV_KIND_LOCATOR 2
+
+#define WV_MAX_STRIDES 8
+
+/* Hyper-parameters; field names follow the reference constructors
+ * (model/generator.py:63-104, model/detector.py:82-114, model/locator.py:84-115). */
+typedef struct wv_config {
+    int32_t kind;
+    int32_t dimension;
+    int32_t msg_dimension;
+    int32_t channels_enc;
+    int32_t channels_dec;
+    int32_t n_fft_base;
+    int32_t n_residual_enc;
+    int32_t n_residual_dec;
+    int32_t n_strides;
+    int32_t strides[WV_MAX_STRIDES];   /* as given to the constructor, e.g. {8,5,4,2} */
+    int32_t kernel_size;
+    int32_t last_kernel_size;
+    int32_t residual_kernel_size;
+    int32_t dilation_base;
+    int32_t zero_init;                 /* 1: res_scale_param / scale_param tensors exist */
+    int32_t nbits;
+    int32_t output_dim;
+    int32_t embedding_dim;
+    int32_t embedding_layers;
+    int32_t freq_bands;
+    float res_scale_enc;
+    float res_scale_dec;
+    float wav_std;
+    float spec_means[WV_MAX_STRIDES + 1];
+    float spec_stds[WV_MAX_STRIDES + 1];
+} wv_config;
+
+typedef struct wv_model wv_model;
+
+const char* wv_last_error(void);
+const char* wv_version(void);
+
+/* Fill cfg with the reference defaults for `kind`. */
+int wv_config_default(int kind, wv_config* cfg);
+
+/* ---- model lifetime --------------------------------------------------------------------- */
+int wv_model_create(const wv_config* cfg, wv_model** out);
+void wv_model_destroy(wv_model* m);
+
+/* Parameter table: the state-dict keys (stripped layout) this model expects. */
+int wv_model_num_params(const wv_model* m);
+/* name_out: caller buffer of name_cap bytes; shape_out: 4 int64 (unused dims = 1). */
+int wv_model_param_info(const wv_model* m, int index, char* name_out, int name_cap,
+                        int64_t* shape_out, int* ndim_out, int* is_weight_normed);
+
+/* Hand over one tensor in the reference's layout (HOST memory, float32, numel checked). */
+int wv_model_set_param(wv_model* m, const char* name, const float* host_data, int64_t numel);
+/* Same for a weight-normed tensor given as the (g, v) pair of
+ * `...parametrizations.weight.original0/1`; folded as w = g * v / ||v|| (modules/conv.py:73-74). */
+int wv_model_set_param_wn(wv_model* m, const char* name, const float* host_g, int64_t g_numel,
+                          const float* host_v, int64_t v_numel);
+/* Optional override of a CausalSTFT basis buffer `...spec.weight` [2F,1,n_fft] (checkpoints
+ * carry it, modules/conv.py:1026); by default the basis is generated as conv.py:1003-1020 does. */
+int wv_model_set_stft_basis(wv_model* m, const char* name, const float* host_data, int64_t numel);
+/* Pack (transpose / interleave / compose heads) and upload. Fails if a parameter is missing. */
+int wv_model_finalize(wv_model* m);
+
+/* ---- forward passes --------------------------------------------------------------------- */
+/* Device scratch needed for a [B,1,T] batch (bytes). */
+size_t wv_workspace_bytes(const wv_model* m, int B, int T);
+
+/* x [B,1,T]; msg [msg_rows, msg_dimension] float (0/1), msg_rows == B or 1 (broadcast);
+ * out [B,1,T] = delta, or delta + x when add_input != 0. */
+int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_rows,
+                         float* out, int add_input, int B, int T,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* x [B,1,T]; logits [B,nbits,T] or NULL; mean_prob [B,nbits] or NULL (mean_t sigmoid(logit)). */
+int wv_detector_forward(wv_model* m, const float* x, float* logits, float* mean_prob,
+                        int B, int T, void* workspace, size_t workspace_bytes, void* stream);
+
+/* x [B,1,T]; logits [B,1,T]. */
+int wv_locator_forward(wv_model* m, const float* x, float* logits, int B, int T,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Encoder only (SEANetEncoder.forward, modules/seanet.py:883-976): latent [B,dimension,ceil(T/hop)].
+ * msg may be NULL (no FiLM), as for the detector / locator. */
+int wv_encoder_forward(wv_model* m, const float* x, const float* msg, int msg_rows, float* latent,
+                       int B, int T, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- single fused units ----------------------------------------------------------------
+ * Activations (X, resid, film, Y, wav, P, H, x, Z, logits, mean_prob) are DEVICE pointers.
+ * Weights / biases (w_*, *_bias, bias, basis) are HOST pointers in the reference's own layouts;
+ * they are packed and uploaded per call and the call is synchronous: these entry points exist so
+ * that every kernel can be parity-tested on its own, not for serving. */
+
+/* Y = epilogue( DWconv_k,s,d( W1x1 @ act(pre_scale * X) ) + dw_bias )
+ *   X [B,K,Tin], w_pw [M,K] (1x1, no bias), w_dw [M,ks], dw_bias [M] or NULL
+ *   causal left pad (ks-1)*d-(s-1), zero right pad to complete the last frame
+ *   (SConv1d, modules/conv.py:715-763); Tout = ceil(Tin/s).
+ *   pre_elu: 1 -> act = ELU, 0 -> identity.
+ *   film [B,bands,2] (gamma,beta) or NULL: y = y*gamma+beta per band (seanet.py:928-966);
+ *   resid [B,M,Tout] or NULL: y = y*out_scale + resid (seanet.py:272-277).
+ * This is the ResnetBlock half (seanet.py:39-116) and the Downsample+FiLM unit (seanet.py:733-772). */
+int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const float* dw_bias,
+                const float* film, const float* resid, float* Y,
+                int B, int K, int M, int Tin, int ks, int stride, int dilation,
+                float pre_scale, int pre_elu, float out_scale, int bands, void* stream);
+
+/* Y = W1x1 @ producer(X) + bias, then optional L2-normalise over channels * sqrt(M).
+ *   mode 0: producer = act(pre_scale*X)                                  (plain 1x1)
+ *   mode 1: producer = causal DW conv k (no bias) of act(pre_scale*X)    (conv_post, seanet.py:797-823)
+ *   mode 2: producer = causal DW ConvTranspose k=2r,s=r of act(pre_scale*X), right-trimmed by r
+ *           (upsample, seanet.py:1112-1138; SConvTranspose1d conv.py:838-881); Tout = Tin*r
+ *   accumulate != 0: Y += out_scale * (W @ producer(X))  (SpecBlock add, seanet.py:500-505). */
+int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const float* bias, float* Y,
+                int B, int K, int M, int Tin, int mode, int ks_or_ratio,
+                float pre_scale, int pre_elu, int l2norm, int accumulate, float out_scale,
+                void* stream);
+
+/* P[b,f,t] = (log(max(|STFT|,1e-5)) - mean)/std, CausalSTFT magnitude with eps 1e-12
+ * (modules/conv.py:1036-1080, seanet.py:479-494). wav [B,1,T]; basis [2F,n_fft] host or NULL
+ * (NULL: generated); P [B,F,ceil(T/hop)]. */
+int wv_op_stft_logmag(const float* wav, const float* host_basis, float* P, int B, int T,
+                      int n_fft, int hop, float mean, float std, void* stream);
+
+/* conv_pre: Y = Conv1d(1->C,k)(x * in_scale) + bias  (seanet.py:657-664). x [B,1,T], w [C,1,k]. */
+int wv_op_conv_pre(const float* x, const float* w, const float* bias, float* Y, int B, int C,
+                   int T, int ks, float in_scale, void* stream);
+
+/* decoder tail: out = tanh(out_scale*(Conv1d(C->1,k)(ELU(pre_scale*H)) + bias)) (+ x)
+ * (seanet.py:1177-1202, generator.py:410, watermarking.py:440). H [B,C,Tin>=T], w [1,C,k]. */
+int wv_op_tail(const float* H, const float* w, const float* bias, const float* x_or_null,
+               float* out, int B, int C, int Tin, int T, int ks, float pre_scale, float out_scale,
+               void* stream);
+
+/* detector / locator head: ConvTranspose1d(D->O,k=s=hop)+bias -> trim to T -> Conv1d(O->nb,1)+bias
+ * (detector.py:300-310). Z [B,D,Fr]; w_rev [D,O,hop]; w_last [nb,O]; either output may be NULL. */
+int wv_op_head(const float* Z, const float* w_rev, const float* b_rev,
+               const float* w_last, const float* b_last, float* logits, float* mean_prob,
+               int B, int D, int O, int nb, int hop, int Fr, int T, void* stream);
+
+/* message MLP + all FiLM gammas/betas (seanet.py:831-846,905-912): msg [rows,msg_dim] ->
+ * film [B,n_scales,bands,2]; uses the model's parameters. */
+int wv_model_film(wv_model* m, const float* msg, int msg_rows, float* film, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVEVERIFY_HIP_H */

@@ -1,0 +1,198 @@
+"""Kernel-level parity: every fused unit through the C ABI (wv_op_*) against the numpy oracle
+on the same seeded inputs.  float32 everywhere; tolerance 2e-5 * max(1, |ref|max) (different
+summation order of the f32 MFMA fmaf chain vs BLAS)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wv_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from waveverify_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return _ops
+
+
+def rnd(rng, *shape, scale=1.0):
+    return (scale * rng.standard_normal(shape)).astype(np.float32)
+
+
+def close(got, ref, tol=2e-5, what=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = float(np.abs(got - ref).max()) if ref.size else 0.0
+    lim = tol * max(1.0, float(np.abs(ref).max()) if ref.size else 1.0)
+    assert np.isfinite(got).all(), what
+    assert err <= lim, f"{what}: max|d|={err:.3e} > {lim:.3e}"
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# (K, M, Tin, ks, stride, dil) — resblock halves, all four downsample shapes, ragged sizes
+PW_DW_CASES = [
+    (64, 64, 1000, 5, 1, 1), (128, 128, 777, 5, 1, 1), (96, 96, 300, 5, 1, 1),
+    (192, 192, 130, 5, 1, 2), (512, 512, 50, 5, 1, 1), (8, 8, 67, 5, 1, 1), (5, 7, 1, 3, 1, 1),
+    (64, 128, 1001, 4, 2, 1), (128, 256, 500, 8, 4, 1), (256, 512, 203, 10, 5, 1),
+    (512, 1024, 400, 16, 8, 1), (32, 64, 37, 16, 8, 1), (768, 768, 400, 5, 1, 1),
+]
+
+
+@pytest.mark.parametrize("K,M,Tin,ks,stride,dil", PW_DW_CASES)
+@pytest.mark.parametrize("epi", ["none", "resid", "film"])
+def test_pw_dw(ops, K, M, Tin, ks, stride, dil, epi):
+    if epi == "film" and M % 4:
+        pytest.skip("FiLM needs channels divisible by the band count")
+    if epi == "resid" and stride != 1:
+        pytest.skip("residual only on stride-1 units")
+    rng = np.random.default_rng(K * 7 + M + Tin)
+    B = 3
+    X = rnd(rng, B, K, Tin)
+    w_pw = rnd(rng, M, K, 1, scale=K ** -0.5)
+    w_dw = rnd(rng, M, 1, ks, scale=ks ** -0.5)
+    b_dw = rnd(rng, M, scale=0.1)
+    pre = 0.8660254
+    h = O.sconv1d(O.elu(X * np.float32(pre)), w_pw, None)
+    ref = O.sconv1d(h, w_dw, b_dw, stride=stride, dilation=dil, groups=M)
+    kw = {}
+    if epi == "resid":
+        R = rnd(rng, *ref.shape)
+        ref = ref * np.float32(0.37) + R
+        kw = dict(resid=cu(R), out_scale=0.37)
+    elif epi == "film":
+        film = rnd(rng, B, 4, 2)
+        bw = M // 4
+        ref = ref * np.repeat(film[:, :, 0], bw, 1)[:, :, None] + np.repeat(film[:, :, 1], bw, 1)[:, :, None]
+        kw = dict(film=cu(film), bands=4)
+    got = ops.pw_dw(cu(X), w_pw, w_dw, b_dw, stride=stride, dilation=dil, pre_scale=pre, pre_elu=True, **kw)
+    close(got, ref.astype(np.float32), what=f"pw_dw {epi}")
+
+
+def test_pw_dw_no_prologue_no_bias(ops):
+    """decoder head: 1x1 (128->1536, no bias) -> DW k5 (seanet.py:1070-1091)."""
+    rng = np.random.default_rng(5)
+    X = rnd(rng, 2, 128, 50)
+    w_pw = rnd(rng, 1536, 128, 1, scale=128 ** -0.5)
+    w_dw = rnd(rng, 1536, 1, 5)
+    ref = O.sconv1d(O.sconv1d(X, w_pw, None), w_dw, None, groups=1536)
+    close(ops.pw_dw(cu(X), w_pw, w_dw, None, pre_elu=False), ref, what="dec head")
+
+
+@pytest.mark.parametrize("K,M,Tin,r", [(1536, 768, 50, 8), (768, 384, 400, 5), (384, 192, 333, 4),
+                                       (192, 96, 1000, 2), (16, 8, 9, 2), (24, 12, 1, 3)])
+def test_upsample_convtr_pw(ops, K, M, Tin, r):
+    rng = np.random.default_rng(K + r)
+    X = rnd(rng, 2, K, Tin)
+    w_ct = rnd(rng, K, 1, 2 * r, scale=(2 * r) ** -0.5)
+    w_pw = rnd(rng, M, K, 1, scale=K ** -0.5)
+    b = rnd(rng, M, scale=0.1)
+    up = O.sconvtr1d_depthwise(O.elu(X * np.float32(0.7071)), w_ct, r)
+    assert up.shape[-1] == Tin * r
+    ref = O.sconv1d(up, w_pw, b)
+    got = ops.dw_pw(cu(X), w_pw, b, w_ct, mode=2, ks_or_ratio=r, pre_scale=0.7071, pre_elu=True)
+    close(got, ref, what="upsample")
+
+
+@pytest.mark.parametrize("K,M,Tin", [(1024, 128, 50), (128, 64, 500), (32, 16, 17), (64, 128, 51)])
+def test_conv_post_l2norm(ops, K, M, Tin):
+    rng = np.random.default_rng(K + M)
+    X = rnd(rng, 3, K, Tin)
+    w_dw = rnd(rng, K, 1, 5, scale=0.4)
+    w_pw = rnd(rng, M, K, 1, scale=K ** -0.5)
+    b = rnd(rng, M)
+    h = O.sconv1d(O.sconv1d(O.elu(X), w_dw, None, groups=K), w_pw, b)
+    nrm = np.sqrt((h ** 2).sum(1, keepdims=True))
+    ref = (h / np.maximum(nrm, 1e-12) * np.float32(M ** 0.5)).astype(np.float32)
+    got = ops.dw_pw(cu(X), w_pw, b, w_dw, mode=1, ks_or_ratio=5, pre_elu=True, l2norm=True)
+    close(got, ref, what="conv_post")
+
+
+@pytest.mark.parametrize("F,C,T", [(33, 64, 1000), (513, 1024, 50), (129, 256, 300), (9, 8, 33)])
+def test_pointwise_accumulate(ops, F, C, T):
+    """SpecBlock tail: x += scale * (W @ P) (seanet.py:497-505)."""
+    rng = np.random.default_rng(F)
+    P = rnd(rng, 2, F, T)
+    Xa = rnd(rng, 2, C, T)
+    w = rnd(rng, C, F, 1, scale=F ** -0.5)
+    ref = Xa + np.float32(0.61) * O.sconv1d(P, w, None)
+    acc = cu(Xa)
+    ops.dw_pw(cu(P), w, None, None, mode=0, accumulate_into=acc, out_scale=0.61)
+    close(acc, ref.astype(np.float32), what="spec add")
+
+
+@pytest.mark.parametrize("n_fft,hop,T", [(64, 1, 1000), (128, 2, 1001), (256, 8, 4000), (512, 40, 4001),
+                                         (1024, 320, 16000), (16, 1, 5), (32, 4, 1), (256, 32, 777)])
+def test_stft_logmag(ops, n_fft, hop, T):
+    rng = np.random.default_rng(n_fft + hop)
+    wav = np.clip(rnd(rng, 2, 1, T, scale=0.1), -1, 1)
+    wav[1, 0, : T // 3] = 0.0                      # silence -> exercises both clamps
+    mag = O.causal_stft_mag(wav, n_fft, hop)
+    ref = ((np.log(np.maximum(mag, np.float32(1e-5))) - np.float32(-4.3)) / np.float32(2.8)).astype(np.float32)
+    got = ops.stft_logmag(cu(wav), n_fft, hop, mean=-4.3, std=2.8)
+    # log() amplifies relative error of tiny magnitudes; compare in the log domain with a loose
+    # absolute bound where mag is near the 1e-5 clamp, tight elsewhere
+    got_np = got.cpu().numpy()
+    assert got_np.shape == ref.shape
+    big = mag > 1e-3
+    assert np.abs(got_np - ref)[big].max(initial=0) <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(got_np - ref)[~big].max(initial=0) <= 5e-3
+
+
+def test_stft_with_given_basis(ops):
+    rng = np.random.default_rng(3)
+    wav = rnd(rng, 2, 1, 500, scale=0.1)
+    basis = O.dft_basis(64) * np.float32(1.01)
+    mag = O.causal_stft_mag(wav, 64, 1, basis)
+    ref = np.log(np.maximum(mag, np.float32(1e-5))).astype(np.float32)
+    got = ops.stft_logmag(cu(wav), 64, 1, basis=basis).cpu().numpy()
+    big = mag > 1e-3
+    assert np.abs(got - ref)[big].max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("C,T,ks", [(64, 16000, 5), (32, 1001, 5), (8, 3, 7), (4, 1, 5)])
+def test_conv_pre(ops, C, T, ks):
+    rng = np.random.default_rng(C)
+    x = rnd(rng, 3, 1, T, scale=0.1)
+    w = rnd(rng, C, 1, ks)
+    b = rnd(rng, C)
+    ref = O.sconv1d((x * np.float32(8.912)).astype(np.float32), w, b)
+    close(ops.conv_pre(cu(x), w, b, 8.912), ref, what="conv_pre")
+
+
+@pytest.mark.parametrize("C,Tin,T,ks", [(96, 16000, 16000, 5), (96, 16320, 16001, 5), (8, 68, 67, 5), (8, 4, 1, 5)])
+def test_tail(ops, C, Tin, T, ks):
+    rng = np.random.default_rng(C + T)
+    H = rnd(rng, 2, C, Tin)
+    x = rnd(rng, 2, 1, T, scale=0.1)
+    w = rnd(rng, 1, C, ks, scale=(C * ks) ** -0.5)
+    b = rnd(rng, 1)
+    y = O.sconv1d(O.elu(H * np.float32(0.7071)), w, b)
+    ref = (np.tanh(y * np.float32(0.1122))[..., :T] + x).astype(np.float32)
+    close(ops.tail(cu(H), w, b, cu(x), T=T, pre_scale=0.7071, out_scale=0.1122), ref, 1e-6, "tail")
+    ref2 = np.tanh(y * np.float32(0.1122))[..., :T].astype(np.float32)
+    close(ops.tail(cu(H), w, b, None, T=T, pre_scale=0.7071, out_scale=0.1122), ref2, 1e-6, "tail no add")
+
+
+@pytest.mark.parametrize("D,O_,nb,hop,Fr,T", [(128, 32, 16, 320, 50, 16000), (128, 32, 16, 320, 51, 16001),
+                                               (64, 32, 1, 32, 500, 16000), (16, 8, 16, 4, 17, 67), (8, 8, 1, 4, 1, 1)])
+def test_head(ops, D, O_, nb, hop, Fr, T):
+    rng = np.random.default_rng(D + hop)
+    Z = rnd(rng, 2, D, Fr)
+    sd = {"reverse_convolution.weight": rnd(rng, D, O_, hop, scale=D ** -0.5),
+          "reverse_convolution.bias": rnd(rng, O_, scale=0.1),
+          "last_layer.weight": rnd(rng, nb, O_, 1, scale=O_ ** -0.5),
+          "last_layer.bias": rnd(rng, nb)}
+    net = O._Net(None, sd)
+    ref = O.head_forward(net, Z, T)
+    logits, mean = ops.head(cu(Z), sd["reverse_convolution.weight"], sd["reverse_convolution.bias"],
+                            sd["last_layer.weight"], sd["last_layer.bias"], T)
+    close(logits, ref, what="head logits")
+    close(mean, O.mean_probabilities(ref), 2e-6, "mean prob")
+    _, mean_only = ops.head(cu(Z), sd["reverse_convolution.weight"], sd["reverse_convolution.bias"],
+                            sd["last_layer.weight"], sd["last_layer.bias"], T, want_logits=False)
+    assert torch.equal(mean, mean_only)            # fused reduction is deterministic

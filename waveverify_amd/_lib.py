@@ -1,0 +1,97 @@
+"""ctypes binding of libwaveverify_hip.so (include/waveverify_hip.h).
+
+There is no CPU fallback: if the shared library is missing, loading fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libwaveverify_hip.so")
+WV_MAX_STRIDES = 8
+
+WV_KIND = {"generator": 0, "detector": 1, "locator": 2}
+
+
+class WvConfig(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("dimension", C.c_int32), ("msg_dimension", C.c_int32),
+        ("channels_enc", C.c_int32), ("channels_dec", C.c_int32), ("n_fft_base", C.c_int32),
+        ("n_residual_enc", C.c_int32), ("n_residual_dec", C.c_int32), ("n_strides", C.c_int32),
+        ("strides", C.c_int32 * WV_MAX_STRIDES),
+        ("kernel_size", C.c_int32), ("last_kernel_size", C.c_int32),
+        ("residual_kernel_size", C.c_int32), ("dilation_base", C.c_int32),
+        ("zero_init", C.c_int32), ("nbits", C.c_int32), ("output_dim", C.c_int32),
+        ("embedding_dim", C.c_int32), ("embedding_layers", C.c_int32), ("freq_bands", C.c_int32),
+        ("res_scale_enc", C.c_float), ("res_scale_dec", C.c_float), ("wav_std", C.c_float),
+        ("spec_means", C.c_float * (WV_MAX_STRIDES + 1)),
+        ("spec_stds", C.c_float * (WV_MAX_STRIDES + 1)),
+    ]
+
+
+_FP = C.POINTER(C.c_float)
+_VP = C.c_void_p
+
+# name -> (restype, argtypes); the complete export list of include/waveverify_hip.h
+SIGNATURES = {
+    "wv_last_error": (C.c_char_p, []),
+    "wv_version": (C.c_char_p, []),
+    "wv_config_default": (C.c_int, [C.c_int, C.POINTER(WvConfig)]),
+    "wv_model_create": (C.c_int, [C.POINTER(WvConfig), C.POINTER(_VP)]),
+    "wv_model_destroy": (None, [_VP]),
+    "wv_model_num_params": (C.c_int, [_VP]),
+    "wv_model_param_info": (C.c_int, [_VP, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "wv_model_set_param": (C.c_int, [_VP, C.c_char_p, _VP, C.c_int64]),
+    "wv_model_set_param_wn": (C.c_int, [_VP, C.c_char_p, _VP, C.c_int64, _VP, C.c_int64]),
+    "wv_model_set_stft_basis": (C.c_int, [_VP, C.c_char_p, _VP, C.c_int64]),
+    "wv_model_finalize": (C.c_int, [_VP]),
+    "wv_workspace_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),
+    "wv_generator_forward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int,
+                                       _VP, C.c_size_t, _VP]),
+    "wv_detector_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_locator_forward": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_encoder_forward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_int, _VP,
+                                     C.c_size_t, _VP]),
+    "wv_model_film": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP]),
+    "wv_op_pw_dw": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
+                              C.c_int, _VP]),
+    "wv_op_dw_pw": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, _VP]),
+    "wv_op_stft_logmag": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    C.c_float, _VP]),
+    "wv_op_conv_pre": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_float, _VP]),
+    "wv_op_tail": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_float, C.c_float, _VP]),
+    "wv_op_head": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_int, C.c_int, C.c_int, _VP]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once). Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"waveverify_amd: HIP extension not found at {LIB_PATH}; build it with "
+            "`python -m waveverify_amd.build` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().wv_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what or 'waveverify_hip'} failed (code {rc}): {msg}")

@@ -1,0 +1,100 @@
+// Internal launcher interface between the host-side model plan (wv_model.hip) and the
+// gfx950 kernels (wv_kernels.hip).  All pointers are device pointers; weights are in the
+// PACKED layouts described next to each struct.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wv {
+
+constexpr int BK = 16;          // K-chunk staged per pipeline step
+constexpr int M_ALIGN = 128;    // packed 1x1 weights: Mp = roundup(M, M_ALIGN)
+
+inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// Packed pointwise weight: Wt[Kp][Mp] (transposed, zero padded), Kp = roundup(K, BK).
+struct PwWeight {
+    const float* wt = nullptr;
+    int K = 0, M = 0, Kp = 0, Mp = 0;
+};
+
+// ---- K1: 1x1 GEMM -> depth-wise stencil epilogue ------------------------------------------
+struct PwDwArgs {
+    const float* X;       // [B, K, Tin]
+    PwWeight pw;          // 1x1 (no bias)
+    const float* dw_w;    // [M, ks]
+    const float* dw_b;    // [M] or null
+    const float* film;    // [B, film_stride] (gamma,beta interleaved per band) or null
+    const float* resid;   // [B, M, Tout] or null
+    float* Y;             // [B, M, Tout]
+    int B, Tin, Tout, ks, stride, dil, pad;
+    float pre_scale;
+    int pre_elu;
+    float out_scale;
+    int bands, film_stride;
+    float post_scale;     // optional activation of the OUTPUT (consumer's prologue hoisted):
+    int post_elu;         //   y = post_elu ? ELU(post_scale*y) : y
+};
+hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s);
+
+// ---- K2: (identity | DW conv | DW conv-transpose) producer -> 1x1 GEMM -> epilogue ---------
+struct DwPwArgs {
+    const float* X;       // [B, K, Tin]
+    const float* dw_w;    // mode 1: [K, ks]; mode 2: [K, 2r]; mode 0: unused
+    PwWeight pw;
+    const float* bias;    // [M] or null
+    float* Y;             // [B, M, Tout]
+    int B, Tin, Tout, mode, ks, ratio;
+    float pre_scale;
+    int pre_elu;
+    int l2norm;           // normalise over channels * sqrt(M) (needs M <= 128)
+    int accumulate;       // Y += out_scale * result
+    float out_scale;
+};
+hipError_t launch_dw_pw(const DwPwArgs& a, hipStream_t s);
+
+// ---- K3a: causal STFT log-magnitude ---------------------------------------------------------
+// basis_t[n_fft][Mp]: column 2f = windowed cos row f, column 2f+1 = windowed sin row f.
+struct StftArgs {
+    const float* wav;     // [B, 1, T]
+    const float* basis_t;
+    float* P;             // [B, F, Tf]
+    int B, T, Tf, n_fft, hop, F, Mp;
+    float mean, inv_std;
+};
+hipError_t launch_stft_logmag(const StftArgs& a, hipStream_t s);
+
+// ---- K4: conv_pre ---------------------------------------------------------------------------
+hipError_t launch_conv_pre(const float* x, const float* w, const float* bias, float* Y, int B,
+                           int C, int T, int ks, float in_scale, hipStream_t s);
+
+// ---- K5: decoder tail -----------------------------------------------------------------------
+hipError_t launch_tail(const float* H, const float* w, const float* bias, const float* x,
+                       float* out, int B, int C, int Tin, int T, int ks, float pre_scale,
+                       float out_scale, hipStream_t s);
+
+// ---- K6: detector / locator head ------------------------------------------------------------
+// wc[D][nb*hop] = sum_o w_last[n][o] * w_rev[d][o][j]; bc[nb] = w_last @ b_rev + b_last.
+struct HeadArgs {
+    const float* Z;       // [B, D, Fr]
+    const float* wc;
+    const float* bc;
+    float* logits;        // [B, nb, T] or null
+    float* mean_prob;     // [B, nb] or null
+    int B, D, nb, hop, Fr, T;
+};
+hipError_t launch_head(const HeadArgs& a, hipStream_t s);
+
+// ---- K7: message MLP + FiLM parameters ------------------------------------------------------
+struct FilmArgs {
+    const float* msg;     // [rows, msg_dim]
+    int msg_rows, msg_dim, E, n_layers, n_out;
+    const float* w0; const float* b0;          // [E, msg_dim], [E]
+    const float* wl; const float* bl;          // [n_layers, E, E], [n_layers, E]
+    const float* wf; const float* bf;          // [n_out, E], [n_out]
+    float* film;          // [B, n_out]
+    int B;
+};
+hipError_t launch_film(const FilmArgs& a, hipStream_t s);
+
+}  // namespace wv

@@ -1,0 +1,637 @@
+// gfx950 (MI355X / CDNA4) kernels of the WaveVerify embed/detect hot path.
+//
+// Everything dense (1x1 convs, DFT basis, detector head) runs through ONE tiled GEMM core on
+// the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (k-ordered fmaf chain, so results
+// are float32-faithful to the reference's fp32 convs); the stencils that surround each GEMM
+// in the reference (scale -> ELU prologue, causal depth-wise conv / conv-transpose, FiLM,
+// residual, L2-norm, log-magnitude) are fused into the GEMM's operand loader or its epilogue so
+// every activation crosses HBM once per fused unit.
+//
+// Layout: activations [B, C, T] float32, time innermost.  GEMM roles: A = weights W^T packed
+// [Kp][Mp] (k-major, so an MFMA A-fragment is 32 consecutive floats), B = activations
+// [K][time] (k-major too), D[m][t].  64-lane wavefronts, 4 waves per workgroup.
+#include "wv_kernels.h"
+
+namespace wv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int NT_ = 256;   // threads per workgroup
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
+__device__ __forceinline__ float act(float x, float scale, int elu) {
+    x *= scale;
+    return elu ? elu1(x) : x;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------
+// GEMM core.  Tile BM x BN per workgroup, WM x WN waves, each wave MT x NT MFMA tiles of 32x32.
+// Operands are fetched by loader functors (global -> registers, with whatever fused prologue),
+// committed to LDS one K-chunk ahead (register prefetch + double-buffered LDS, one barrier per
+// chunk), and consumed by ds_read_b32 fragments: lane l reads row k+(l>>5), column base+(l&31),
+// i.e. 32 consecutive floats per half-wave -> conflict-free.
+// ------------------------------------------------------------------------------------------
+template <int BM_, int BN_, int WM_, int WN_>
+struct Tile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int MT = BM / (32 * WM);
+    static constexpr int NT = BN / (32 * WN);
+    static constexpr int A_PER = BK * BM / NT_;
+    static constexpr int B_PER = BK * BN / NT_;
+    static constexpr int BKSTEP = NT_ / BN;              // k rows covered per B slot
+    static constexpr int STAGE = BK * (BM + BN);         // floats per LDS stage
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(MT >= 1 && NT >= 1, "tile too small for the wave grid");
+    static_assert((BK * BM) % NT_ == 0 && (BK * BN) % NT_ == 0 && NT_ % BN == 0, "staging map");
+};
+
+template <class T>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[T::MT][T::NT]) {
+#pragma unroll
+    for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < T::NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// LA: float load(int k, int m)            (m in [0,BM))
+// LB: void init(int col); float load(int k)   (col in [0,BN) fixed per thread)
+template <class T, class LA, class LB>
+__device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::MT][T::NT], const LA& la, LB& lb,
+                                              int nchunks, float* smem) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN;
+    const int bcol = tid % T::BN, bk0 = tid / T::BN;
+    float ra[T::A_PER], rb[T::B_PER];
+    lb.init(bcol);
+
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < T::A_PER; ++r) {
+            const int e = tid + r * NT_;
+            ra[r] = la.load(c * BK + e / T::BM, e % T::BM);
+        }
+#pragma unroll
+        for (int r = 0; r < T::B_PER; ++r) rb[r] = lb.load(c * BK + bk0 + r * T::BKSTEP);
+    };
+    auto commit = [&](float* buf) {
+        float* As = buf;
+        float* Bs = buf + BK * T::BM;
+#pragma unroll
+        for (int r = 0; r < T::A_PER; ++r) As[tid + r * NT_] = ra[r];
+#pragma unroll
+        for (int r = 0; r < T::B_PER; ++r) Bs[(bk0 + r * T::BKSTEP) * T::BN + bcol] = rb[r];
+    };
+
+    fetch(0);
+    commit(smem);
+    __syncthreads();
+    const int arow = (lane >> 5), acol = wm * T::MT * 32 + (lane & 31);
+    const int bcol_f = wn * T::NT * 32 + (lane & 31);
+    for (int c = 0; c < nchunks; ++c) {
+        const float* As = smem + (c & 1) * T::STAGE;
+        const float* Bs = As + BK * T::BM;
+        if (c + 1 < nchunks) fetch(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[T::MT], b[T::NT];
+#pragma unroll
+            for (int i = 0; i < T::MT; ++i) a[i] = As[(kk + arow) * T::BM + acol + i * 32];
+#pragma unroll
+            for (int j = 0; j < T::NT; ++j) b[j] = Bs[(kk + arow) * T::BN + bcol_f + j * 32];
+#pragma unroll
+            for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+                for (int j = 0; j < T::NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) commit(smem + ((c + 1) & 1) * T::STAGE);
+        __syncthreads();
+    }
+}
+
+// Visit every accumulator element with its (row, col) inside the workgroup tile.
+// C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <class T, class F>
+__device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[T::MT][T::NT], F&& f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN;
+#pragma unroll
+    for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < T::NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * T::MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = wn * T::NT * 32 + j * 32 + (lane & 31);
+                f(row, col, acc[i][j][r]);
+            }
+}
+
+struct WLoader {                       // packed Wt[Kp][Mp]
+    const float* wt; int Mp, m0;
+    __device__ __forceinline__ float load(int k, int m) const { return wt[(size_t)k * Mp + m0 + m]; }
+};
+
+// ------------------------------------------------------------------------------------------
+// K1  pw_dw:  Y = epi( DWconv(W @ act(s*X)) + b )
+// One workgroup: (m-tile, time-tile, clip).  The GEMM produces H[BM][BN] for the input-time
+// window the output tile needs (halo = (ks-1)*d - (s-1) on the left, recomputed per tile);
+// H goes to LDS (aliasing the staging buffers) and the depth-wise stencil + FiLM / residual
+// epilogue reads it back with time on the lanes, so global stores are coalesced.
+// Zero padding: X is staged as 0 outside [0,Tin) and the 1x1 has no bias, so H is 0 there,
+// which is exactly the zero pad SConv1d inserts between the 1x1 and the DW conv.
+// ------------------------------------------------------------------------------------------
+struct XLoaderPw {
+    const float* Xb; int K, Tin, ti0; float scale; int elu;
+    const float* p; bool inb;
+    __device__ __forceinline__ void init(int col) {
+        const int ti = ti0 + col;
+        inb = ti >= 0 && ti < Tin;
+        p = Xb + (inb ? ti : 0);
+    }
+    __device__ __forceinline__ float load(int k) const {
+        return (inb && k < K) ? act(p[(size_t)k * Tin], scale, elu) : 0.f;
+    }
+};
+
+template <class T>
+__global__ __launch_bounds__(NT_) void pw_dw_kernel(PwDwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HLD = T::BN + 4;
+    const int m0 = blockIdx.x * T::BM;
+    const int b = blockIdx.z;
+    const int M = p.pw.M, K = p.pw.K;
+    const int tto = (T::BN - (p.ks - 1) * p.dil - 1) / p.stride + 1;   // outputs per tile
+    const int to0 = blockIdx.y * tto;
+    const int ti0 = to0 * p.stride - p.pad;
+
+    f32x16 acc[T::MT][T::NT];
+    zero_acc<T>(acc);
+    WLoader la{p.pw.wt, p.pw.Mp, m0};
+    XLoaderPw lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, false};
+    gemm_mainloop<T>(acc, la, lb, p.pw.Kp / BK, smem);
+
+    float* Hs = smem;                                    // [BM][HLD], aliases the stages
+    for_each_acc<T>(acc, [&](int row, int col, float v) { Hs[row * HLD + col] = v; });
+    __syncthreads();
+
+    const int bw = p.film ? (M / p.bands) : 1;
+    const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
+    int o = threadIdx.x % tto, m = threadIdx.x / tto;
+    const int dm = NT_ / tto, dq = NT_ % tto;
+    while (m < T::BM) {
+        const int gm = m0 + m, to = to0 + o;
+        if (gm < M && to < p.Tout) {
+            float y = p.dw_b ? p.dw_b[gm] : 0.f;
+            const float* h = Hs + m * HLD + o * p.stride;
+            const float* w = p.dw_w + (size_t)gm * p.ks;
+            for (int i = 0; i < p.ks; ++i) y = fmaf(w[i], h[i * p.dil], y);
+            if (filmb) {
+                const int band = gm / bw;
+                y = y * filmb[2 * band] + filmb[2 * band + 1];
+            }
+            const size_t oi = ((size_t)b * M + gm) * p.Tout + to;
+            if (p.resid) y = y * p.out_scale + p.resid[oi];
+            if (p.post_elu) y = elu1(y * p.post_scale);
+            p.Y[oi] = y;
+        }
+        o += dq; m += dm;
+        if (o >= tto) { o -= tto; ++m; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2  dw_pw:  Y = epi( W @ producer(X) + b ), producer fused into the B-operand loader.
+// ------------------------------------------------------------------------------------------
+struct XLoaderDw {
+    const float* Xb; const float* dw_w; int K, Tin, Tout, t0, mode, ks, ratio; float scale; int elu;
+    int t, l, ph; bool inb;
+    __device__ __forceinline__ void init(int col) {
+        t = t0 + col;
+        inb = t < Tout;
+        l = 0; ph = 0;
+        if (mode == 2) { l = t / ratio; ph = t - l * ratio; }
+    }
+    __device__ __forceinline__ float load(int k) const {
+        if (!inb || k >= K) return 0.f;
+        const float* xr = Xb + (size_t)k * Tin;
+        if (mode == 0) return act(xr[t], scale, elu);
+        if (mode == 1) {                           // causal depth-wise conv, stride 1, no bias
+            const float* w = dw_w + (size_t)k * ks;
+            float v = 0.f;
+            for (int i = 0; i < ks; ++i) {
+                const int ti = t - (ks - 1) + i;
+                if (ti >= 0) v = fmaf(w[i], act(xr[ti], scale, elu), v);
+            }
+            return v;
+        }
+        // mode 2: depth-wise ConvTranspose k=2r, s=r, right-trimmed by r (polyphase form)
+        const float* w = dw_w + (size_t)k * 2 * ratio;
+        float v = act(xr[l], scale, elu) * w[ph];
+        if (l >= 1) v = fmaf(act(xr[l - 1], scale, elu), w[ph + ratio], v);
+        return v;
+    }
+};
+
+template <class T>
+__global__ __launch_bounds__(NT_) void dw_pw_kernel(DwPwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int m0 = blockIdx.x * T::BM;
+    const int t0 = blockIdx.y * T::BN;
+    const int b = blockIdx.z;
+    const int M = p.pw.M, K = p.pw.K;
+
+    f32x16 acc[T::MT][T::NT];
+    zero_acc<T>(acc);
+    WLoader la{p.pw.wt, p.pw.Mp, m0};
+    XLoaderDw lb{p.X + (size_t)b * K * p.Tin, p.dw_w, K, p.Tin, p.Tout, t0, p.mode, p.ks, p.ratio,
+                 p.pre_scale, p.pre_elu, 0, 0, 0, false};
+    gemm_mainloop<T>(acc, la, lb, p.pw.Kp / BK, smem);
+
+    float* Yb = p.Y + (size_t)b * M * p.Tout;
+    if (p.l2norm) {
+        // L2Norm over channels (seanet.py:288-318); host guarantees a single m-tile (M <= BM).
+        float* red = smem;                               // [WM][BN]
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave / T::WN, wn = wave % T::WN;
+        float ss[T::NT];
+#pragma unroll
+        for (int j = 0; j < T::NT; ++j) ss[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < T::NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * T::MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = 0.f;
+                    if (row < M) v = acc[i][j][r] + (p.bias ? p.bias[row] : 0.f);
+                    acc[i][j][r] = v;
+                    ss[j] = fmaf(v, v, ss[j]);
+                }
+#pragma unroll
+        for (int j = 0; j < T::NT; ++j) {
+            ss[j] += __shfl_xor(ss[j], 32);
+            if (lane < 32) red[wm * T::BN + wn * T::NT * 32 + j * 32 + lane] = ss[j];
+        }
+        __syncthreads();
+        const float sq = sqrtf((float)M);
+        for_each_acc<T>(acc, [&](int row, int col, float v) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < T::WM; ++w) tot += red[w * T::BN + col];
+            const int t = t0 + col;
+            if (row < M && t < p.Tout)
+                Yb[(size_t)row * p.Tout + t] = v / fmaxf(sqrtf(tot), 1e-12f) * sq;
+        });
+        return;
+    }
+    for_each_acc<T>(acc, [&](int row, int col, float v) {
+        const int gm = m0 + row, t = t0 + col;
+        if (gm < M && t < p.Tout) {
+            const size_t oi = (size_t)gm * p.Tout + t;
+            if (p.accumulate) Yb[oi] = fmaf(p.out_scale, v, Yb[oi]);
+            else Yb[oi] = v + (p.bias ? p.bias[gm] : 0.f);
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// K3a  causal STFT -> log-magnitude -> affine.  GEMM with A = interleaved (cos,sin) basis and
+// B = frames gathered on the fly from the waveform (left zero history only at true t < 0).
+// An accumulator register pair (2q, 2q+1) of one lane is (re, im) of one bin, so the
+// magnitude needs no cross-lane traffic.
+// ------------------------------------------------------------------------------------------
+struct FrameLoader {
+    const float* wb; int T, Tf, n_fft, hop, t0;
+    int base; bool inb;
+    __device__ __forceinline__ void init(int col) {
+        const int t = t0 + col;
+        inb = t < Tf;
+        base = t * hop - (n_fft - 1);
+    }
+    __device__ __forceinline__ float load(int k) const {
+        const int idx = base + k;
+        return (inb && k < n_fft && idx >= 0 && idx < T) ? wb[idx] : 0.f;
+    }
+};
+
+template <class T>
+__global__ __launch_bounds__(NT_) void stft_logmag_kernel(StftArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int m0 = blockIdx.x * T::BM;
+    const int t0 = blockIdx.y * T::BN;
+    const int b = blockIdx.z;
+    f32x16 acc[T::MT][T::NT];
+    zero_acc<T>(acc);
+    WLoader la{p.basis_t, p.Mp, m0};
+    FrameLoader lb{p.wav + (size_t)b * p.T, p.T, p.Tf, p.n_fft, p.hop, t0, 0, false};
+    gemm_mainloop<T>(acc, la, lb, (p.n_fft + BK - 1) / BK, smem);
+
+    float* Pb = p.P + (size_t)b * p.F * p.Tf;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN;
+#pragma unroll
+    for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < T::NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int row = m0 + wm * T::MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int t = t0 + wn * T::NT * 32 + j * 32 + (lane & 31);
+                const int f = row >> 1;                  // row even: (re, im) = regs (r, r+1)
+                if (f < p.F && t < p.Tf) {
+                    const float re = acc[i][j][r], im = acc[i][j][r + 1];
+                    const float mag = sqrtf(fmaxf(fmaf(re, re, im * im), 1e-12f));   // conv.py:1078
+                    Pb[(size_t)f * p.Tf + t] = (__logf(fmaxf(mag, 1e-5f)) - p.mean) * p.inv_std;
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4  conv_pre: Conv1d(1 -> C, k) on x*in_scale (seanet.py:657-664).  HBM-bound: one read of
+// x, C coalesced row writes.
+// ------------------------------------------------------------------------------------------
+constexpr int MAX_KS = 16;
+
+__global__ __launch_bounds__(NT_) void conv_pre_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ Y, int C, int T, int ks,
+                                                       float in_scale) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * NT_ + threadIdx.x;
+    if (t >= T) return;
+    const float* xb = x + (size_t)b * T;
+    float xv[MAX_KS];
+#pragma unroll
+    for (int i = 0; i < MAX_KS; ++i) {
+        const int ti = t - (ks - 1) + i;
+        xv[i] = (i < ks && ti >= 0) ? xb[ti] * in_scale : 0.f;
+    }
+    float* yb = Y + (size_t)b * C * T + t;
+    for (int c = 0; c < C; ++c) {
+        float y = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MAX_KS; ++i)
+            if (i < ks) y = fmaf(w[c * ks + i], xv[i], y);
+        yb[(size_t)c * T] = y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5  decoder tail: tanh(out_scale*(Conv1d(C -> 1, k)(ELU(s*H)) + b)) (+ x).  HBM-bound read of
+// H[B,C,Tin].  Each wave owns 64 consecutive input columns (ks-1 of them halo); a lane
+// activates its own column once and gets its ks-1 left neighbours by wave shuffles.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT_) void tail_kernel(const float* __restrict__ H,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ bias,
+                                                   const float* __restrict__ x,
+                                                   float* __restrict__ out, int C, int Tin, int T,
+                                                   int ks, float pre_scale, float out_scale) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per_wave = 64 - (ks - 1);
+    const int t = (blockIdx.x * 4 + wave) * per_wave - (ks - 1) + lane;   // this lane's column
+    const bool inb = t >= 0 && t < Tin;
+    const float* hb = H + (size_t)b * C * Tin + (inb ? t : 0);
+    float y = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float e = inb ? elu1(hb[(size_t)c * Tin] * pre_scale) : 0.f;
+        const float* wc = w + c * ks;
+        y = fmaf(wc[ks - 1], e, y);
+        for (int i = 1; i < ks; ++i) {
+            const float ei = __shfl_up(e, i);          // lanes < i get garbage; they are halo lanes
+            y = fmaf(wc[ks - 1 - i], ei, y);
+        }
+    }
+    if (lane >= ks - 1 && t < T) {
+        float v = tanhf((y + (bias ? bias[0] : 0.f)) * out_scale);
+        if (x) v += x[(size_t)b * T + t];
+        out[(size_t)b * T + t] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6  detector / locator head.  The reference's ConvTranspose1d(k = s = hop) -> trim ->
+// Conv1d(O -> nb, 1) is one GEMM per frame against the composed weight wc[D][nb*hop].
+// Workgroup = (bit, clip): rows = frames of the clip, cols = the hop samples of that bit.
+// sigmoid + mean over time are reduced in-register, so for detect() the [B,nb,T] logits
+// never reach HBM (core.py:577-580); summation order is fixed -> deterministic.
+// ------------------------------------------------------------------------------------------
+struct ZLoader {
+    const float* Zb; int D, Fr, f0;
+    __device__ __forceinline__ float load(int k, int m) const {
+        const int f = f0 + m;
+        return (k < D && f < Fr) ? Zb[(size_t)k * Fr + f] : 0.f;
+    }
+};
+struct WcLoader {
+    const float* wc; int D, ld, hop, j0; const float* p; bool inb;
+    __device__ __forceinline__ void init(int col) {
+        inb = j0 + col < hop;
+        p = wc + (inb ? j0 + col : 0);
+    }
+    __device__ __forceinline__ float load(int k) const { return (inb && k < D) ? p[(size_t)k * ld] : 0.f; }
+};
+
+template <class T>
+__global__ __launch_bounds__(NT_) void head_kernel(HeadArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bit = blockIdx.x, b = blockIdx.y;
+    const float bc = p.bc[bit];
+    float psum = 0.f;
+    const int nchunks = (p.D + BK - 1) / BK;
+    for (int f0 = 0; f0 < p.Fr; f0 += T::BM) {
+        for (int j0 = 0; j0 < p.hop; j0 += T::BN) {
+            f32x16 acc[T::MT][T::NT];
+            zero_acc<T>(acc);
+            ZLoader la{p.Z + (size_t)b * p.D * p.Fr, p.D, p.Fr, f0};
+            WcLoader lb{p.wc + (size_t)bit * p.hop, p.D, p.nb * p.hop, p.hop, j0, nullptr, false};
+            gemm_mainloop<T>(acc, la, lb, nchunks, smem);
+            for_each_acc<T>(acc, [&](int row, int col, float v) {
+                const int f = f0 + row, j = j0 + col;
+                const int t = f * p.hop + j;
+                if (f < p.Fr && j < p.hop && t < p.T) {
+                    const float lg = v + bc;
+                    if (p.logits) p.logits[((size_t)b * p.nb + bit) * p.T + t] = lg;
+                    psum += sigmoidf_(lg);
+                }
+            });
+        }
+    }
+    if (p.mean_prob) {
+        float* red = smem;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) psum += __shfl_xor(psum, off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = psum;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            p.mean_prob[(size_t)b * p.nb + bit] = (red[0] + red[1] + red[2] + red[3]) / (float)p.T;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7  message MLP + FiLM gammas/betas (seanet.py:831-846, 905-912).  One workgroup per clip.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT_) void film_kernel(FilmArgs p) {
+    __shared__ float h0[NT_], h1[NT_];
+    const int b = blockIdx.x, e = threadIdx.x;
+    const float* msg = p.msg + (size_t)(p.msg_rows == 1 ? 0 : b) * p.msg_dim;
+    if (e < p.E) {
+        float v = p.b0[e];
+        for (int i = 0; i < p.msg_dim; ++i) v = fmaf(p.w0[e * p.msg_dim + i], msg[i], v);
+        h0[e] = v;                                     // no ReLU after the first Linear
+    }
+    __syncthreads();
+    float* cur = h0;
+    float* nxt = h1;
+    for (int l = 0; l < p.n_layers; ++l) {
+        if (e < p.E) {
+            const float* w = p.wl + ((size_t)l * p.E + e) * p.E;
+            float v = p.bl[l * p.E + e];
+            for (int i = 0; i < p.E; ++i) v = fmaf(w[i], cur[i], v);
+            nxt[e] = fmaxf(v, 0.f);
+        }
+        __syncthreads();
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    for (int o = e; o < p.n_out; o += NT_) {
+        float v = p.bf[o];
+        for (int i = 0; i < p.E; ++i) v = fmaf(p.wf[(size_t)o * p.E + i], cur[i], v);
+        p.film[(size_t)b * p.n_out + o] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Launchers
+// ------------------------------------------------------------------------------------------
+template <class T>
+static constexpr size_t stage_bytes() { return 2 * (size_t)T::STAGE * sizeof(float); }
+
+template <class K>
+static hipError_t set_smem(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <class T>
+static hipError_t run_pw_dw(const PwDwArgs& a, hipStream_t s) {
+    const int tto = (T::BN - (a.ks - 1) * a.dil - 1) / a.stride + 1;
+    if (tto < 1 || tto > NT_) return hipErrorInvalidValue;
+    size_t smem = stage_bytes<T>();
+    const size_t hb = (size_t)T::BM * (T::BN + 4) * sizeof(float);
+    if (hb > smem) smem = hb;
+    hipError_t e = set_smem(pw_dw_kernel<T>, smem);
+    if (e != hipSuccess) return e;
+    dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + tto - 1) / tto, a.B);
+    hipLaunchKernelGGL(pw_dw_kernel<T>, grid, dim3(NT_), smem, s, a);
+    return hipGetLastError();
+}
+
+static int pick_bm(int M) {
+    if (M <= 32) return 32;
+    if (M <= 64) return 64;
+    if (M <= 96) return 96;
+    if (M % 128 == 0) return 128;
+    if (M % 96 == 0) return 96;
+    return 128;
+}
+
+hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
+    if (a.ks < 1 || a.stride < 1 || a.dil < 1 || a.pw.Mp % M_ALIGN || a.pw.Kp % BK)
+        return hipErrorInvalidValue;
+    const int need = (a.ks - 1) * a.dil + 1;            // H columns one output needs
+    const bool narrow = a.Tin + a.pad <= 64 && need <= 64;
+    if (narrow) {
+        if (pick_bm(a.pw.M) <= 64) return run_pw_dw<Tile<64, 64, 2, 2>>(a, s);
+        return run_pw_dw<Tile<128, 64, 2, 2>>(a, s);
+    }
+    switch (pick_bm(a.pw.M)) {
+        case 32: return run_pw_dw<Tile<32, 128, 1, 4>>(a, s);
+        case 64: return run_pw_dw<Tile<64, 128, 1, 4>>(a, s);
+        case 96: return run_pw_dw<Tile<96, 128, 1, 4>>(a, s);
+        default: return run_pw_dw<Tile<128, 128, 1, 4>>(a, s);
+    }
+}
+
+template <class T>
+static hipError_t run_dw_pw(const DwPwArgs& a, hipStream_t s) {
+    const size_t smem = stage_bytes<T>();
+    if (a.l2norm && a.pw.M > T::BM) return hipErrorInvalidValue;
+    dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + T::BN - 1) / T::BN, a.B);
+    hipLaunchKernelGGL(dw_pw_kernel<T>, grid, dim3(NT_), smem, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dw_pw(const DwPwArgs& a, hipStream_t s) {
+    if (a.pw.Mp % M_ALIGN || a.pw.Kp % BK || a.mode < 0 || a.mode > 2) return hipErrorInvalidValue;
+    if (a.mode == 2 && a.Tout != a.Tin * a.ratio) return hipErrorInvalidValue;
+    if (a.mode != 2 && a.Tout != a.Tin) return hipErrorInvalidValue;
+    int bm = pick_bm(a.pw.M);
+    if (a.l2norm) bm = a.pw.M <= 64 ? 64 : 128;
+    if (a.Tout <= 64) {
+        if (bm <= 64) return run_dw_pw<Tile<64, 64, 2, 2>>(a, s);
+        return run_dw_pw<Tile<128, 64, 2, 2>>(a, s);
+    }
+    switch (bm) {
+        case 32: return run_dw_pw<Tile<32, 128, 1, 4>>(a, s);
+        case 64: return run_dw_pw<Tile<64, 128, 1, 4>>(a, s);
+        case 96: return run_dw_pw<Tile<96, 128, 1, 4>>(a, s);
+        default: return run_dw_pw<Tile<128, 128, 1, 4>>(a, s);
+    }
+}
+
+template <class T>
+static hipError_t run_stft(const StftArgs& a, hipStream_t s) {
+    dim3 grid((2 * a.F + T::BM - 1) / T::BM, (a.Tf + T::BN - 1) / T::BN, a.B);
+    hipLaunchKernelGGL(stft_logmag_kernel<T>, grid, dim3(NT_), stage_bytes<T>(), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_stft_logmag(const StftArgs& a, hipStream_t s) {
+    if (a.Mp % M_ALIGN || a.Mp < 2 * a.F) return hipErrorInvalidValue;
+    if (a.Tf <= 64) return run_stft<Tile<128, 64, 2, 2>>(a, s);
+    if (2 * a.F <= 64) return run_stft<Tile<64, 128, 1, 4>>(a, s);
+    if (2 * a.F <= 96) return run_stft<Tile<96, 128, 1, 4>>(a, s);
+    return run_stft<Tile<128, 128, 1, 4>>(a, s);
+}
+
+hipError_t launch_conv_pre(const float* x, const float* w, const float* bias, float* Y, int B,
+                           int C, int T, int ks, float in_scale, hipStream_t s) {
+    if (ks < 1 || ks > MAX_KS) return hipErrorInvalidValue;
+    dim3 grid((T + NT_ - 1) / NT_, B);
+    hipLaunchKernelGGL(conv_pre_kernel, grid, dim3(NT_), 0, s, x, w, bias, Y, C, T, ks, in_scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_tail(const float* H, const float* w, const float* bias, const float* x,
+                       float* out, int B, int C, int Tin, int T, int ks, float pre_scale,
+                       float out_scale, hipStream_t s) {
+    if (ks < 1 || ks > 32 || T > Tin) return hipErrorInvalidValue;
+    const int per_block = 4 * (64 - (ks - 1));
+    dim3 grid((T + per_block - 1) / per_block, B);
+    hipLaunchKernelGGL(tail_kernel, grid, dim3(NT_), 0, s, H, w, bias, x, out, C, Tin, T, ks,
+                       pre_scale, out_scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
+    using T = Tile<64, 64, 2, 2>;
+    dim3 grid(a.nb, a.B);
+    hipLaunchKernelGGL(head_kernel<T>, grid, dim3(NT_), stage_bytes<T>(), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_film(const FilmArgs& a, hipStream_t s) {
+    if (a.E > NT_ || a.E < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(film_kernel, dim3(a.B), dim3(NT_), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace wv

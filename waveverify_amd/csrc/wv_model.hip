@@ -1,0 +1,782 @@
+// Host side of libwaveverify_hip.so: parameter table (reference state-dict grammar), weight
+// packing, the launch plan of the three nets, and the extern "C" API of
+// include/waveverify_hip.h.  No torch here: raw device pointers + a hipStream_t.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/waveverify_hip.h"
+#include "wv_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(WV_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+struct Param {
+    std::string name;
+    std::vector<int64_t> shape;   // reference layout
+    bool wn = false;
+    bool optional = false;        // message MLP / FiLM of a detector/locator encoder
+    std::vector<float> data;
+    bool set = false;
+    int64_t numel() const { int64_t n = 1; for (auto d : shape) n *= d; return n; }
+};
+
+using wv::PwWeight;
+
+struct ResBlock {
+    PwWeight pw1, pw2;
+    const float *dw1_w, *dw1_b, *dw2_w, *dw2_b;
+    float pre_scale, out_scale;
+    int ks, dil1, dil2;
+};
+struct SpecLayer {
+    const float* basis_t; int n_fft, hop, F, Mp; float mean, inv_std;
+    PwWeight pw; float scale;
+};
+struct DownLayer { PwWeight pw; const float *dw_w, *dw_b; int ratio; float pre_scale; };
+struct UpLayer {
+    const float* ct_w; int ratio; PwWeight pw; const float* pw_b; float pre_scale;
+    std::vector<ResBlock> res;
+};
+
+}  // namespace
+
+struct wv_model {
+    wv_config cfg{};
+    std::vector<Param> params;
+    std::unordered_map<std::string, int> index;
+    std::unordered_map<std::string, std::vector<float>> stft_override;
+    bool finalized = false;
+    std::vector<void*> dev;                      // owned device allocations
+
+    // ---- encoder plan
+    const float *pre_w = nullptr, *pre_b = nullptr;
+    std::vector<std::vector<ResBlock>> enc_blocks;
+    std::vector<SpecLayer> specs;                // n_scales + 1 (last = spec_post)
+    std::vector<DownLayer> downs;
+    const float* post_dw_w = nullptr; PwWeight post_pw; const float* post_b = nullptr;
+    bool has_film = false;
+    const float *f_w0 = nullptr, *f_b0 = nullptr, *f_wl = nullptr, *f_bl = nullptr,
+                *f_wf = nullptr, *f_bf = nullptr;
+    // ---- decoder plan
+    PwWeight dec_pw0; const float *dec_dw0_w = nullptr, *dec_dw0_b = nullptr;
+    std::vector<UpLayer> ups;
+    const float *last_w = nullptr, *last_b = nullptr;
+    float dec_post = 1.f;
+    // ---- head plan
+    const float *head_wc = nullptr, *head_bc = nullptr;
+    int head_nb = 0;
+
+    ~wv_model() { for (void* p : dev) (void)hipFree(p); }
+};
+
+namespace {
+
+int hop_of(const wv_config& c) { int h = 1; for (int i = 0; i < c.n_strides; ++i) h *= c.strides[i]; return h; }
+int ratio_enc(const wv_config& c, int s) { return c.strides[c.n_strides - 1 - s]; }   // seanet.py:646
+
+void add(wv_model* m, const std::string& name, std::vector<int64_t> shape, bool wn, bool optional = false) {
+    Param p; p.name = name; p.shape = std::move(shape); p.wn = wn; p.optional = optional;
+    m->index[name] = (int)m->params.size();
+    m->params.push_back(std::move(p));
+}
+
+void add_resblock(wv_model* m, const std::string& pre, int dim, int k, bool zero_init) {
+    if (zero_init) add(m, pre + ".res_scale_param", {1}, false);
+    const int idx[2][2] = {{1, 2}, {4, 5}};
+    for (auto& pd : idx) {
+        add(m, pre + ".block." + std::to_string(pd[0]) + ".conv.conv.weight", {dim, dim, 1}, true);
+        add(m, pre + ".block." + std::to_string(pd[1]) + ".conv.conv.bias", {dim}, false);
+        add(m, pre + ".block." + std::to_string(pd[1]) + ".conv.conv.weight", {dim, 1, k}, true);
+    }
+}
+
+// Key grammar: modules/seanet.py:657-846 (encoder), :1067-1204 (decoder), detector.py:209-218.
+void build_param_table(wv_model* m) {
+    const wv_config& c = m->cfg;
+    const int C0 = c.channels_enc, S = c.n_strides;
+    const bool zi = c.zero_init != 0;
+    add(m, "encoder.conv_pre.1.conv.conv.bias", {C0}, false);
+    add(m, "encoder.conv_pre.1.conv.conv.weight", {C0, 1, c.kernel_size}, true);
+    int mult = 1;
+    for (int s = 0; s < S; ++s) {
+        for (int j = 0; j < c.n_residual_enc; ++j)
+            add_resblock(m, "encoder.blocks." + std::to_string(s) + "." + std::to_string(j),
+                         mult * C0, c.residual_kernel_size, zi);
+        mult *= 2;
+    }
+    mult = 1;
+    for (int s = 0; s < S; ++s) {
+        const std::string pre = "encoder.spec_blocks." + std::to_string(s);
+        if (zi) add(m, pre + ".scale_param", {1}, false);
+        add(m, pre + ".layer.conv.conv.weight", {mult * C0, mult * c.n_fft_base / 2 + 1, 1}, true);
+        mult *= 2;
+    }
+    mult = 1;
+    for (int s = 0; s < S; ++s) {
+        const int C = mult * C0, r = ratio_enc(c, s);
+        const std::string pre = "encoder.downsample." + std::to_string(s);
+        add(m, pre + ".2.conv.conv.weight", {2 * C, C, 1}, true);
+        add(m, pre + ".3.conv.conv.bias", {2 * C}, false);
+        add(m, pre + ".3.conv.conv.weight", {2 * C, 1, 2 * r}, true);
+        mult *= 2;
+    }
+    const int Ctop = mult * C0;
+    if (zi) add(m, "encoder.spec_post.scale_param", {1}, false);
+    add(m, "encoder.spec_post.layer.conv.conv.weight", {Ctop, mult * c.n_fft_base / 2 + 1, 1}, true);
+    add(m, "encoder.conv_post.1.conv.conv.weight", {Ctop, 1, c.last_kernel_size}, true);
+    add(m, "encoder.conv_post.2.conv.conv.bias", {c.dimension}, false);
+    add(m, "encoder.conv_post.2.conv.conv.weight", {c.dimension, Ctop, 1}, true);
+    // message MLP + FiLM exist in every SEANetEncoder but only the generator's forward uses them
+    const bool opt = c.kind != WV_KIND_GENERATOR;
+    const int E = c.embedding_dim;
+    add(m, "encoder.msg_embedding.0.weight", {E, c.msg_dimension}, false, opt);
+    add(m, "encoder.msg_embedding.0.bias", {E}, false, opt);
+    for (int l = 0; l < c.embedding_layers; ++l) {
+        const std::string pre = "encoder.msg_embedding." + std::to_string(1 + 2 * l);
+        add(m, pre + ".weight", {E, E}, false, opt);
+        add(m, pre + ".bias", {E}, false, opt);
+    }
+    for (int s = 0; s < S; ++s)
+        for (int b = 0; b < c.freq_bands; ++b)
+            for (const char* nm : {"gamma", "beta"}) {
+                const std::string pre = "encoder.film_layers." + std::to_string(s) + "." +
+                                        std::to_string(b) + "." + nm + "_layer";
+                add(m, pre + ".weight", {1, E}, false, opt);
+                add(m, pre + ".bias", {1}, false, opt);
+            }
+    if (c.kind == WV_KIND_GENERATOR) {
+        const int Cd = c.channels_dec;
+        int dm = 1 << S;
+        add(m, "decoder.model.0.conv.conv.weight", {dm * Cd, c.dimension, 1}, true);
+        add(m, "decoder.model.1.conv.conv.bias", {dm * Cd}, false);
+        add(m, "decoder.model.1.conv.conv.weight", {dm * Cd, 1, c.kernel_size}, true);
+        int n = 2;
+        for (int i = 0; i < S; ++i) {
+            const int C = dm * Cd, r = c.strides[i];
+            add(m, "decoder.model." + std::to_string(n + 2) + ".convtr.convtr.weight", {C, 1, 2 * r}, true);
+            add(m, "decoder.model." + std::to_string(n + 3) + ".conv.conv.bias", {C / 2}, false);
+            add(m, "decoder.model." + std::to_string(n + 3) + ".conv.conv.weight", {C / 2, C, 1}, true);
+            for (int j = 0; j < c.n_residual_dec; ++j)
+                add_resblock(m, "decoder.model." + std::to_string(n + 4 + j), C / 2,
+                             c.residual_kernel_size, zi);
+            n += 4 + c.n_residual_dec;
+            dm /= 2;
+        }
+        add(m, "decoder.model." + std::to_string(n + 2) + ".conv.conv.bias", {1}, false);
+        add(m, "decoder.model." + std::to_string(n + 2) + ".conv.conv.weight", {1, Cd, c.last_kernel_size}, true);
+    } else {
+        const int nb = c.kind == WV_KIND_DETECTOR ? c.nbits : 1;
+        add(m, "reverse_convolution.weight", {c.dimension, c.output_dim, hop_of(c)}, false);
+        add(m, "reverse_convolution.bias", {c.output_dim}, false);
+        add(m, "last_layer.weight", {nb, c.output_dim, 1}, false);
+        add(m, "last_layer.bias", {nb}, false);
+    }
+}
+
+// ------------------------------------------------------------------------------ packing
+struct Uploader {
+    wv_model* m;
+    int err = WV_OK;
+    const float* up(const std::vector<float>& h) {
+        if (err != WV_OK) return nullptr;
+        void* d = nullptr;
+        const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(float);
+        if (hipMalloc(&d, bytes) != hipSuccess) { err = fail(WV_EHIP, "hipMalloc failed while packing weights"); return nullptr; }
+        m->dev.push_back(d);
+        if (!h.empty() && hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            err = fail(WV_EHIP, "hipMemcpy failed while packing weights");
+            return nullptr;
+        }
+        return static_cast<const float*>(d);
+    }
+    const std::vector<float>& host(const std::string& name) {
+        static const std::vector<float> empty;
+        auto it = m->index.find(name);
+        if (it == m->index.end()) { err = fail(WV_ENOKEY, "internal: unknown key " + name); return empty; }
+        return m->params[it->second].data;
+    }
+    const float* plain(const std::string& name) { return up(host(name)); }
+    float scalar_or(const std::string& name, float dflt) {
+        auto it = m->index.find(name);
+        return it == m->index.end() ? dflt : m->params[it->second].data[0];
+    }
+    // W[M][K] (a 1x1 conv weight [M,K,1]) -> Wt[Kp][Mp], zero padded
+    PwWeight pw_from(const std::vector<float>& w, int M, int K) {
+        PwWeight p; p.M = M; p.K = K; p.Kp = wv::round_up(K, wv::BK); p.Mp = wv::round_up(M, wv::M_ALIGN);
+        std::vector<float> t((size_t)p.Kp * p.Mp, 0.f);
+        for (int mm = 0; mm < M; ++mm)
+            for (int k = 0; k < K; ++k) t[(size_t)k * p.Mp + mm] = w[(size_t)mm * K + k];
+        p.wt = up(t);
+        return p;
+    }
+    PwWeight pw(const std::string& name) {
+        auto it = m->index.find(name);
+        const Param& P = m->params[it->second];
+        return pw_from(P.data, (int)P.shape[0], (int)P.shape[1]);
+    }
+};
+
+// CausalSTFT basis exactly as modules/conv.py:1003-1020 forms it: float32 angle
+// (-2*pi/n_fft) * k * n, cos / sin of that float32 angle, times torch.hann_window (periodic).
+std::vector<float> make_basis(int n_fft) {
+    const int F = n_fft / 2 + 1;
+    std::vector<float> w((size_t)2 * F * n_fft);
+    const float c = (float)(-2.0 * M_PI / n_fft);
+    const float wc = (float)(2.0 * M_PI / n_fft);
+    for (int k = 0; k < F; ++k) {
+        volatile float ck = c * (float)k;
+        for (int n = 0; n < n_fft; ++n) {
+            volatile float ang = ck * (float)n;
+            volatile float wa = (float)n * wc;
+            const float win = 0.5f - 0.5f * (float)std::cos((double)wa);
+            w[(size_t)k * n_fft + n] = (float)std::cos((double)ang) * win;
+            w[(size_t)(F + k) * n_fft + n] = (float)std::sin((double)ang) * win;
+        }
+    }
+    return w;
+}
+
+// [2F][n_fft] reference layout -> basis_t[Kp][Mp] with column 2f = cos row f, 2f+1 = sin row f
+const float* pack_basis(Uploader& U, const std::vector<float>& basis, int n_fft, int* Mp_out) {
+    const int F = n_fft / 2 + 1;
+    const int Mp = wv::round_up(2 * F, wv::M_ALIGN), Kp = wv::round_up(n_fft, wv::BK);
+    std::vector<float> t((size_t)Kp * Mp, 0.f);
+    for (int f = 0; f < F; ++f)
+        for (int n = 0; n < n_fft; ++n) {
+            t[(size_t)n * Mp + 2 * f] = basis[(size_t)f * n_fft + n];
+            t[(size_t)n * Mp + 2 * f + 1] = basis[(size_t)(F + f) * n_fft + n];
+        }
+    *Mp_out = Mp;
+    return U.up(t);
+}
+
+ResBlock pack_resblock(Uploader& U, const std::string& pre, int idx, float rs, int ks, int dil1) {
+    ResBlock r{};
+    r.pw1 = U.pw(pre + ".block.1.conv.conv.weight");
+    r.dw1_w = U.plain(pre + ".block.2.conv.conv.weight");
+    r.dw1_b = U.plain(pre + ".block.2.conv.conv.bias");
+    r.pw2 = U.pw(pre + ".block.4.conv.conv.weight");
+    r.dw2_w = U.plain(pre + ".block.5.conv.conv.weight");
+    r.dw2_b = U.plain(pre + ".block.5.conv.conv.bias");
+    r.pre_scale = (float)std::pow(1.0 + idx * (double)rs * rs, -0.5);      // seanet.py:183
+    r.out_scale = rs * U.scalar_or(pre + ".res_scale_param", 1.f);         // seanet.py:272-274
+    r.ks = ks; r.dil1 = dil1; r.dil2 = 1;                                   // dilations=[base**j, 1]
+    return r;
+}
+
+int ipow(int b, int e) { int r = 1; while (e-- > 0) r *= b; return r; }
+
+int pack_model(wv_model* m) {
+    const wv_config& c = m->cfg;
+    Uploader U{m};
+    const int S = c.n_strides, C0 = c.channels_enc;
+    const float rs = c.res_scale_enc;
+    m->pre_w = U.plain("encoder.conv_pre.1.conv.conv.weight");
+    m->pre_b = U.plain("encoder.conv_pre.1.conv.conv.bias");
+    int mult = 1, stride = 1;
+    for (int s = 0; s <= S; ++s) {
+        const bool post = s == S;
+        const std::string pre = post ? "encoder.spec_post" : "encoder.spec_blocks." + std::to_string(s);
+        if (!post) {
+            std::vector<ResBlock> blocks;
+            for (int j = 1; j <= c.n_residual_enc; ++j)                    // idx = j (seanet.py:684)
+                blocks.push_back(pack_resblock(U, "encoder.blocks." + std::to_string(s) + "." + std::to_string(j - 1),
+                                               j, rs, c.residual_kernel_size, ipow(c.dilation_base, j)));
+            m->enc_blocks.push_back(std::move(blocks));
+        }
+        SpecLayer sp{};
+        sp.n_fft = mult * c.n_fft_base; sp.hop = stride; sp.F = sp.n_fft / 2 + 1;
+        auto ov = m->stft_override.find(pre + ".spec.weight");
+        sp.basis_t = pack_basis(U, ov != m->stft_override.end() ? ov->second : make_basis(sp.n_fft),
+                                sp.n_fft, &sp.Mp);
+        const int mi = post ? WV_MAX_STRIDES : s;                           // spec_post uses [-1]
+        sp.mean = post ? c.spec_means[WV_MAX_STRIDES] : c.spec_means[s];
+        sp.inv_std = 1.f / (post ? c.spec_stds[WV_MAX_STRIDES] : c.spec_stds[s]);
+        (void)mi;
+        sp.pw = U.pw(pre + ".layer.conv.conv.weight");
+        sp.scale = U.scalar_or(pre + ".scale_param", 1.f) * rs;            // seanet.py:500-502
+        m->specs.push_back(sp);
+        if (!post) {
+            DownLayer d{};
+            const std::string dp = "encoder.downsample." + std::to_string(s);
+            d.pw = U.pw(dp + ".2.conv.conv.weight");
+            d.dw_w = U.plain(dp + ".3.conv.conv.weight");
+            d.dw_b = U.plain(dp + ".3.conv.conv.bias");
+            d.ratio = ratio_enc(c, s);
+            d.pre_scale = (float)std::pow(1.0 + c.n_residual_enc * (double)rs * rs, -0.5);   // seanet.py:739
+            m->downs.push_back(d);
+            stride *= d.ratio;
+            mult *= 2;
+        }
+    }
+    m->post_dw_w = U.plain("encoder.conv_post.1.conv.conv.weight");
+    m->post_pw = U.pw("encoder.conv_post.2.conv.conv.weight");
+    m->post_b = U.plain("encoder.conv_post.2.conv.conv.bias");
+    (void)C0;
+
+    // message MLP + FiLM (only when the tensors were provided; mandatory for the generator)
+    m->has_film = m->params[m->index["encoder.msg_embedding.0.weight"]].set;
+    if (m->has_film) {
+        const int E = c.embedding_dim;
+        m->f_w0 = U.plain("encoder.msg_embedding.0.weight");
+        m->f_b0 = U.plain("encoder.msg_embedding.0.bias");
+        std::vector<float> wl, bl, wf, bf;
+        for (int l = 0; l < c.embedding_layers; ++l) {
+            const std::string pre = "encoder.msg_embedding." + std::to_string(1 + 2 * l);
+            const auto& w = U.host(pre + ".weight"); const auto& b = U.host(pre + ".bias");
+            wl.insert(wl.end(), w.begin(), w.end()); bl.insert(bl.end(), b.begin(), b.end());
+        }
+        for (int s = 0; s < S; ++s)
+            for (int b = 0; b < c.freq_bands; ++b)
+                for (const char* nm : {"gamma", "beta"}) {
+                    const std::string pre = "encoder.film_layers." + std::to_string(s) + "." +
+                                            std::to_string(b) + "." + nm + "_layer";
+                    const auto& w = U.host(pre + ".weight"); const auto& bb = U.host(pre + ".bias");
+                    wf.insert(wf.end(), w.begin(), w.end()); bf.push_back(bb[0]);
+                }
+        m->f_wl = U.up(wl); m->f_bl = U.up(bl); m->f_wf = U.up(wf); m->f_bf = U.up(bf);
+        (void)E;
+    }
+
+    if (c.kind == WV_KIND_GENERATOR) {
+        const float rd = c.res_scale_dec;
+        m->dec_pw0 = U.pw("decoder.model.0.conv.conv.weight");
+        m->dec_dw0_w = U.plain("decoder.model.1.conv.conv.weight");
+        m->dec_dw0_b = U.plain("decoder.model.1.conv.conv.bias");
+        m->dec_post = (float)std::pow(1.0 + c.n_residual_dec * (double)rd * rd, -0.5);     // seanet.py:1104
+        int n = 2;
+        for (int i = 0; i < S; ++i) {
+            UpLayer u{};
+            u.ratio = c.strides[i];
+            u.ct_w = U.plain("decoder.model." + std::to_string(n + 2) + ".convtr.convtr.weight");
+            u.pw = U.pw("decoder.model." + std::to_string(n + 3) + ".conv.conv.weight");
+            u.pw_b = U.plain("decoder.model." + std::to_string(n + 3) + ".conv.conv.bias");
+            u.pre_scale = i > 0 ? m->dec_post : 1.f;
+            for (int j = 0; j < c.n_residual_dec; ++j)                     // idx = j (seanet.py:1159)
+                u.res.push_back(pack_resblock(U, "decoder.model." + std::to_string(n + 4 + j), j, rd,
+                                              c.residual_kernel_size, ipow(c.dilation_base, j)));
+            m->ups.push_back(std::move(u));
+            n += 4 + c.n_residual_dec;
+        }
+        m->last_w = U.plain("decoder.model." + std::to_string(n + 2) + ".conv.conv.weight");
+        m->last_b = U.plain("decoder.model." + std::to_string(n + 2) + ".conv.conv.bias");
+    } else {
+        // compose ConvTranspose1d(D->O, k=s=hop) with Conv1d(O->nb, 1) (detector.py:300-310)
+        const int D = c.dimension, O = c.output_dim, hop = hop_of(c);
+        const int nb = c.kind == WV_KIND_DETECTOR ? c.nbits : 1;
+        const auto& w1 = U.host("reverse_convolution.weight");   // [D][O][hop]
+        const auto& b1 = U.host("reverse_convolution.bias");
+        const auto& w2 = U.host("last_layer.weight");            // [nb][O]
+        const auto& b2 = U.host("last_layer.bias");
+        std::vector<float> wc((size_t)D * nb * hop), bc(nb);
+        for (int d = 0; d < D; ++d)
+            for (int nn = 0; nn < nb; ++nn)
+                for (int j = 0; j < hop; ++j) {
+                    double acc = 0;
+                    for (int o = 0; o < O; ++o) acc += (double)w2[(size_t)nn * O + o] * w1[((size_t)d * O + o) * hop + j];
+                    wc[((size_t)d * nb + nn) * hop + j] = (float)acc;
+                }
+        for (int nn = 0; nn < nb; ++nn) {
+            double acc = b2[nn];
+            for (int o = 0; o < O; ++o) acc += (double)w2[(size_t)nn * O + o] * b1[o];
+            bc[nn] = (float)acc;
+        }
+        m->head_wc = U.up(wc); m->head_bc = U.up(bc); m->head_nb = nb;
+    }
+    return U.err;
+}
+
+// ------------------------------------------------------------------------------ workspace
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct WsLayout {
+    size_t act = 0;        // floats per activation buffer
+    size_t spec = 0;       // floats of the STFT scratch
+    size_t film = 0, latent = 0;
+    size_t off_a = 0, off_b = 0, off_c = 0, off_p = 0, off_film = 0, off_lat = 0, total = 0;
+};
+
+WsLayout layout(const wv_model* m, int B, int T) {
+    const wv_config& c = m->cfg;
+    WsLayout L;
+    size_t Tl = (size_t)T, C = (size_t)c.channels_enc, mx = C * Tl, sp = 0;
+    int mult = 1;
+    size_t stride = 1;
+    for (int s = 0; s <= c.n_strides; ++s) {
+        const size_t F = (size_t)mult * c.n_fft_base / 2 + 1;
+        const size_t Tf = ((size_t)T + stride - 1) / stride;
+        sp = std::max(sp, F * Tf);
+        if (s < c.n_strides) {
+            const int r = ratio_enc(c, s);
+            Tl = (Tl + r - 1) / r; C *= 2; mx = std::max(mx, C * Tl);
+            stride *= r; mult *= 2;
+        }
+    }
+    const size_t Fr = Tl;
+    if (c.kind == WV_KIND_GENERATOR) {
+        size_t Cd = (size_t)c.channels_dec << c.n_strides, Td = Fr;
+        mx = std::max(mx, Cd * Td);
+        for (int i = 0; i < c.n_strides; ++i) { Td *= c.strides[i]; Cd /= 2; mx = std::max(mx, Cd * Td); }
+    }
+    L.act = (size_t)B * mx; L.spec = (size_t)B * sp;
+    L.film = (size_t)B * c.n_strides * c.freq_bands * 2;
+    L.latent = (size_t)B * c.dimension * Fr;
+    size_t o = 0;
+    L.off_a = o; o += align_up(L.act * 4);
+    L.off_b = o; o += align_up(L.act * 4);
+    L.off_c = o; o += align_up(L.act * 4);
+    L.off_p = o; o += align_up(L.spec * 4);
+    L.off_film = o; o += align_up(L.film * 4);
+    L.off_lat = o; o += align_up(L.latent * 4);
+    L.total = o;
+    return L;
+}
+
+// ------------------------------------------------------------------------------ forward
+#define LAUNCH(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(WV_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+struct Bufs { float *a, *b, *c; };   // a = current activation, b / c = scratch
+
+int run_resblock(const ResBlock& r, Bufs& bf, int B, int T, hipStream_t st) {
+    wv::PwDwArgs a{};
+    a.X = bf.a; a.pw = r.pw1; a.dw_w = r.dw1_w; a.dw_b = r.dw1_b; a.Y = bf.b;
+    a.B = B; a.Tin = T; a.Tout = T; a.ks = r.ks; a.stride = 1; a.dil = r.dil1; a.pad = (r.ks - 1) * r.dil1;
+    a.pre_scale = r.pre_scale; a.pre_elu = 1; a.out_scale = 1.f; a.bands = 1;
+    LAUNCH(wv::launch_pw_dw(a, st));
+    wv::PwDwArgs b{};
+    b.X = bf.b; b.pw = r.pw2; b.dw_w = r.dw2_w; b.dw_b = r.dw2_b; b.resid = bf.a; b.Y = bf.c;
+    b.B = B; b.Tin = T; b.Tout = T; b.ks = r.ks; b.stride = 1; b.dil = r.dil2; b.pad = (r.ks - 1) * r.dil2;
+    b.pre_scale = 1.f; b.pre_elu = 1; b.out_scale = r.out_scale; b.bands = 1;
+    LAUNCH(wv::launch_pw_dw(b, st));
+    float* t = bf.a; bf.a = bf.c; bf.c = t;
+    return WV_OK;
+}
+
+int run_film(wv_model* m, const float* msg, int msg_rows, float* film, int B, hipStream_t st) {
+    const wv_config& c = m->cfg;
+    if (!m->has_film) return fail(WV_ESTATE, "this model was finalized without message-MLP / FiLM tensors");
+    if (msg_rows != B && msg_rows != 1) return fail(WV_EINVAL, "msg_rows must be B or 1");
+    wv::FilmArgs f{};
+    f.msg = msg; f.msg_rows = msg_rows; f.msg_dim = c.msg_dimension; f.E = c.embedding_dim;
+    f.n_layers = c.embedding_layers; f.n_out = c.n_strides * c.freq_bands * 2;
+    f.w0 = m->f_w0; f.b0 = m->f_b0; f.wl = m->f_wl; f.bl = m->f_bl; f.wf = m->f_wf; f.bf = m->f_bf;
+    f.film = film; f.B = B;
+    LAUNCH(wv::launch_film(f, st));
+    return WV_OK;
+}
+
+// SEANetEncoder.forward (modules/seanet.py:883-976). Result in `latent` [B, dimension, Fr].
+int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, float* latent, int B,
+                int T, char* ws, const WsLayout& L, hipStream_t st, int* Fr_out) {
+    const wv_config& c = m->cfg;
+    Bufs bf{(float*)(ws + L.off_a), (float*)(ws + L.off_b), (float*)(ws + L.off_c)};
+    float* P = (float*)(ws + L.off_p);
+    float* film = nullptr;
+    if (msg) {
+        film = (float*)(ws + L.off_film);
+        int rc = run_film(m, msg, msg_rows, film, B, st);
+        if (rc) return rc;
+    }
+    LAUNCH(wv::launch_conv_pre(x, m->pre_w, m->pre_b, bf.a, B, c.channels_enc, T, c.kernel_size,
+                               1.f / c.wav_std, st));
+    int Tl = T, C = c.channels_enc;
+    const int film_stride = c.n_strides * c.freq_bands * 2;
+    for (int s = 0; s <= c.n_strides; ++s) {
+        const bool post = s == c.n_strides;
+        if (!post)
+            for (const ResBlock& r : m->enc_blocks[s]) {
+                int rc = run_resblock(r, bf, B, Tl, st);
+                if (rc) return rc;
+            }
+        const SpecLayer& sp = m->specs[s];
+        wv::StftArgs sa{};
+        sa.wav = x; sa.basis_t = sp.basis_t; sa.P = P; sa.B = B; sa.T = T;
+        sa.Tf = (T + sp.hop - 1) / sp.hop; sa.n_fft = sp.n_fft; sa.hop = sp.hop; sa.F = sp.F; sa.Mp = sp.Mp;
+        sa.mean = sp.mean; sa.inv_std = sp.inv_std;
+        if (sa.Tf != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");
+        LAUNCH(wv::launch_stft_logmag(sa, st));
+        wv::DwPwArgs acc{};                                                 // x += scale * W @ P
+        acc.X = P; acc.pw = sp.pw; acc.Y = bf.a; acc.B = B; acc.Tin = Tl; acc.Tout = Tl; acc.mode = 0;
+        acc.pre_scale = 1.f; acc.pre_elu = 0; acc.accumulate = 1; acc.out_scale = sp.scale;
+        LAUNCH(wv::launch_dw_pw(acc, st));
+        if (post) break;
+        const DownLayer& d = m->downs[s];
+        wv::PwDwArgs a{};
+        a.X = bf.a; a.pw = d.pw; a.dw_w = d.dw_w; a.dw_b = d.dw_b; a.Y = bf.b;
+        a.B = B; a.Tin = Tl; a.Tout = (Tl + d.ratio - 1) / d.ratio;
+        a.ks = 2 * d.ratio; a.stride = d.ratio; a.dil = 1; a.pad = d.ratio;  // (k-1) - (s-1) = r
+        a.pre_scale = d.pre_scale; a.pre_elu = 1; a.out_scale = 1.f;
+        a.bands = c.freq_bands; a.film_stride = film_stride;
+        a.film = film ? film + (size_t)s * c.freq_bands * 2 : nullptr;
+        if (film && (2 * C) % c.freq_bands) return fail(WV_EINVAL, "channels not divisible by freq_bands");
+        LAUNCH(wv::launch_pw_dw(a, st));
+        float* t = bf.a; bf.a = bf.b; bf.b = t;
+        Tl = a.Tout; C *= 2;
+    }
+    wv::DwPwArgs cp{};                       // conv_post: ELU -> DW k -> 1x1 + bias -> L2Norm
+    cp.X = bf.a; cp.dw_w = m->post_dw_w; cp.pw = m->post_pw; cp.bias = m->post_b; cp.Y = latent;
+    cp.B = B; cp.Tin = Tl; cp.Tout = Tl; cp.mode = 1; cp.ks = c.last_kernel_size;
+    cp.pre_scale = 1.f; cp.pre_elu = 1; cp.l2norm = 1;
+    if (c.dimension > 128) return fail(WV_EINVAL, "dimension > 128 not supported by the fused L2-norm epilogue");
+    LAUNCH(wv::launch_dw_pw(cp, st));
+    *Fr_out = Tl;
+    return WV_OK;
+}
+
+int check_common(const wv_model* m, int B, int T, const void* ws, size_t ws_bytes, WsLayout* L) {
+    if (!m) return fail(WV_EINVAL, "null model");
+    if (!m->finalized) return fail(WV_ESTATE, "wv_model_finalize has not been called");
+    if (B < 1 || T < 1) return fail(WV_EINVAL, "B and T must be >= 1");
+    *L = layout(m, B, T);
+    if (!ws || ws_bytes < L->total)
+        return fail(WV_ENOMEM, "workspace too small: need " + std::to_string(L->total) + " bytes");
+    return WV_OK;
+}
+
+}  // namespace
+
+// ================================================================================ C API
+extern "C" {
+
+const char* wv_last_error(void) { return g_err.c_str(); }
+const char* wv_version(void) { return "waveverify_hip 0.1 (gfx950, f32 MFMA)"; }
+
+int wv_config_default(int kind, wv_config* c) {
+    if (!c || kind < 0 || kind > 2) return fail(WV_EINVAL, "bad kind / null cfg");
+    std::memset(c, 0, sizeof(*c));
+    c->kind = kind;
+    c->dimension = 128; c->msg_dimension = 16; c->channels_enc = 64; c->channels_dec = 96;
+    c->n_fft_base = 64; c->n_residual_enc = 2; c->n_residual_dec = 3;
+    c->n_strides = 4; const int st[4] = {8, 5, 4, 2};
+    for (int i = 0; i < 4; ++i) c->strides[i] = st[i];
+    c->kernel_size = 5; c->last_kernel_size = 5; c->residual_kernel_size = 5; c->dilation_base = 1;
+    c->zero_init = 1; c->nbits = 16; c->output_dim = 32; c->embedding_dim = 64;
+    c->embedding_layers = 2; c->freq_bands = 4;
+    c->res_scale_enc = c->res_scale_dec = 0.5773502691896258f; c->wav_std = 0.1122080159f;
+    const float mu[5] = {-4.554f, -4.315f, -4.021f, -3.726f, -3.477f};
+    const float sd[5] = {2.830f, 2.837f, 2.817f, 2.796f, 2.871f};
+    for (int i = 0; i < 5; ++i) { c->spec_means[i] = mu[i]; c->spec_stds[i] = sd[i]; }
+    c->spec_means[WV_MAX_STRIDES] = mu[4]; c->spec_stds[WV_MAX_STRIDES] = sd[4];   // spec_post = [-1]
+    if (kind == WV_KIND_LOCATOR) {            // model/locator.py:84-115
+        c->dimension = 64; c->channels_enc = 32; c->n_residual_enc = 1;
+        c->n_strides = 2; c->strides[0] = 8; c->strides[1] = 4; c->strides[2] = c->strides[3] = 0;
+    }
+    return WV_OK;
+}
+
+int wv_model_create(const wv_config* cfg, wv_model** out) {
+    if (!cfg || !out) return fail(WV_EINVAL, "null argument");
+    if (cfg->kind < 0 || cfg->kind > 2) return fail(WV_EINVAL, "bad kind");
+    if (cfg->n_strides < 1 || cfg->n_strides > WV_MAX_STRIDES) return fail(WV_EINVAL, "bad n_strides");
+    for (int i = 0; i < cfg->n_strides; ++i)
+        if (cfg->strides[i] < 1 || 2 * cfg->strides[i] > 64) return fail(WV_EINVAL, "stride out of range (1..32)");
+    if (cfg->channels_enc < 1 || cfg->dimension < 1 || cfg->n_fft_base < 2 || (cfg->n_fft_base & 1))
+        return fail(WV_EINVAL, "bad channel / fft sizes");
+    if (cfg->embedding_dim > 256 || cfg->freq_bands < 1) return fail(WV_EINVAL, "bad embedding_dim / freq_bands");
+    if (cfg->kernel_size > 16 || cfg->last_kernel_size > 16 || cfg->residual_kernel_size > 16)
+        return fail(WV_EINVAL, "kernel sizes above 16 are not supported");
+    auto* m = new wv_model();
+    m->cfg = *cfg;
+    build_param_table(m);
+    *out = m;
+    return WV_OK;
+}
+
+void wv_model_destroy(wv_model* m) { delete m; }
+
+int wv_model_num_params(const wv_model* m) { return m ? (int)m->params.size() : 0; }
+
+int wv_model_param_info(const wv_model* m, int i, char* name_out, int name_cap, int64_t* shape_out,
+                        int* ndim_out, int* is_wn) {
+    if (!m || i < 0 || i >= (int)m->params.size()) return fail(WV_EINVAL, "index out of range");
+    const Param& p = m->params[i];
+    if (name_out && name_cap > 0) { std::strncpy(name_out, p.name.c_str(), name_cap - 1); name_out[name_cap - 1] = 0; }
+    if (shape_out) for (int d = 0; d < 4; ++d) shape_out[d] = d < (int)p.shape.size() ? p.shape[d] : 1;
+    if (ndim_out) *ndim_out = (int)p.shape.size();
+    if (is_wn) *is_wn = p.wn ? 1 : 0;
+    return WV_OK;
+}
+
+int wv_model_set_param(wv_model* m, const char* name, const float* data, int64_t numel) {
+    if (!m || !name || !data) return fail(WV_EINVAL, "null argument");
+    if (m->finalized) return fail(WV_ESTATE, "model already finalized");
+    auto it = m->index.find(name);
+    if (it == m->index.end()) return fail(WV_ENOKEY, std::string("unknown parameter: ") + name);
+    Param& p = m->params[it->second];
+    if (numel != p.numel())
+        return fail(WV_EINVAL, std::string("size mismatch for ") + name + ": got " + std::to_string(numel) +
+                                   ", expected " + std::to_string(p.numel()));
+    p.data.assign(data, data + numel);
+    p.set = true;
+    return WV_OK;
+}
+
+int wv_model_set_param_wn(wv_model* m, const char* name, const float* g, int64_t gn, const float* v, int64_t vn) {
+    if (!m || !name || !g || !v) return fail(WV_EINVAL, "null argument");
+    auto it = m->index.find(name);
+    if (it == m->index.end()) return fail(WV_ENOKEY, std::string("unknown parameter: ") + name);
+    Param& p = m->params[it->second];
+    if (!p.wn) return fail(WV_EINVAL, std::string(name) + " is not weight-normed in the reference");
+    if (vn != p.numel() || gn != p.shape[0]) return fail(WV_EINVAL, std::string("size mismatch for ") + name);
+    // w = g * v / ||v||, norm over all dims but 0 (modules/conv.py:73-74)
+    const int64_t rows = p.shape[0], inner = vn / rows;
+    std::vector<float> w((size_t)vn);
+    for (int64_t r = 0; r < rows; ++r) {
+        float ss = 0.f;
+        for (int64_t i = 0; i < inner; ++i) ss += v[r * inner + i] * v[r * inner + i];
+        const float sc = g[r] / std::sqrt(ss);
+        for (int64_t i = 0; i < inner; ++i) w[(size_t)(r * inner + i)] = v[r * inner + i] * sc;
+    }
+    return wv_model_set_param(m, name, w.data(), vn);
+}
+
+int wv_model_set_stft_basis(wv_model* m, const char* name, const float* data, int64_t numel) {
+    if (!m || !name || !data) return fail(WV_EINVAL, "null argument");
+    if (m->finalized) return fail(WV_ESTATE, "model already finalized");
+    const std::string n(name);
+    int mult = 1; bool ok = false;
+    for (int s = 0; s <= m->cfg.n_strides; ++s) {
+        const std::string key = (s == m->cfg.n_strides ? std::string("encoder.spec_post")
+                                                       : "encoder.spec_blocks." + std::to_string(s)) + ".spec.weight";
+        const int n_fft = mult * m->cfg.n_fft_base;
+        if (key == n) {
+            if (numel != (int64_t)(n_fft + 2) * n_fft) return fail(WV_EINVAL, "size mismatch for " + n);
+            ok = true;
+        }
+        mult *= 2;
+    }
+    if (!ok) return fail(WV_ENOKEY, "unknown STFT buffer: " + n);
+    m->stft_override[n].assign(data, data + numel);
+    return WV_OK;
+}
+
+int wv_model_finalize(wv_model* m) {
+    if (!m) return fail(WV_EINVAL, "null model");
+    if (m->finalized) return WV_OK;
+    int n_film_set = 0, n_film = 0;
+    for (const Param& p : m->params) {
+        if (p.optional) { ++n_film; n_film_set += p.set; continue; }
+        if (!p.set) return fail(WV_ENOKEY, "missing parameter: " + p.name);
+    }
+    if (n_film_set != 0 && n_film_set != n_film)
+        return fail(WV_ENOKEY, "message-MLP / FiLM tensors must be given all or none");
+    int rc = pack_model(m);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    m->finalized = true;
+    for (Param& p : m->params) { p.data.clear(); p.data.shrink_to_fit(); }
+    return WV_OK;
+}
+
+size_t wv_workspace_bytes(const wv_model* m, int B, int T) {
+    if (!m || B < 1 || T < 1) return 0;
+    return layout(m, B, T).total;
+}
+
+int wv_encoder_forward(wv_model* m, const float* x, const float* msg, int msg_rows, float* latent,
+                       int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    WsLayout L;
+    int rc = check_common(m, B, T, ws, ws_bytes, &L);
+    if (rc) return rc;
+    if (!x || !latent) return fail(WV_EINVAL, "null tensor");
+    int Fr = 0;
+    return run_encoder(m, x, msg, msg_rows, latent, B, T, (char*)ws, L, (hipStream_t)stream, &Fr);
+}
+
+int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_rows, float* out,
+                         int add_input, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    WsLayout L;
+    int rc = check_common(m, B, T, ws, ws_bytes, &L);
+    if (rc) return rc;
+    if (m->cfg.kind != WV_KIND_GENERATOR) return fail(WV_ESTATE, "not a generator model");
+    if (!x || !msg || !out) return fail(WV_EINVAL, "null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    const wv_config& c = m->cfg;
+    char* w = (char*)ws;
+    float* latent = (float*)(w + L.off_lat);
+    int Fr = 0;
+    rc = run_encoder(m, x, msg, msg_rows, latent, B, T, w, L, st, &Fr);
+    if (rc) return rc;
+    // SEANetDecoder.forward (modules/seanet.py:1212-1226)
+    Bufs bf{(float*)(w + L.off_a), (float*)(w + L.off_b), (float*)(w + L.off_c)};
+    wv::PwDwArgs h{};
+    h.X = latent; h.pw = m->dec_pw0; h.dw_w = m->dec_dw0_w; h.dw_b = m->dec_dw0_b; h.Y = bf.a;
+    h.B = B; h.Tin = Fr; h.Tout = Fr; h.ks = c.kernel_size; h.stride = 1; h.dil = 1; h.pad = c.kernel_size - 1;
+    h.pre_scale = 1.f; h.pre_elu = 0; h.out_scale = 1.f; h.bands = 1;
+    LAUNCH(wv::launch_pw_dw(h, st));
+    int Tl = Fr;
+    for (const UpLayer& u : m->ups) {
+        wv::DwPwArgs a{};
+        a.X = bf.a; a.dw_w = u.ct_w; a.pw = u.pw; a.bias = u.pw_b; a.Y = bf.b;
+        a.B = B; a.Tin = Tl; a.Tout = Tl * u.ratio; a.mode = 2; a.ratio = u.ratio;
+        a.pre_scale = u.pre_scale; a.pre_elu = 1;
+        LAUNCH(wv::launch_dw_pw(a, st));
+        float* t = bf.a; bf.a = bf.b; bf.b = t;
+        Tl = a.Tout;
+        for (const ResBlock& r : u.res) {
+            rc = run_resblock(r, bf, B, Tl, st);
+            if (rc) return rc;
+        }
+    }
+    LAUNCH(wv::launch_tail(bf.a, m->last_w, m->last_b, add_input ? x : nullptr, out, B, c.channels_dec,
+                           Tl, T, c.last_kernel_size, m->dec_post, c.wav_std, st));
+    return WV_OK;
+}
+
+static int run_head_model(wv_model* m, const float* x, float* logits, float* mean_prob, int B, int T,
+                          void* ws, size_t ws_bytes, void* stream) {
+    WsLayout L;
+    int rc = check_common(m, B, T, ws, ws_bytes, &L);
+    if (rc) return rc;
+    if (!x || (!logits && !mean_prob)) return fail(WV_EINVAL, "null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)ws;
+    float* latent = (float*)(w + L.off_lat);
+    int Fr = 0;
+    rc = run_encoder(m, x, nullptr, 0, latent, B, T, w, L, st, &Fr);
+    if (rc) return rc;
+    wv::HeadArgs h{};
+    h.Z = latent; h.wc = m->head_wc; h.bc = m->head_bc; h.logits = logits; h.mean_prob = mean_prob;
+    h.B = B; h.D = m->cfg.dimension; h.nb = m->head_nb; h.hop = hop_of(m->cfg); h.Fr = Fr; h.T = T;
+    LAUNCH(wv::launch_head(h, st));
+    return WV_OK;
+}
+
+int wv_detector_forward(wv_model* m, const float* x, float* logits, float* mean_prob, int B, int T,
+                        void* ws, size_t ws_bytes, void* stream) {
+    if (m && m->cfg.kind != WV_KIND_DETECTOR) return fail(WV_ESTATE, "not a detector model");
+    return run_head_model(m, x, logits, mean_prob, B, T, ws, ws_bytes, stream);
+}
+
+int wv_locator_forward(wv_model* m, const float* x, float* logits, int B, int T, void* ws,
+                       size_t ws_bytes, void* stream) {
+    if (m && m->cfg.kind != WV_KIND_LOCATOR) return fail(WV_ESTATE, "not a locator model");
+    return run_head_model(m, x, logits, nullptr, B, T, ws, ws_bytes, stream);
+}
+
+int wv_model_film(wv_model* m, const float* msg, int msg_rows, float* film, int B, void* stream) {
+    if (!m || !m->finalized) return fail(WV_ESTATE, "model not finalized");
+    if (!msg || !film || B < 1) return fail(WV_EINVAL, "bad argument");
+    return run_film(m, msg, msg_rows, film, B, (hipStream_t)stream);
+}
+
+}  // extern "C"

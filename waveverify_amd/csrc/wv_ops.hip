@@ -1,0 +1,158 @@
+// wv_op_* entry points: each fused unit on its own, with weights handed over in the
+// reference's layouts (HOST pointers; packed and uploaded per call, synchronously).  These are
+// the handles the kernel-level parity tests pull; the model forward passes (wv_model.hip) use
+// the same launchers with weights packed once at finalize.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/waveverify_hip.h"
+#include "wv_kernels.h"
+
+namespace {
+
+extern "C" const char* wv_last_error(void);
+
+struct Tmp {                       // scoped device uploads
+    std::vector<void*> d;
+    bool ok = true;
+    const float* up(const float* h, size_t n) {
+        if (!h || !ok) return nullptr;
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)) != hipSuccess) { ok = false; return nullptr; }
+        d.push_back(p);
+        if (n && hipMemcpy(p, h, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { ok = false; return nullptr; }
+        return (const float*)p;
+    }
+    const float* upv(const std::vector<float>& v) { return up(v.data(), v.size()); }
+    wv::PwWeight pw(const float* w, int M, int K) {
+        wv::PwWeight p; p.M = M; p.K = K; p.Kp = wv::round_up(K, wv::BK); p.Mp = wv::round_up(M, wv::M_ALIGN);
+        std::vector<float> t((size_t)p.Kp * p.Mp, 0.f);
+        for (int m = 0; m < M; ++m)
+            for (int k = 0; k < K; ++k) t[(size_t)k * p.Mp + m] = w[(size_t)m * K + k];
+        p.wt = upv(t);
+        return p;
+    }
+    ~Tmp() { (void)hipDeviceSynchronize(); for (void* p : d) (void)hipFree(p); }
+};
+
+int done(Tmp& t, hipError_t e, hipStream_t s) {
+    if (!t.ok) return WV_EHIP;
+    if (e != hipSuccess) return e == hipErrorInvalidValue ? WV_EINVAL : WV_EHIP;
+    return hipStreamSynchronize(s) == hipSuccess ? WV_OK : WV_EHIP;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const float* dw_bias,
+                const float* film, const float* resid, float* Y, int B, int K, int M, int Tin,
+                int ks, int stride, int dilation, float pre_scale, int pre_elu, float out_scale,
+                int bands, void* stream) {
+    if (!X || !w_pw || !w_dw || !Y || B < 1 || K < 1 || M < 1 || Tin < 1) return WV_EINVAL;
+    Tmp t;
+    wv::PwDwArgs a{};
+    a.X = X; a.pw = t.pw(w_pw, M, K); a.dw_w = t.up(w_dw, (size_t)M * ks);
+    a.dw_b = t.up(dw_bias, M); a.film = film; a.resid = resid; a.Y = Y;
+    a.B = B; a.Tin = Tin; a.Tout = (Tin + stride - 1) / stride; a.ks = ks; a.stride = stride;
+    a.dil = dilation; a.pad = (ks - 1) * dilation - (stride - 1);
+    a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = out_scale;
+    a.bands = bands > 0 ? bands : 1; a.film_stride = 2 * a.bands;
+    if (a.pad < 0) return WV_EINVAL;
+    return done(t, wv::launch_pw_dw(a, (hipStream_t)stream), (hipStream_t)stream);
+}
+
+int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const float* bias, float* Y,
+                int B, int K, int M, int Tin, int mode, int ks_or_ratio, float pre_scale, int pre_elu,
+                int l2norm, int accumulate, float out_scale, void* stream) {
+    if (!X || !w_pw || !Y || B < 1 || K < 1 || M < 1 || Tin < 1) return WV_EINVAL;
+    Tmp t;
+    wv::DwPwArgs a{};
+    a.X = X; a.pw = t.pw(w_pw, M, K); a.bias = t.up(bias, M); a.Y = Y;
+    a.B = B; a.Tin = Tin; a.mode = mode; a.Tout = Tin;
+    if (mode == 1) { a.ks = ks_or_ratio; a.dw_w = t.up(w_dw, (size_t)K * a.ks); }
+    if (mode == 2) { a.ratio = ks_or_ratio; a.Tout = Tin * a.ratio; a.dw_w = t.up(w_dw, (size_t)K * 2 * a.ratio); }
+    a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.l2norm = l2norm; a.accumulate = accumulate;
+    a.out_scale = out_scale;
+    return done(t, wv::launch_dw_pw(a, (hipStream_t)stream), (hipStream_t)stream);
+}
+
+int wv_op_stft_logmag(const float* wav, const float* host_basis, float* P, int B, int T, int n_fft,
+                      int hop, float mean, float std, void* stream) {
+    if (!wav || !P || B < 1 || T < 1 || n_fft < 2 || hop < 1) return WV_EINVAL;
+    const int F = n_fft / 2 + 1;
+    std::vector<float> basis;
+    if (host_basis) basis.assign(host_basis, host_basis + (size_t)2 * F * n_fft);
+    else {
+        basis.resize((size_t)2 * F * n_fft);
+        const float c = (float)(-2.0 * M_PI / n_fft), wc = (float)(2.0 * M_PI / n_fft);
+        for (int k = 0; k < F; ++k) {
+            volatile float ck = c * (float)k;
+            for (int n = 0; n < n_fft; ++n) {
+                volatile float ang = ck * (float)n;
+                volatile float wa = (float)n * wc;
+                const float win = 0.5f - 0.5f * (float)std::cos((double)wa);
+                basis[(size_t)k * n_fft + n] = (float)std::cos((double)ang) * win;
+                basis[(size_t)(F + k) * n_fft + n] = (float)std::sin((double)ang) * win;
+            }
+        }
+    }
+    const int Mp = wv::round_up(2 * F, wv::M_ALIGN), Kp = wv::round_up(n_fft, wv::BK);
+    std::vector<float> bt((size_t)Kp * Mp, 0.f);
+    for (int f = 0; f < F; ++f)
+        for (int n = 0; n < n_fft; ++n) {
+            bt[(size_t)n * Mp + 2 * f] = basis[(size_t)f * n_fft + n];
+            bt[(size_t)n * Mp + 2 * f + 1] = basis[(size_t)(F + f) * n_fft + n];
+        }
+    Tmp t;
+    wv::StftArgs a{};
+    a.wav = wav; a.basis_t = t.upv(bt); a.P = P; a.B = B; a.T = T; a.Tf = (T + hop - 1) / hop;
+    a.n_fft = n_fft; a.hop = hop; a.F = F; a.Mp = Mp; a.mean = mean; a.inv_std = 1.f / std;
+    return done(t, wv::launch_stft_logmag(a, (hipStream_t)stream), (hipStream_t)stream);
+}
+
+int wv_op_conv_pre(const float* x, const float* w, const float* bias, float* Y, int B, int C, int T,
+                   int ks, float in_scale, void* stream) {
+    if (!x || !w || !Y) return WV_EINVAL;
+    Tmp t;
+    return done(t, wv::launch_conv_pre(x, t.up(w, (size_t)C * ks), t.up(bias, C), Y, B, C, T, ks,
+                                       in_scale, (hipStream_t)stream), (hipStream_t)stream);
+}
+
+int wv_op_tail(const float* H, const float* w, const float* bias, const float* x_or_null, float* out,
+               int B, int C, int Tin, int T, int ks, float pre_scale, float out_scale, void* stream) {
+    if (!H || !w || !out) return WV_EINVAL;
+    Tmp t;
+    return done(t, wv::launch_tail(H, t.up(w, (size_t)C * ks), t.up(bias, 1), x_or_null, out, B, C, Tin,
+                                   T, ks, pre_scale, out_scale, (hipStream_t)stream), (hipStream_t)stream);
+}
+
+int wv_op_head(const float* Z, const float* w_rev, const float* b_rev, const float* w_last,
+               const float* b_last, float* logits, float* mean_prob, int B, int D, int O, int nb,
+               int hop, int Fr, int T, void* stream) {
+    if (!Z || !w_rev || !b_rev || !w_last || !b_last || (!logits && !mean_prob)) return WV_EINVAL;
+    if (T > Fr * hop) return WV_EINVAL;
+    std::vector<float> wc((size_t)D * nb * hop), bc(nb);
+    for (int d = 0; d < D; ++d)
+        for (int n = 0; n < nb; ++n)
+            for (int j = 0; j < hop; ++j) {
+                double acc = 0;
+                for (int o = 0; o < O; ++o) acc += (double)w_last[(size_t)n * O + o] * w_rev[((size_t)d * O + o) * hop + j];
+                wc[((size_t)d * nb + n) * hop + j] = (float)acc;
+            }
+    for (int n = 0; n < nb; ++n) {
+        double acc = b_last[n];
+        for (int o = 0; o < O; ++o) acc += (double)w_last[(size_t)n * O + o] * b_rev[o];
+        bc[n] = (float)acc;
+    }
+    Tmp t;
+    wv::HeadArgs a{};
+    a.Z = Z; a.wc = t.upv(wc); a.bc = t.upv(bc); a.logits = logits; a.mean_prob = mean_prob;
+    a.B = B; a.D = D; a.nb = nb; a.hop = hop; a.Fr = Fr; a.T = T;
+    return done(t, wv::launch_head(a, (hipStream_t)stream), (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+"""Single fused units of the hot path through the C ABI (wv_op_* of include/waveverify_hip.h).
+
+Activations are CUDA tensors; weights are host arrays in the reference's layouts.  These are
+test handles — the nets in nets.py run the same kernels with weights packed once."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _w(a) -> Optional[np.ndarray]:
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(a, np.float32))
+
+
+def _hp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data
+
+
+def _dp(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _dev(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("activations must live on the GPU")
+    return t.float().contiguous()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pw_dw(X, w_pw, w_dw, dw_bias=None, film=None, resid=None, stride=1, dilation=1,
+          pre_scale=1.0, pre_elu=True, out_scale=1.0, bands=1) -> torch.Tensor:
+    lib = _lib.load()
+    X = _dev(X)
+    B, K, Tin = X.shape
+    w_pw, w_dw, dw_bias = _w(w_pw), _w(w_dw), _w(dw_bias)
+    M, ks = w_dw.shape[0], w_dw.shape[-1]
+    w_pw = w_pw.reshape(M, K)
+    Tout = -(-Tin // stride)
+    Y = torch.empty((B, M, Tout), dtype=torch.float32, device=X.device)
+    film = None if film is None else _dev(film)
+    resid = None if resid is None else _dev(resid)
+    _lib.check(lib.wv_op_pw_dw(X.data_ptr(), _hp(w_pw), _hp(w_dw), _hp(dw_bias), _dp(film), _dp(resid),
+                               Y.data_ptr(), B, K, M, Tin, ks, stride, dilation, pre_scale,
+                               int(pre_elu), out_scale, bands, _stream()), "wv_op_pw_dw")
+    return Y
+
+
+def dw_pw(X, w_pw, bias=None, w_dw=None, mode=0, ks_or_ratio=0, pre_scale=1.0, pre_elu=False,
+          l2norm=False, accumulate_into: Optional[torch.Tensor] = None, out_scale=1.0) -> torch.Tensor:
+    lib = _lib.load()
+    X = _dev(X)
+    B, K, Tin = X.shape
+    w_pw, bias, w_dw = _w(w_pw), _w(bias), _w(w_dw)
+    M = w_pw.shape[0]
+    w_pw = w_pw.reshape(M, K)
+    Tout = Tin * ks_or_ratio if mode == 2 else Tin
+    if accumulate_into is not None:
+        Y = accumulate_into
+        assert Y.is_cuda and Y.is_contiguous() and tuple(Y.shape) == (B, M, Tout)
+    else:
+        Y = torch.empty((B, M, Tout), dtype=torch.float32, device=X.device)
+    _lib.check(lib.wv_op_dw_pw(X.data_ptr(), _hp(w_dw), _hp(w_pw), _hp(bias), Y.data_ptr(), B, K, M,
+                               Tin, mode, ks_or_ratio, pre_scale, int(pre_elu), int(l2norm),
+                               int(accumulate_into is not None), out_scale, _stream()), "wv_op_dw_pw")
+    return Y
+
+
+def stft_logmag(wav, n_fft, hop, mean=0.0, std=1.0, basis=None) -> torch.Tensor:
+    lib = _lib.load()
+    wav = _dev(wav)
+    B, T = wav.shape[0], wav.shape[-1]
+    Tf = -(-T // hop)
+    P = torch.empty((B, n_fft // 2 + 1, Tf), dtype=torch.float32, device=wav.device)
+    basis = _w(basis)
+    _lib.check(lib.wv_op_stft_logmag(wav.data_ptr(), _hp(basis), P.data_ptr(), B, T, n_fft, hop, mean,
+                                     std, _stream()), "wv_op_stft_logmag")
+    return P
+
+
+def conv_pre(x, w, bias, in_scale) -> torch.Tensor:
+    lib = _lib.load()
+    x = _dev(x)
+    B, T = x.shape[0], x.shape[-1]
+    w, bias = _w(w), _w(bias)
+    Cc, ks = w.shape[0], w.shape[-1]
+    Y = torch.empty((B, Cc, T), dtype=torch.float32, device=x.device)
+    _lib.check(lib.wv_op_conv_pre(x.data_ptr(), _hp(w), _hp(bias), Y.data_ptr(), B, Cc, T, ks, in_scale,
+                                  _stream()), "wv_op_conv_pre")
+    return Y
+
+
+def tail(H, w, bias, x=None, T=None, pre_scale=1.0, out_scale=1.0) -> torch.Tensor:
+    lib = _lib.load()
+    H = _dev(H)
+    B, Cc, Tin = H.shape
+    T = Tin if T is None else T
+    w, bias = _w(w), _w(bias)
+    ks = w.shape[-1]
+    x = None if x is None else _dev(x)
+    out = torch.empty((B, 1, T), dtype=torch.float32, device=H.device)
+    _lib.check(lib.wv_op_tail(H.data_ptr(), _hp(w), _hp(bias), _dp(x), out.data_ptr(), B, Cc, Tin, T, ks,
+                              pre_scale, out_scale, _stream()), "wv_op_tail")
+    return out
+
+
+def head(Z, w_rev, b_rev, w_last, b_last, T, want_logits=True, want_mean=True):
+    lib = _lib.load()
+    Z = _dev(Z)
+    B, D, Fr = Z.shape
+    w_rev, b_rev, w_last, b_last = _w(w_rev), _w(b_rev), _w(w_last), _w(b_last)
+    O, hop = w_rev.shape[1], w_rev.shape[2]
+    nb = w_last.shape[0]
+    w_last = w_last.reshape(nb, O)
+    logits = torch.empty((B, nb, T), dtype=torch.float32, device=Z.device) if want_logits else None
+    mean = torch.empty((B, nb), dtype=torch.float32, device=Z.device) if want_mean else None
+    _lib.check(lib.wv_op_head(Z.data_ptr(), _hp(w_rev), _hp(b_rev), _hp(w_last), _hp(b_last),
+                              _dp(logits), _dp(mean), B, D, O, nb, hop, Fr, T, _stream()), "wv_op_head")
+    return logits, mean
