@@ -184,6 +184,16 @@ int wv_op_head(const float* Z, const float* w_rev, const float* b_rev,
  * film [B,n_scales,bands,2]; uses the model's parameters. */
 int wv_model_film(wv_model* m, const float* msg, int msg_rows, float* film, int B, void* stream);
 
+/* ---- measurement hook (bench.py's roofline figures) ---------------------------------------
+ * When enabled, every kernel launch is bracketed by a hipEvent pair on the launch stream and
+ * aggregated by "<kernel>|<role>" together with its ALGORITHMIC flops and bytes (the per-unit
+ * figures of DESIGN.md).  wv_profile_collect(-1, ...) synchronises, snapshots and returns the
+ * number of entries; wv_profile_collect(i, ...) reads entry i of that snapshot. */
+int wv_profile_enable(int on);
+int wv_profile_reset(void);
+int wv_profile_collect(int index, char* name_out, int name_cap, int64_t* launches,
+                       double* total_ms, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,11 @@ SIGNATURES = {
     "wv_encoder_forward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_int, _VP,
                                      C.c_size_t, _VP]),
     "wv_model_film": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP]),
+    "wv_profile_enable": (C.c_int, [C.c_int]),
+    "wv_profile_reset": (C.c_int, []),
+    "wv_profile_collect": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]),
     "wv_op_pw_dw": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
                               C.c_int, _VP]),
@@ -82,6 +87,9 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"waveverify_amd: HIP extension not found at {LIB_PATH}; build it with "
             "`python -m waveverify_amd.build` (there is no CPU fallback)")
+    # torch first: its bundled libamdhip64 (soname libamdhip64.so.7) must be THE HIP runtime of
+    # the process, so that torch's device pointers and streams are valid inside this library.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError if the .so lacks a declared symbol

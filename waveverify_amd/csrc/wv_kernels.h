@@ -97,4 +97,16 @@ struct FilmArgs {
 };
 hipError_t launch_film(const FilmArgs& a, hipStream_t s);
 
+// ---- optional per-launch profiling with HIP events on the launch stream ---------------------
+// When enabled every launcher brackets its kernel with an event pair; entries aggregate by
+// "<kernel symbol>|<role>".  Roles are set by the model plan (e.g. "enc.down_film").
+namespace prof {
+void enable(bool on);
+bool enabled();
+void reset();
+void set_role(const char* role);
+struct Entry { const char* name; long long launches; double ms, flops, bytes; };
+int collect(Entry* out, int cap);   // synchronises the recorded events; returns entry count
+}  // namespace prof
+
 }  // namespace wv

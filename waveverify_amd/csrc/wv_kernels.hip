@@ -508,6 +508,76 @@ __global__ __launch_bounds__(NT_) void film_kernel(FilmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-launch profiler (HIP events on the launch stream)
+// ------------------------------------------------------------------------------------------
+}  // namespace wv
+#include <map>
+#include <string>
+#include <vector>
+namespace wv {
+namespace prof {
+namespace {
+struct Rec { hipEvent_t a, b; int key; };
+struct Agg { std::string name; long long launches = 0; double ms = 0, flops = 0, bytes = 0; };
+bool g_on = false;
+thread_local const char* g_role = "";
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+std::vector<Agg> g_agg;
+std::map<std::string, int> g_index;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+void drain() {
+    for (Rec& r : g_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess)
+            g_agg[r.key].ms += ms;
+        g_pool.push_back(r.a); g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+}
+}  // namespace
+void enable(bool on) { g_on = on; }
+bool enabled() { return g_on; }
+void reset() { drain(); g_agg.clear(); g_index.clear(); }
+void set_role(const char* role) { g_role = role ? role : ""; }
+int collect(Entry* out, int cap) {
+    drain();
+    int n = 0;
+    for (const Agg& a : g_agg) {
+        if (n < cap) out[n] = Entry{a.name.c_str(), a.launches, a.ms, a.flops, a.bytes};
+        ++n;
+    }
+    return n;
+}
+struct Scope {
+    hipStream_t s; int rec = -1;
+    Scope(hipStream_t st, const char* kernel, double flops, double bytes) : s(st) {
+        if (!g_on) return;
+        std::string key = std::string(kernel) + "|" + g_role;
+        auto it = g_index.find(key);
+        int k;
+        if (it == g_index.end()) { k = (int)g_agg.size(); g_index[key] = k; Agg a; a.name = key; g_agg.push_back(a); }
+        else k = it->second;
+        g_agg[k].launches += 1; g_agg[k].flops += flops; g_agg[k].bytes += bytes;
+        Rec r{get_event(), get_event(), k};
+        (void)hipEventRecord(r.a, s);
+        g_recs.push_back(r);
+        rec = (int)g_recs.size() - 1;
+    }
+    ~Scope() { if (rec >= 0) (void)hipEventRecord(g_recs[rec].b, s); }
+};
+}  // namespace prof
+
+template <class T>
+static std::string tile_name(const char* base) {
+    return std::string(base) + "<" + std::to_string(T::BM) + "," + std::to_string(T::BN) + "," +
+           std::to_string(T::WM) + "," + std::to_string(T::WN) + ">";
+}
+
+// ------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------
 template <class T>
@@ -527,9 +597,17 @@ static hipError_t run_pw_dw(const PwDwArgs& a, hipStream_t s) {
     size_t smem = stage_bytes<T>();
     const size_t hb = (size_t)T::BM * (T::BN + 4) * sizeof(float);
     if (hb > smem) smem = hb;
-    hipError_t e = set_smem(pw_dw_kernel<T>, smem);
-    if (e != hipSuccess) return e;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = set_smem(pw_dw_kernel<T>, smem);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
     dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + tto - 1) / tto, a.B);
+    static const std::string name = tile_name<T>("pw_dw");
+    const double M = a.pw.M, K = a.pw.K, Bd = a.B;
+    prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
+                   4.0 * Bd * (K * a.Tin + M * a.Tout * (a.resid ? 2.0 : 1.0)));
     hipLaunchKernelGGL(pw_dw_kernel<T>, grid, dim3(NT_), smem, s, a);
     return hipGetLastError();
 }
@@ -565,6 +643,11 @@ static hipError_t run_dw_pw(const DwPwArgs& a, hipStream_t s) {
     const size_t smem = stage_bytes<T>();
     if (a.l2norm && a.pw.M > T::BM) return hipErrorInvalidValue;
     dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + T::BN - 1) / T::BN, a.B);
+    static const std::string name = tile_name<T>("dw_pw");
+    const double M = a.pw.M, K = a.pw.K, Bd = a.B;
+    const double stencil = a.mode == 1 ? 2.0 * a.ks : (a.mode == 2 ? 4.0 : 0.0);
+    prof::Scope ps(s, name.c_str(), Bd * a.Tout * (2.0 * M * K + stencil * K),
+                   4.0 * Bd * (K * a.Tin + M * a.Tout * (a.accumulate ? 2.0 : 1.0)));
     hipLaunchKernelGGL(dw_pw_kernel<T>, grid, dim3(NT_), smem, s, a);
     return hipGetLastError();
 }
@@ -590,6 +673,9 @@ hipError_t launch_dw_pw(const DwPwArgs& a, hipStream_t s) {
 template <class T>
 static hipError_t run_stft(const StftArgs& a, hipStream_t s) {
     dim3 grid((2 * a.F + T::BM - 1) / T::BM, (a.Tf + T::BN - 1) / T::BN, a.B);
+    static const std::string name = tile_name<T>("stft_logmag");
+    prof::Scope ps(s, name.c_str(), 2.0 * a.B * (2.0 * a.F) * a.n_fft * a.Tf,
+                   4.0 * a.B * ((double)a.T + (double)a.F * a.Tf));
     hipLaunchKernelGGL(stft_logmag_kernel<T>, grid, dim3(NT_), stage_bytes<T>(), s, a);
     return hipGetLastError();
 }
@@ -606,6 +692,7 @@ hipError_t launch_conv_pre(const float* x, const float* w, const float* bias, fl
                            int C, int T, int ks, float in_scale, hipStream_t s) {
     if (ks < 1 || ks > MAX_KS) return hipErrorInvalidValue;
     dim3 grid((T + NT_ - 1) / NT_, B);
+    prof::Scope ps(s, "conv_pre", 2.0 * B * C * ks * (double)T, 4.0 * B * (double)T * (1.0 + C));
     hipLaunchKernelGGL(conv_pre_kernel, grid, dim3(NT_), 0, s, x, w, bias, Y, C, T, ks, in_scale);
     return hipGetLastError();
 }
@@ -616,6 +703,7 @@ hipError_t launch_tail(const float* H, const float* w, const float* bias, const 
     if (ks < 1 || ks > 32 || T > Tin) return hipErrorInvalidValue;
     const int per_block = 4 * (64 - (ks - 1));
     dim3 grid((T + per_block - 1) / per_block, B);
+    prof::Scope ps(s, "tail", 2.0 * B * C * ks * (double)T, 4.0 * B * ((double)C * Tin + 2.0 * T));
     hipLaunchKernelGGL(tail_kernel, grid, dim3(NT_), 0, s, H, w, bias, x, out, C, Tin, T, ks,
                        pre_scale, out_scale);
     return hipGetLastError();
@@ -624,12 +712,16 @@ hipError_t launch_tail(const float* H, const float* w, const float* bias, const 
 hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
     using T = Tile<64, 64, 2, 2>;
     dim3 grid(a.nb, a.B);
+    static const std::string name = tile_name<T>("head");
+    prof::Scope ps(s, name.c_str(), 2.0 * a.B * a.D * (double)a.nb * a.hop * a.Fr,
+                   4.0 * a.B * ((double)a.D * a.Fr + (a.logits ? (double)a.nb * a.T : 0.0)));
     hipLaunchKernelGGL(head_kernel<T>, grid, dim3(NT_), stage_bytes<T>(), s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_film(const FilmArgs& a, hipStream_t s) {
     if (a.E > NT_ || a.E < 1) return hipErrorInvalidValue;
+    prof::Scope ps(s, "film", 2.0 * a.B * a.E * (a.msg_dim + a.n_layers * a.E + a.n_out), 4.0 * a.B * (a.msg_dim + a.n_out));
     hipLaunchKernelGGL(film_kernel, dim3(a.B), dim3(NT_), 0, s, a);
     return hipGetLastError();
 }

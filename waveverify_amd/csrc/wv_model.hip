@@ -456,7 +456,8 @@ WsLayout layout(const wv_model* m, int B, int T) {
 
 struct Bufs { float *a, *b, *c; };   // a = current activation, b / c = scratch
 
-int run_resblock(const ResBlock& r, Bufs& bf, int B, int T, hipStream_t st) {
+int run_resblock(const ResBlock& r, Bufs& bf, int B, int T, hipStream_t st, const char* role) {
+    wv::prof::set_role(role);
     wv::PwDwArgs a{};
     a.X = bf.a; a.pw = r.pw1; a.dw_w = r.dw1_w; a.dw_b = r.dw1_b; a.Y = bf.b;
     a.B = B; a.Tin = T; a.Tout = T; a.ks = r.ks; a.stride = 1; a.dil = r.dil1; a.pad = (r.ks - 1) * r.dil1;
@@ -475,6 +476,7 @@ int run_film(wv_model* m, const float* msg, int msg_rows, float* film, int B, hi
     const wv_config& c = m->cfg;
     if (!m->has_film) return fail(WV_ESTATE, "this model was finalized without message-MLP / FiLM tensors");
     if (msg_rows != B && msg_rows != 1) return fail(WV_EINVAL, "msg_rows must be B or 1");
+    wv::prof::set_role("enc.film");
     wv::FilmArgs f{};
     f.msg = msg; f.msg_rows = msg_rows; f.msg_dim = c.msg_dimension; f.E = c.embedding_dim;
     f.n_layers = c.embedding_layers; f.n_out = c.n_strides * c.freq_bands * 2;
@@ -496,6 +498,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         int rc = run_film(m, msg, msg_rows, film, B, st);
         if (rc) return rc;
     }
+    wv::prof::set_role("enc.conv_pre");
     LAUNCH(wv::launch_conv_pre(x, m->pre_w, m->pre_b, bf.a, B, c.channels_enc, T, c.kernel_size,
                                1.f / c.wav_std, st));
     int Tl = T, C = c.channels_enc;
@@ -504,9 +507,10 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         const bool post = s == c.n_strides;
         if (!post)
             for (const ResBlock& r : m->enc_blocks[s]) {
-                int rc = run_resblock(r, bf, B, Tl, st);
+                int rc = run_resblock(r, bf, B, Tl, st, "enc.resblock");
                 if (rc) return rc;
             }
+        wv::prof::set_role("enc.spec");
         const SpecLayer& sp = m->specs[s];
         wv::StftArgs sa{};
         sa.wav = x; sa.basis_t = sp.basis_t; sa.P = P; sa.B = B; sa.T = T;
@@ -520,6 +524,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         LAUNCH(wv::launch_dw_pw(acc, st));
         if (post) break;
         const DownLayer& d = m->downs[s];
+        wv::prof::set_role(film ? "enc.down_film" : "enc.down");
         wv::PwDwArgs a{};
         a.X = bf.a; a.pw = d.pw; a.dw_w = d.dw_w; a.dw_b = d.dw_b; a.Y = bf.b;
         a.B = B; a.Tin = Tl; a.Tout = (Tl + d.ratio - 1) / d.ratio;
@@ -532,6 +537,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         float* t = bf.a; bf.a = bf.b; bf.b = t;
         Tl = a.Tout; C *= 2;
     }
+    wv::prof::set_role("enc.conv_post");
     wv::DwPwArgs cp{};                       // conv_post: ELU -> DW k -> 1x1 + bias -> L2Norm
     cp.X = bf.a; cp.dw_w = m->post_dw_w; cp.pw = m->post_pw; cp.bias = m->post_b; cp.Y = latent;
     cp.B = B; cp.Tin = Tl; cp.Tout = Tl; cp.mode = 1; cp.ks = c.last_kernel_size;
@@ -718,6 +724,7 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
     if (rc) return rc;
     // SEANetDecoder.forward (modules/seanet.py:1212-1226)
     Bufs bf{(float*)(w + L.off_a), (float*)(w + L.off_b), (float*)(w + L.off_c)};
+    wv::prof::set_role("dec.head");
     wv::PwDwArgs h{};
     h.X = latent; h.pw = m->dec_pw0; h.dw_w = m->dec_dw0_w; h.dw_b = m->dec_dw0_b; h.Y = bf.a;
     h.B = B; h.Tin = Fr; h.Tout = Fr; h.ks = c.kernel_size; h.stride = 1; h.dil = 1; h.pad = c.kernel_size - 1;
@@ -725,6 +732,7 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
     LAUNCH(wv::launch_pw_dw(h, st));
     int Tl = Fr;
     for (const UpLayer& u : m->ups) {
+        wv::prof::set_role("dec.upsample");
         wv::DwPwArgs a{};
         a.X = bf.a; a.dw_w = u.ct_w; a.pw = u.pw; a.bias = u.pw_b; a.Y = bf.b;
         a.B = B; a.Tin = Tl; a.Tout = Tl * u.ratio; a.mode = 2; a.ratio = u.ratio;
@@ -733,10 +741,11 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
         float* t = bf.a; bf.a = bf.b; bf.b = t;
         Tl = a.Tout;
         for (const ResBlock& r : u.res) {
-            rc = run_resblock(r, bf, B, Tl, st);
+            rc = run_resblock(r, bf, B, Tl, st, "dec.resblock");
             if (rc) return rc;
         }
     }
+    wv::prof::set_role("dec.tail");
     LAUNCH(wv::launch_tail(bf.a, m->last_w, m->last_b, add_input ? x : nullptr, out, B, c.channels_dec,
                            Tl, T, c.last_kernel_size, m->dec_post, c.wav_std, st));
     return WV_OK;
@@ -754,6 +763,7 @@ static int run_head_model(wv_model* m, const float* x, float* logits, float* mea
     int Fr = 0;
     rc = run_encoder(m, x, nullptr, 0, latent, B, T, w, L, st, &Fr);
     if (rc) return rc;
+    wv::prof::set_role("head");
     wv::HeadArgs h{};
     h.Z = latent; h.wc = m->head_wc; h.bc = m->head_bc; h.logits = logits; h.mean_prob = mean_prob;
     h.B = B; h.D = m->cfg.dimension; h.nb = m->head_nb; h.hop = hop_of(m->cfg); h.Fr = Fr; h.T = T;
@@ -771,6 +781,27 @@ int wv_locator_forward(wv_model* m, const float* x, float* logits, int B, int T,
                        size_t ws_bytes, void* stream) {
     if (m && m->cfg.kind != WV_KIND_LOCATOR) return fail(WV_ESTATE, "not a locator model");
     return run_head_model(m, x, logits, nullptr, B, T, ws, ws_bytes, stream);
+}
+
+int wv_profile_enable(int on) { wv::prof::enable(on != 0); return WV_OK; }
+int wv_profile_reset(void) { wv::prof::reset(); return WV_OK; }
+int wv_profile_collect(int index, char* name_out, int name_cap, int64_t* launches, double* total_ms,
+                       double* flops, double* bytes) {
+    static thread_local std::vector<wv::prof::Entry> snap;
+    if (index < 0) {                                   // refresh the snapshot, return its size
+        snap.resize(4096);
+        int n = wv::prof::collect(snap.data(), (int)snap.size());
+        snap.resize(std::min<int>(n, 4096));
+        return (int)snap.size();
+    }
+    if (index >= (int)snap.size()) return fail(WV_EINVAL, "profile index out of range");
+    const wv::prof::Entry& e = snap[index];
+    if (name_out && name_cap > 0) { std::strncpy(name_out, e.name, name_cap - 1); name_out[name_cap - 1] = 0; }
+    if (launches) *launches = e.launches;
+    if (total_ms) *total_ms = e.ms;
+    if (flops) *flops = e.flops;
+    if (bytes) *bytes = e.bytes;
+    return WV_OK;
 }
 
 int wv_model_film(wv_model* m, const float* msg, int msg_rows, float* film, int B, void* stream) {
