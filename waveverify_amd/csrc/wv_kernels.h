@@ -34,6 +34,8 @@ struct PwDwArgs {
     int bands, film_stride;
     float post_scale;     // optional activation of the OUTPUT (consumer's prologue hoisted):
     int post_elu;         //   y = post_elu ? ELU(post_scale*y) : y
+    int tto, off;         // filled by launch_pw_dw: outputs per time tile; stencil offset inside
+                          // the 4-aligned H window
 };
 hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s);
 

@@ -26,23 +26,27 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 
 // ------------------------------------------------------------------------------------------
 // GEMM core.  Tile BM x BN per workgroup, WM x WN waves, each wave MT x NT MFMA tiles of 32x32.
-// Operands are fetched by loader functors (global -> registers, with whatever fused prologue),
-// committed to LDS one K-chunk ahead (register prefetch + double-buffered LDS, one barrier per
-// chunk), and consumed by ds_read_b32 fragments: lane l reads row k+(l>>5), column base+(l&31),
-// i.e. 32 consecutive floats per half-wave -> conflict-free.
+// Per K-chunk (BK rows): operands are fetched RAW into registers one chunk ahead (16-byte loads
+// where the tile is aligned), the MFMAs of the current chunk run while those loads are in
+// flight, and only then are the raw values transformed (scale -> ELU, stencil taps, ...) and
+// committed to the other LDS stage -- so no s_waitcnt on global memory sits in front of the
+// matrix work.  One barrier per chunk.  Fragments are ds_read_b32: lane l reads row k+(l>>5),
+// column base+(l&31): 32 consecutive floats per half-wave, conflict-free.
 // ------------------------------------------------------------------------------------------
 template <int BM_, int BN_, int WM_, int WN_>
 struct Tile {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
     static constexpr int MT = BM / (32 * WM);
     static constexpr int NT = BN / (32 * WN);
-    static constexpr int A_PER = BK * BM / NT_;
-    static constexpr int B_PER = BK * BN / NT_;
-    static constexpr int BKSTEP = NT_ / BN;              // k rows covered per B slot
-    static constexpr int STAGE = BK * (BM + BN);         // floats per LDS stage
+    static constexpr int A_VEC = BK * BM / 4;                 // float4 per stage
+    static constexpr int A_PER = (A_VEC + NT_ - 1) / NT_;
+    static constexpr int B_TPR = BN / 4;                      // threads per k-row (4 columns each)
+    static constexpr int BKSTEP = NT_ / B_TPR;                // k rows per pass
+    static constexpr int B_PER = BK / BKSTEP;
+    static constexpr int STAGE = BK * (BM + BN);              // floats per LDS stage
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(MT >= 1 && NT >= 1, "tile too small for the wave grid");
-    static_assert((BK * BM) % NT_ == 0 && (BK * BN) % NT_ == 0 && NT_ % BN == 0, "staging map");
+    static_assert(BM % 4 == 0 && BK % BKSTEP == 0 && B_PER >= 1, "staging map");
 };
 
 template <class T>
@@ -55,38 +59,48 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[T::MT][T::NT]) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
-// LA: float load(int k, int m)            (m in [0,BM))
-// LB: void init(int col); float load(int k)   (col in [0,BN) fixed per thread)
+// LA: float4 load4(int k, int m)                      m multiple of 4, in [0,BM)
+// LB: NRAW; init(col4); fetch(k, raw[4*NRAW]); finish(k, raw, out[4])   4 consecutive columns
 template <class T, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::MT][T::NT], const LA& la, LB& lb,
                                               int nchunks, float* smem) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN;
-    const int bcol = tid % T::BN, bk0 = tid / T::BN;
-    float ra[T::A_PER], rb[T::B_PER];
+    const int bcol = (tid % T::B_TPR) * 4, bk0 = tid / T::B_TPR;
+    float4 ra[T::A_PER];
+    float rb[T::B_PER][4 * LB::NRAW];
     lb.init(bcol);
 
     auto fetch = [&](int c) {
 #pragma unroll
         for (int r = 0; r < T::A_PER; ++r) {
-            const int e = tid + r * NT_;
-            ra[r] = la.load(c * BK + e / T::BM, e % T::BM);
+            const int e4 = tid + r * NT_;
+            if (T::A_VEC % NT_ == 0 || e4 < T::A_VEC)
+                ra[r] = la.load4(c * BK + e4 / (T::BM / 4), (e4 % (T::BM / 4)) * 4);
         }
 #pragma unroll
-        for (int r = 0; r < T::B_PER; ++r) rb[r] = lb.load(c * BK + bk0 + r * T::BKSTEP);
+        for (int r = 0; r < T::B_PER; ++r) lb.fetch(c * BK + bk0 + r * T::BKSTEP, rb[r]);
     };
-    auto commit = [&](float* buf) {
+    auto commit = [&](int c, float* buf) {
         float* As = buf;
         float* Bs = buf + BK * T::BM;
 #pragma unroll
-        for (int r = 0; r < T::A_PER; ++r) As[tid + r * NT_] = ra[r];
+        for (int r = 0; r < T::A_PER; ++r) {
+            const int e4 = tid + r * NT_;
+            if (T::A_VEC % NT_ == 0 || e4 < T::A_VEC) *reinterpret_cast<float4*>(As + e4 * 4) = ra[r];
+        }
 #pragma unroll
-        for (int r = 0; r < T::B_PER; ++r) Bs[(bk0 + r * T::BKSTEP) * T::BN + bcol] = rb[r];
+        for (int r = 0; r < T::B_PER; ++r) {
+            float o[4];
+            lb.finish(c * BK + bk0 + r * T::BKSTEP, rb[r], o);
+            *reinterpret_cast<float4*>(Bs + (bk0 + r * T::BKSTEP) * T::BN + bcol) =
+                make_float4(o[0], o[1], o[2], o[3]);
+        }
     };
 
     fetch(0);
-    commit(smem);
+    commit(0, smem);
     __syncthreads();
     const int arow = (lane >> 5), acol = wm * T::MT * 32 + (lane & 31);
     const int bcol_f = wn * T::NT * 32 + (lane & 31);
@@ -107,7 +121,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::MT][T::NT], const
                 for (int j = 0; j < T::NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < nchunks) commit(smem + ((c + 1) & 1) * T::STAGE);
+        if (c + 1 < nchunks) commit(c + 1, smem + ((c + 1) & 1) * T::STAGE);
         __syncthreads();
     }
 }
@@ -130,173 +144,236 @@ __device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[T::MT][T::NT], 
             }
 }
 
-struct WLoader {                       // packed Wt[Kp][Mp]
+struct WLoader {                       // packed Wt[Kp][Mp], rows 16-byte aligned
     const float* wt; int Mp, m0;
-    __device__ __forceinline__ float load(int k, int m) const { return wt[(size_t)k * Mp + m0 + m]; }
+    __device__ __forceinline__ float4 load4(int k, int m) const {
+        return *reinterpret_cast<const float4*>(wt + (size_t)k * Mp + m0 + m);
+    }
+};
+
+// B operand = rows of a [K][ld] matrix, columns c0+col .. (zero outside [0,ncols) and k >= K),
+// optional scale -> ELU applied at commit time.  16-byte loads when the tile is aligned.
+struct RowLoader {
+    static constexpr int NRAW = 1;
+    const float* base; int K, ld, ncols, c0; float scale; int elu;
+    const float* p; int c; bool full, vec;
+    __device__ __forceinline__ void init(int col4) {
+        c = c0 + col4;
+        full = c >= 0 && c + 3 < ncols;
+        vec = full && ((ld & 3) == 0) && ((c & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+        p = base + c;
+    }
+    __device__ __forceinline__ void fetch(int k, float (&raw)[4]) const {
+        if (k < K && vec) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * ld);
+            raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                raw[i] = (k < K && c + i >= 0 && c + i < ncols) ? p[(size_t)k * ld + i] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void finish(int, const float (&raw)[4], float (&o)[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = act(raw[i], scale, elu);      // act(0) == 0
+    }
 };
 
 // ------------------------------------------------------------------------------------------
 // K1  pw_dw:  Y = epi( DWconv(W @ act(s*X)) + b )
 // One workgroup: (m-tile, time-tile, clip).  The GEMM produces H[BM][BN] for the input-time
-// window the output tile needs (halo = (ks-1)*d - (s-1) on the left, recomputed per tile);
-// H goes to LDS (aliasing the staging buffers) and the depth-wise stencil + FiLM / residual
-// epilogue reads it back with time on the lanes, so global stores are coalesced.
+// window the output tile needs (halo = (ks-1)*d - (s-1) on the left, recomputed per tile; the
+// window start is 4-aligned so X rows are read with 16-byte loads); H goes to LDS (aliasing the
+// staging buffers) and the depth-wise stencil + FiLM / residual epilogue reads it back one
+// channel row per wave: the row's taps, bias and FiLM scalars are wave-uniform (SGPRs), time is
+// on the lanes, global stores are 256-byte coalesced.
 // Zero padding: X is staged as 0 outside [0,Tin) and the 1x1 has no bias, so H is 0 there,
 // which is exactly the zero pad SConv1d inserts between the 1x1 and the DW conv.
 // ------------------------------------------------------------------------------------------
-struct XLoaderPw {
-    const float* Xb; int K, Tin, ti0; float scale; int elu;
-    const float* p; bool inb;
-    __device__ __forceinline__ void init(int col) {
-        const int ti = ti0 + col;
-        inb = ti >= 0 && ti < Tin;
-        p = Xb + (inb ? ti : 0);
-    }
-    __device__ __forceinline__ float load(int k) const {
-        return (inb && k < K) ? act(p[(size_t)k * Tin], scale, elu) : 0.f;
-    }
-};
-
-template <class T>
+template <class T, int KS>
 __global__ __launch_bounds__(NT_) void pw_dw_kernel(PwDwArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HLD = T::BN + 4;
     const int m0 = blockIdx.x * T::BM;
     const int b = blockIdx.z;
     const int M = p.pw.M, K = p.pw.K;
-    const int tto = (T::BN - (p.ks - 1) * p.dil - 1) / p.stride + 1;   // outputs per tile
-    const int to0 = blockIdx.y * tto;
-    const int ti0 = to0 * p.stride - p.pad;
+    const int ks = KS ? KS : p.ks;
+    const int to0 = blockIdx.y * p.tto;
+    const int ti0 = to0 * p.stride - p.pad - p.off;
 
     f32x16 acc[T::MT][T::NT];
     zero_acc<T>(acc);
     WLoader la{p.pw.wt, p.pw.Mp, m0};
-    XLoaderPw lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, false};
+    RowLoader lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu,
+                 nullptr, 0, false, false};
     gemm_mainloop<T>(acc, la, lb, p.pw.Kp / BK, smem);
 
     float* Hs = smem;                                    // [BM][HLD], aliases the stages
     for_each_acc<T>(acc, [&](int row, int col, float v) { Hs[row * HLD + col] = v; });
     __syncthreads();
 
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bw = p.film ? (M / p.bands) : 1;
     const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
-    int o = threadIdx.x % tto, m = threadIdx.x / tto;
-    const int dm = NT_ / tto, dq = NT_ % tto;
-    while (m < T::BM) {
-        const int gm = m0 + m, to = to0 + o;
-        if (gm < M && to < p.Tout) {
-            float y = p.dw_b ? p.dw_b[gm] : 0.f;
-            const float* h = Hs + m * HLD + o * p.stride;
-            const float* w = p.dw_w + (size_t)gm * p.ks;
-            for (int i = 0; i < p.ks; ++i) y = fmaf(w[i], h[i * p.dil], y);
-            if (filmb) {
-                const int band = gm / bw;
-                y = y * filmb[2 * band] + filmb[2 * band + 1];
-            }
-            const size_t oi = ((size_t)b * M + gm) * p.Tout + to;
-            if (p.resid) y = y * p.out_scale + p.resid[oi];
-            if (p.post_elu) y = elu1(y * p.post_scale);
-            p.Y[oi] = y;
+    for (int m = wave; m < T::BM; m += 4) {              // m is wave-uniform
+        const int gm = m0 + m;
+        if (gm >= M) break;
+        const float* wr = p.dw_w + (size_t)gm * ks;
+        float w[KS ? KS : 1];
+        if (KS) {
+#pragma unroll
+            for (int i = 0; i < KS; ++i) w[i] = wr[i];
         }
-        o += dq; m += dm;
-        if (o >= tto) { o -= tto; ++m; }
+        const float bias = p.dw_b ? p.dw_b[gm] : 0.f;
+        float gam = 1.f, bet = 0.f;
+        if (filmb) { const int band = gm / bw; gam = filmb[2 * band]; bet = filmb[2 * band + 1]; }
+        const float* hrow = Hs + m * HLD + p.off;
+        const size_t obase = ((size_t)b * M + gm) * p.Tout;
+        for (int o = lane; o < p.tto; o += 64) {
+            const int to = to0 + o;
+            if (to >= p.Tout) break;
+            const float* h = hrow + o * p.stride;
+            float y = bias;
+            if (KS) {
+#pragma unroll
+                for (int i = 0; i < KS; ++i) y = fmaf(w[i], h[i * p.dil], y);
+            } else {
+                for (int i = 0; i < ks; ++i) y = fmaf(wr[i], h[i * p.dil], y);
+            }
+            y = fmaf(y, gam, bet);
+            if (p.resid) y = fmaf(y, p.out_scale, p.resid[obase + to]);
+            if (p.post_elu) y = elu1(y * p.post_scale);
+            p.Y[obase + to] = y;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // K2  dw_pw:  Y = epi( W @ producer(X) + b ), producer fused into the B-operand loader.
+//   MODE 0: act(s*X)   MODE 1: causal DW conv k of act(s*X)   MODE 2: DW ConvTranspose(2r, r)
 // ------------------------------------------------------------------------------------------
-struct XLoaderDw {
-    const float* Xb; const float* dw_w; int K, Tin, Tout, t0, mode, ks, ratio; float scale; int elu;
-    int t, l, ph; bool inb;
-    __device__ __forceinline__ void init(int col) {
-        t = t0 + col;
-        inb = t < Tout;
-        l = 0; ph = 0;
-        if (mode == 2) { l = t / ratio; ph = t - l * ratio; }
-    }
-    __device__ __forceinline__ float load(int k) const {
-        if (!inb || k >= K) return 0.f;
-        const float* xr = Xb + (size_t)k * Tin;
-        if (mode == 0) return act(xr[t], scale, elu);
-        if (mode == 1) {                           // causal depth-wise conv, stride 1, no bias
-            const float* w = dw_w + (size_t)k * ks;
+struct ConvLoader {                    // MODE 1 (conv_post only: tiny layer, computed at commit)
+    static constexpr int NRAW = 1;
+    const float* Xb; const float* dw_w; int K, Tin, t0, ks; float scale; int elu; int t;
+    __device__ __forceinline__ void init(int col4) { t = t0 + col4; }
+    __device__ __forceinline__ void fetch(int, float (&)[4]) const {}
+    __device__ __forceinline__ void finish(int k, const float (&)[4], float (&o)[4]) const {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
             float v = 0.f;
-            for (int i = 0; i < ks; ++i) {
-                const int ti = t - (ks - 1) + i;
-                if (ti >= 0) v = fmaf(w[i], act(xr[ti], scale, elu), v);
+            if (k < K && t + c < Tin) {
+                const float* xr = Xb + (size_t)k * Tin;
+                const float* w = dw_w + (size_t)k * ks;
+                for (int i = 0; i < ks; ++i) {
+                    const int ti = t + c - (ks - 1) + i;
+                    if (ti >= 0) v = fmaf(w[i], act(xr[ti], scale, elu), v);
+                }
             }
-            return v;
+            o[c] = v;
         }
-        // mode 2: depth-wise ConvTranspose k=2r, s=r, right-trimmed by r (polyphase form)
-        const float* w = dw_w + (size_t)k * 2 * ratio;
-        float v = act(xr[l], scale, elu) * w[ph];
-        if (l >= 1) v = fmaf(act(xr[l - 1], scale, elu), w[ph + ratio], v);
-        return v;
     }
 };
 
-template <class T>
+struct ConvTrLoader {                  // MODE 2: polyphase depth-wise ConvTranspose, right-trimmed
+    static constexpr int NRAW = 4;     // x[l], x[l-1], w[ph], w[ph+r] per column
+    const float* Xb; const float* dw_w; int K, Tin, Tout, t0, ratio; float scale; int elu;
+    int l[4], ph[4]; bool inb[4];
+    __device__ __forceinline__ void init(int col4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int t = t0 + col4 + c;
+            inb[c] = t < Tout;
+            l[c] = t / ratio; ph[c] = t - l[c] * ratio;
+        }
+    }
+    __device__ __forceinline__ void fetch(int k, float (&raw)[16]) const {
+        const bool kv = k < K;
+        const float* xr = Xb + (size_t)(kv ? k : 0) * Tin;
+        const float* w = dw_w + (size_t)(kv ? k : 0) * 2 * ratio;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool v = kv && inb[c];
+            raw[4 * c + 0] = v ? xr[l[c]] : 0.f;
+            raw[4 * c + 1] = (v && l[c] >= 1) ? xr[l[c] - 1] : 0.f;
+            raw[4 * c + 2] = v ? w[ph[c]] : 0.f;
+            raw[4 * c + 3] = v ? w[ph[c] + ratio] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void finish(int, const float (&raw)[16], float (&o)[4]) const {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            o[c] = fmaf(act(raw[4 * c + 1], scale, elu), raw[4 * c + 3],
+                        act(raw[4 * c], scale, elu) * raw[4 * c + 2]);
+    }
+};
+
+template <class T, class LB>
+__device__ __forceinline__ void dw_pw_body(const DwPwArgs& p, LB& lb, float* smem, int m0, int t0, int b) {
+    constexpr int HLD = T::BN + 4;
+    const int M = p.pw.M;
+    {
+        f32x16 acc[T::MT][T::NT];
+        zero_acc<T>(acc);
+        WLoader la{p.pw.wt, p.pw.Mp, m0};
+        gemm_mainloop<T>(acc, la, lb, p.pw.Kp / BK, smem);
+        float* Hs = smem;                                // [BM][HLD], aliases the stages
+        for_each_acc<T>(acc, [&](int row, int col, float v) { Hs[row * HLD + col] = v; });
+    }
+    __syncthreads();
+    float* Hs = smem;
+    float* Yb = p.Y + (size_t)b * M * p.Tout;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ncol = min(T::BN, p.Tout - t0);
+    float* inv = Hs + T::BM * HLD;                       // [BN] column scale (L2-norm only)
+    if (p.l2norm) {
+        // L2Norm over channels (seanet.py:288-318): y = v / max(||v||_2, 1e-12) * sqrt(M).
+        // The host guarantees a single m-tile (M <= BM).
+        for (int c = threadIdx.x; c < T::BN; c += NT_) {
+            float ss = 0.f;
+            for (int m = 0; m < M; ++m) {
+                const float v = Hs[m * HLD + c] + (p.bias ? p.bias[m] : 0.f);
+                ss = fmaf(v, v, ss);
+            }
+            inv[c] = sqrtf((float)M) / fmaxf(sqrtf(ss), 1e-12f);
+        }
+        __syncthreads();
+    }
+    for (int m = wave; m < T::BM; m += 4) {              // wave-uniform row, time on the lanes
+        const int gm = m0 + m;
+        if (gm >= M) break;
+        const float bias = p.bias ? p.bias[gm] : 0.f;
+        float* yrow = Yb + (size_t)gm * p.Tout + t0;
+        const float* h = Hs + m * HLD;
+        for (int c = lane; c < ncol; c += 64) {
+            float v = h[c];
+            if (p.accumulate) v = fmaf(p.out_scale, v, yrow[c]);
+            else v += bias;
+            if (p.l2norm) v *= inv[c];
+            yrow[c] = v;
+        }
+    }
+}
+
+template <class T, int MODE>
 __global__ __launch_bounds__(NT_) void dw_pw_kernel(DwPwArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int m0 = blockIdx.x * T::BM;
     const int t0 = blockIdx.y * T::BN;
     const int b = blockIdx.z;
-    const int M = p.pw.M, K = p.pw.K;
-
-    f32x16 acc[T::MT][T::NT];
-    zero_acc<T>(acc);
-    WLoader la{p.pw.wt, p.pw.Mp, m0};
-    XLoaderDw lb{p.X + (size_t)b * K * p.Tin, p.dw_w, K, p.Tin, p.Tout, t0, p.mode, p.ks, p.ratio,
-                 p.pre_scale, p.pre_elu, 0, 0, 0, false};
-    gemm_mainloop<T>(acc, la, lb, p.pw.Kp / BK, smem);
-
-    float* Yb = p.Y + (size_t)b * M * p.Tout;
-    if (p.l2norm) {
-        // L2Norm over channels (seanet.py:288-318); host guarantees a single m-tile (M <= BM).
-        float* red = smem;                               // [WM][BN]
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int wm = wave / T::WN, wn = wave % T::WN;
-        float ss[T::NT];
-#pragma unroll
-        for (int j = 0; j < T::NT; ++j) ss[j] = 0.f;
-#pragma unroll
-        for (int i = 0; i < T::MT; ++i)
-#pragma unroll
-            for (int j = 0; j < T::NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * T::MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    float v = 0.f;
-                    if (row < M) v = acc[i][j][r] + (p.bias ? p.bias[row] : 0.f);
-                    acc[i][j][r] = v;
-                    ss[j] = fmaf(v, v, ss[j]);
-                }
-#pragma unroll
-        for (int j = 0; j < T::NT; ++j) {
-            ss[j] += __shfl_xor(ss[j], 32);
-            if (lane < 32) red[wm * T::BN + wn * T::NT * 32 + j * 32 + lane] = ss[j];
-        }
-        __syncthreads();
-        const float sq = sqrtf((float)M);
-        for_each_acc<T>(acc, [&](int row, int col, float v) {
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < T::WM; ++w) tot += red[w * T::BN + col];
-            const int t = t0 + col;
-            if (row < M && t < p.Tout)
-                Yb[(size_t)row * p.Tout + t] = v / fmaxf(sqrtf(tot), 1e-12f) * sq;
-        });
-        return;
+    const int K = p.pw.K;
+    const float* Xb = p.X + (size_t)b * K * p.Tin;
+    if (MODE == 0) {
+        RowLoader lb{Xb, K, p.Tin, p.Tin, t0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
+        dw_pw_body<T>(p, lb, smem, m0, t0, b);
+    } else if (MODE == 1) {
+        ConvLoader lb{Xb, p.dw_w, K, p.Tin, t0, p.ks, p.pre_scale, p.pre_elu, 0};
+        dw_pw_body<T>(p, lb, smem, m0, t0, b);
+    } else {
+        ConvTrLoader lb{Xb, p.dw_w, K, p.Tin, p.Tout, t0, p.ratio, p.pre_scale, p.pre_elu, {}, {}, {}};
+        dw_pw_body<T>(p, lb, smem, m0, t0, b);
     }
-    for_each_acc<T>(acc, [&](int row, int col, float v) {
-        const int gm = m0 + row, t = t0 + col;
-        if (gm < M && t < p.Tout) {
-            const size_t oi = (size_t)gm * p.Tout + t;
-            if (p.accumulate) Yb[oi] = fmaf(p.out_scale, v, Yb[oi]);
-            else Yb[oi] = v + (p.bias ? p.bias[gm] : 0.f);
-        }
-    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -306,16 +383,27 @@ __global__ __launch_bounds__(NT_) void dw_pw_kernel(DwPwArgs p) {
 // magnitude needs no cross-lane traffic.
 // ------------------------------------------------------------------------------------------
 struct FrameLoader {
+    static constexpr int NRAW = 1;
     const float* wb; int T, Tf, n_fft, hop, t0;
-    int base; bool inb;
-    __device__ __forceinline__ void init(int col) {
-        const int t = t0 + col;
-        inb = t < Tf;
-        base = t * hop - (n_fft - 1);
+    int base[4]; bool inb[4];
+    __device__ __forceinline__ void init(int col4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int t = t0 + col4 + c;
+            inb[c] = t < Tf;
+            base[c] = t * hop - (n_fft - 1);
+        }
     }
-    __device__ __forceinline__ float load(int k) const {
-        const int idx = base + k;
-        return (inb && k < n_fft && idx >= 0 && idx < T) ? wb[idx] : 0.f;
+    __device__ __forceinline__ void fetch(int k, float (&raw)[4]) const {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int idx = base[c] + k;
+            raw[c] = (inb[c] && k < n_fft && idx >= 0 && idx < T) ? wb[idx] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void finish(int, const float (&raw)[4], float (&o)[4]) const {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = raw[c];
     }
 };
 
@@ -328,7 +416,7 @@ __global__ __launch_bounds__(NT_) void stft_logmag_kernel(StftArgs p) {
     f32x16 acc[T::MT][T::NT];
     zero_acc<T>(acc);
     WLoader la{p.basis_t, p.Mp, m0};
-    FrameLoader lb{p.wav + (size_t)b * p.T, p.T, p.Tf, p.n_fft, p.hop, t0, 0, false};
+    FrameLoader lb{p.wav + (size_t)b * p.T, p.T, p.Tf, p.n_fft, p.hop, t0, {}, {}};
     gemm_mainloop<T>(acc, la, lb, (p.n_fft + BK - 1) / BK, smem);
 
     float* Pb = p.P + (size_t)b * p.F * p.Tf;
@@ -423,20 +511,17 @@ __global__ __launch_bounds__(NT_) void tail_kernel(const float* __restrict__ H,
 // sigmoid + mean over time are reduced in-register, so for detect() the [B,nb,T] logits
 // never reach HBM (core.py:577-580); summation order is fixed -> deterministic.
 // ------------------------------------------------------------------------------------------
-struct ZLoader {
+struct ZLoader {                       // A operand: rows = frames of one clip, Z[b][k][f]
     const float* Zb; int D, Fr, f0;
-    __device__ __forceinline__ float load(int k, int m) const {
-        const int f = f0 + m;
-        return (k < D && f < Fr) ? Zb[(size_t)k * Fr + f] : 0.f;
+    __device__ __forceinline__ float4 load4(int k, int m) const {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = f0 + m + i;
+            v[i] = (k < D && f < Fr) ? Zb[(size_t)k * Fr + f] : 0.f;
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
     }
-};
-struct WcLoader {
-    const float* wc; int D, ld, hop, j0; const float* p; bool inb;
-    __device__ __forceinline__ void init(int col) {
-        inb = j0 + col < hop;
-        p = wc + (inb ? j0 + col : 0);
-    }
-    __device__ __forceinline__ float load(int k) const { return (inb && k < D) ? p[(size_t)k * ld] : 0.f; }
 };
 
 template <class T>
@@ -451,7 +536,8 @@ __global__ __launch_bounds__(NT_) void head_kernel(HeadArgs p) {
             f32x16 acc[T::MT][T::NT];
             zero_acc<T>(acc);
             ZLoader la{p.Z + (size_t)b * p.D * p.Fr, p.D, p.Fr, f0};
-            WcLoader lb{p.wc + (size_t)bit * p.hop, p.D, p.nb * p.hop, p.hop, j0, nullptr, false};
+            RowLoader lb{p.wc + (size_t)bit * p.hop, p.D, p.nb * p.hop, p.hop, j0, 1.f, 0,
+                         nullptr, 0, false, false};
             gemm_mainloop<T>(acc, la, lb, nchunks, smem);
             for_each_acc<T>(acc, [&](int row, int col, float v) {
                 const int f = f0 + row, j = j0 + col;
@@ -590,26 +676,49 @@ static hipError_t set_smem(K kernel, size_t bytes) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <class T>
-static hipError_t run_pw_dw(const PwDwArgs& a, hipStream_t s) {
-    const int tto = (T::BN - (a.ks - 1) * a.dil - 1) / a.stride + 1;
-    if (tto < 1 || tto > NT_) return hipErrorInvalidValue;
+static int gcd_(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+// Time-tile geometry of K1: the H window of a tile starts at ti0 = to0*s - pad - off with `off`
+// chosen so that ti0 is a multiple of 4 for every tile (16-byte X loads); tto outputs per tile.
+static bool pw_dw_geometry(PwDwArgs& a, int BN) {
+    const int span = (a.ks - 1) * a.dil + 1;
+    a.off = (4 - (a.pad % 4)) % 4;
+    int tto = (BN - a.off - span) / a.stride + 1;
+    const int q = 4 / gcd_(a.stride, 4);
+    tto -= tto % q;
+    if (tto < 1) {                                  // cannot align: plain window, scalar loads
+        a.off = 0;
+        tto = (BN - span) / a.stride + 1;
+    }
+    a.tto = tto;
+    return tto >= 1;
+}
+
+template <class T, int KS>
+static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
+    if (!pw_dw_geometry(a, T::BN)) return hipErrorInvalidValue;
     size_t smem = stage_bytes<T>();
     const size_t hb = (size_t)T::BM * (T::BN + 4) * sizeof(float);
     if (hb > smem) smem = hb;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = set_smem(pw_dw_kernel<T>, smem);
+        hipError_t e = set_smem(pw_dw_kernel<T, KS>, smem);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + tto - 1) / tto, a.B);
-    static const std::string name = tile_name<T>("pw_dw");
+    dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + a.tto - 1) / a.tto, a.B);
+    static const std::string name = tile_name<T>(KS ? "pw_dw_k5" : "pw_dw");
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
     prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
                    4.0 * Bd * (K * a.Tin + M * a.Tout * (a.resid ? 2.0 : 1.0)));
-    hipLaunchKernelGGL(pw_dw_kernel<T>, grid, dim3(NT_), smem, s, a);
+    hipLaunchKernelGGL((pw_dw_kernel<T, KS>), grid, dim3(NT_), smem, s, a);
     return hipGetLastError();
+}
+
+template <class T>
+static hipError_t run_pw_dw(const PwDwArgs& a, hipStream_t s) {
+    if (a.ks == 5) return run_pw_dw_ks<T, 5>(a, s);
+    return run_pw_dw_ks<T, 0>(a, s);
 }
 
 static int pick_bm(int M) {
@@ -622,10 +731,10 @@ static int pick_bm(int M) {
 }
 
 hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
-    if (a.ks < 1 || a.stride < 1 || a.dil < 1 || a.pw.Mp % M_ALIGN || a.pw.Kp % BK)
+    if (a.ks < 1 || a.stride < 1 || a.dil < 1 || a.pad < 0 || a.pw.Mp % M_ALIGN || a.pw.Kp % BK)
         return hipErrorInvalidValue;
     const int need = (a.ks - 1) * a.dil + 1;            // H columns one output needs
-    const bool narrow = a.Tin + a.pad <= 64 && need <= 64;
+    const bool narrow = a.Tin + a.pad + 3 <= 64 && need + 3 <= 64;
     if (narrow) {
         if (pick_bm(a.pw.M) <= 64) return run_pw_dw<Tile<64, 64, 2, 2>>(a, s);
         return run_pw_dw<Tile<128, 64, 2, 2>>(a, s);
@@ -638,23 +747,38 @@ hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
     }
 }
 
-template <class T>
-static hipError_t run_dw_pw(const DwPwArgs& a, hipStream_t s) {
-    const size_t smem = stage_bytes<T>();
+template <class T, int MODE>
+static hipError_t run_dw_pw_mode(const DwPwArgs& a, hipStream_t s) {
+    size_t smem = stage_bytes<T>();
+    const size_t hb = ((size_t)T::BM * (T::BN + 4) + T::BN) * sizeof(float);
+    if (hb > smem) smem = hb;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = set_smem(dw_pw_kernel<T, MODE>, smem);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
     if (a.l2norm && a.pw.M > T::BM) return hipErrorInvalidValue;
     dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + T::BN - 1) / T::BN, a.B);
-    static const std::string name = tile_name<T>("dw_pw");
+    static const std::string name = tile_name<T>(MODE == 0 ? "pw" : (MODE == 1 ? "dwconv_pw" : "convtr_pw"));
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
     const double stencil = a.mode == 1 ? 2.0 * a.ks : (a.mode == 2 ? 4.0 : 0.0);
     prof::Scope ps(s, name.c_str(), Bd * a.Tout * (2.0 * M * K + stencil * K),
                    4.0 * Bd * (K * a.Tin + M * a.Tout * (a.accumulate ? 2.0 : 1.0)));
-    hipLaunchKernelGGL(dw_pw_kernel<T>, grid, dim3(NT_), smem, s, a);
+    hipLaunchKernelGGL((dw_pw_kernel<T, MODE>), grid, dim3(NT_), smem, s, a);
     return hipGetLastError();
+}
+
+template <class T>
+static hipError_t run_dw_pw(const DwPwArgs& a, hipStream_t s) {
+    if (a.mode == 0) return run_dw_pw_mode<T, 0>(a, s);
+    if (a.mode == 1) return run_dw_pw_mode<T, 1>(a, s);
+    return run_dw_pw_mode<T, 2>(a, s);
 }
 
 hipError_t launch_dw_pw(const DwPwArgs& a, hipStream_t s) {
     if (a.pw.Mp % M_ALIGN || a.pw.Kp % BK || a.mode < 0 || a.mode > 2) return hipErrorInvalidValue;
-    if (a.mode == 2 && a.Tout != a.Tin * a.ratio) return hipErrorInvalidValue;
+    if (a.mode == 2 && (a.Tout != a.Tin * a.ratio || a.ratio < 1)) return hipErrorInvalidValue;
     if (a.mode != 2 && a.Tout != a.Tin) return hipErrorInvalidValue;
     int bm = pick_bm(a.pw.M);
     if (a.l2norm) bm = a.pw.M <= 64 ? 64 : 128;
