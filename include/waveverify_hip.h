@@ -189,6 +189,7 @@ int wv_model_film(wv_model* m, const float* msg, int msg_rows, float* film, int 
  * aggregated by "<kernel>|<role>" together with its ALGORITHMIC flops and bytes (the per-unit
  * figures of DESIGN.md).  wv_profile_collect(-1, ...) synchronises, snapshots and returns the
  * number of entries; wv_profile_collect(i, ...) reads entry i of that snapshot. */
+int wv_debug_flags(int flags);   /* kernel ablation switches for tools/kbench.py; 0 in production */
 int wv_profile_enable(int on);
 int wv_profile_reset(void);
 int wv_profile_collect(int index, char* name_out, int name_cap, int64_t* launches,

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark / ablation for K1 (pw_dw): one layer shape, event-timed through the
+library's profiler.  python tools/kbench.py [C T B]"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from waveverify_amd import ops, profile, _lib
+
+def run(C, T, B, M=None, ks=5, stride=1, resid=True, reps=5, flags=0, film=False):
+    M = M or C
+    rng = np.random.default_rng(0)
+    X = torch.randn(B, C, T, device="cuda")
+    w_pw = rng.standard_normal((M, C, 1)).astype(np.float32) * C ** -0.5
+    w_dw = rng.standard_normal((M, 1, ks)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    Tout = -(-T // stride)
+    R = torch.randn(B, M, Tout, device="cuda") if resid else None
+    _lib.load().wv_debug_flags(flags)
+    profile.reset(); profile.enable(True)
+    for _ in range(reps):
+        ops.pw_dw(X, w_pw, w_dw, b, resid=R, stride=stride, pre_scale=0.87, pre_elu=True, out_scale=0.5)
+    profile.enable(False)
+    e = profile.collect()[0]
+    _lib.load().wv_debug_flags(0)
+    us = e["ms"] / e["launches"] * 1e3
+    tf = e["flops"] / e["launches"] / (us * 1e-6) / 1e12
+    gb = e["bytes"] / e["launches"] / (us * 1e-6) / 1e9
+    return us, tf, gb, e["kernel"]
+
+if __name__ == "__main__":
+    shapes = [(128, 8000, 256), (64, 16000, 256), (512, 400, 256), (768, 400, 256), (96, 16000, 256)]
+    if len(sys.argv) == 4:
+        shapes = [tuple(int(v) for v in sys.argv[1:4])]
+    names = {0: "full", 1: "no-epilogue", 9: "no-epi,no-Hspill", 3: "no-epi,no-mfma", 5: "no-epi,no-Xload",
+             7: "no-epi,no-mfma,no-Xload", 2: "no-mfma", 4: "no-Xload"}
+    for C, T, B in shapes:
+        for fl, nm in names.items():
+            us, tf, gb, k = run(C, T, B, flags=fl)
+            print(f"C={C:4d} T={T:6d} {k:24s} {nm:26s} {us:9.1f} us  {tf:6.1f} TF/s {gb:7.1f} GB/s", flush=True)

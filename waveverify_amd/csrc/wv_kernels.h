@@ -34,6 +34,8 @@ struct PwDwArgs {
     int bands, film_stride;
     float post_scale;     // optional activation of the OUTPUT (consumer's prologue hoisted):
     int post_elu;         //   y = post_elu ? ELU(post_scale*y) : y
+    int dbg;              // ablation flags (tools/kbench.py): 1 skip stencil epilogue, 2 skip MFMA,
+                          // 4 skip X loads, 8 skip H spill
     int tto, off;         // filled by launch_pw_dw: outputs per time tile; stencil offset inside
                           // the 4-aligned H window
 };
@@ -102,6 +104,7 @@ hipError_t launch_film(const FilmArgs& a, hipStream_t s);
 // ---- optional per-launch profiling with HIP events on the launch stream ---------------------
 // When enabled every launcher brackets its kernel with an event pair; entries aggregate by
 // "<kernel symbol>|<role>".  Roles are set by the model plan (e.g. "enc.down_film").
+void set_debug_flags(int flags);
 namespace prof {
 void enable(bool on);
 bool enabled();

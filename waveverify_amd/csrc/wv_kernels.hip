@@ -36,17 +36,17 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 template <int BM_, int BN_, int WM_, int WN_>
 struct Tile {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int NTHREADS = 64 * WM * WN;
     static constexpr int MT = BM / (32 * WM);
     static constexpr int NT = BN / (32 * WN);
     static constexpr int A_VEC = BK * BM / 4;                 // float4 per stage
-    static constexpr int A_PER = (A_VEC + NT_ - 1) / NT_;
+    static constexpr int A_PER = (A_VEC + NTHREADS - 1) / NTHREADS;
     static constexpr int B_TPR = BN / 4;                      // threads per k-row (4 columns each)
-    static constexpr int BKSTEP = NT_ / B_TPR;                // k rows per pass
-    static constexpr int B_PER = BK / BKSTEP;
+    static constexpr int BKSTEP = NTHREADS / B_TPR;           // k rows per pass
+    static constexpr int B_PER = (BK + BKSTEP - 1) / BKSTEP;
     static constexpr int STAGE = BK * (BM + BN);              // floats per LDS stage
-    static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(MT >= 1 && NT >= 1, "tile too small for the wave grid");
-    static_assert(BM % 4 == 0 && BK % BKSTEP == 0 && B_PER >= 1, "staging map");
+    static_assert(BM % 4 == 0 && NTHREADS % B_TPR == 0 && BKSTEP >= 1, "staging map");
 };
 
 template <class T>
@@ -63,35 +63,46 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[T::MT][T::NT]) {
 // LB: NRAW; init(col4); fetch(k, raw[4*NRAW]); finish(k, raw, out[4])   4 consecutive columns
 template <class T, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::MT][T::NT], const LA& la, LB& lb,
-                                              int nchunks, float* smem) {
+                                              int nchunks, float* smem, int dbg = 0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN;
     const int bcol = (tid % T::B_TPR) * 4, bk0 = tid / T::B_TPR;
     float4 ra[T::A_PER];
     float rb[T::B_PER][4 * LB::NRAW];
+    if (dbg & 4) {
+#pragma unroll
+        for (int r = 0; r < T::B_PER; ++r)
+#pragma unroll
+            for (int i = 0; i < 4 * LB::NRAW; ++i) rb[r][i] = 0.25f;
+    }
     lb.init(bcol);
 
     auto fetch = [&](int c) {
 #pragma unroll
         for (int r = 0; r < T::A_PER; ++r) {
-            const int e4 = tid + r * NT_;
-            if (T::A_VEC % NT_ == 0 || e4 < T::A_VEC)
+            const int e4 = tid + r * T::NTHREADS;
+            if (T::A_VEC % T::NTHREADS == 0 || e4 < T::A_VEC)
                 ra[r] = la.load4(c * BK + e4 / (T::BM / 4), (e4 % (T::BM / 4)) * 4);
         }
+        if (!(dbg & 4)) {
 #pragma unroll
-        for (int r = 0; r < T::B_PER; ++r) lb.fetch(c * BK + bk0 + r * T::BKSTEP, rb[r]);
+            for (int r = 0; r < T::B_PER; ++r)
+                if (BK % T::BKSTEP == 0 || bk0 + r * T::BKSTEP < BK)
+                    lb.fetch(c * BK + bk0 + r * T::BKSTEP, rb[r]);
+        }
     };
     auto commit = [&](int c, float* buf) {
         float* As = buf;
         float* Bs = buf + BK * T::BM;
 #pragma unroll
         for (int r = 0; r < T::A_PER; ++r) {
-            const int e4 = tid + r * NT_;
-            if (T::A_VEC % NT_ == 0 || e4 < T::A_VEC) *reinterpret_cast<float4*>(As + e4 * 4) = ra[r];
+            const int e4 = tid + r * T::NTHREADS;
+            if (T::A_VEC % T::NTHREADS == 0 || e4 < T::A_VEC) *reinterpret_cast<float4*>(As + e4 * 4) = ra[r];
         }
 #pragma unroll
         for (int r = 0; r < T::B_PER; ++r) {
+            if (!(BK % T::BKSTEP == 0 || bk0 + r * T::BKSTEP < BK)) continue;
             float o[4];
             lb.finish(c * BK + bk0 + r * T::BKSTEP, rb[r], o);
             *reinterpret_cast<float4*>(Bs + (bk0 + r * T::BKSTEP) * T::BN + bcol) =
@@ -108,6 +119,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::MT][T::NT], const
         const float* As = smem + (c & 1) * T::STAGE;
         const float* Bs = As + BK * T::BM;
         if (c + 1 < nchunks) fetch(c + 1);
+        if (!(dbg & 2))
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[T::MT], b[T::NT];
@@ -191,60 +203,138 @@ struct RowLoader {
 // which is exactly the zero pad SConv1d inserts between the 1x1 and the DW conv.
 // ------------------------------------------------------------------------------------------
 template <class T, int KS>
-__global__ __launch_bounds__(NT_) void pw_dw_kernel(PwDwArgs p) {
+__global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ? 3 : 2) void pw_dw_kernel(PwDwArgs p) {
+    // Row-strip tile: WN == 1, every wave owns 32 channel rows x the whole BN-column window, so
+    // the depth-wise stencil never crosses a wave: accumulators are spilled two rows at a time
+    // into a wave-private LDS strip (no workgroup barrier), read back with time on the lanes and
+    // written with 16-byte stores.  KS == 5 is the ResnetBlock fast path (k5, stride 1, dil 1).
+    static_assert(T::WN == 1 && T::MT == 1, "row-strip tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HLD = T::BN + 4;
     const int m0 = blockIdx.x * T::BM;
     const int b = blockIdx.z;
     const int M = p.pw.M, K = p.pw.K;
-    const int ks = KS ? KS : p.ks;
     const int to0 = blockIdx.y * p.tto;
     const int ti0 = to0 * p.stride - p.pad - p.off;
 
-    f32x16 acc[T::MT][T::NT];
+    f32x16 acc[1][T::NT];
     zero_acc<T>(acc);
     WLoader la{p.pw.wt, p.pw.Mp, m0};
     RowLoader lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu,
                  nullptr, 0, false, false};
-    gemm_mainloop<T>(acc, la, lb, p.pw.Kp / BK, smem);
+    gemm_mainloop<T>(acc, la, lb, p.pw.Kp / BK, smem, p.dbg);
+    if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.Y[0] = 0.f; return; }
 
-    float* Hs = smem;                                    // [BM][HLD], aliases the stages
-    for_each_acc<T>(acc, [&](int row, int col, float v) { Hs[row * HLD + col] = v; });
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, q = lane & 31;
+    float* Wl = smem;                                        // [BM][8] taps / bias / gamma / beta
+    float* Hw = smem + T::BM * 8 + wave * (2 * HLD);         // this wave's 2-row strip
     const int bw = p.film ? (M / p.bands) : 1;
     const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
-    for (int m = wave; m < T::BM; m += 4) {              // m is wave-uniform
-        const int gm = m0 + m;
-        if (gm >= M) break;
-        const float* wr = p.dw_w + (size_t)gm * ks;
-        float w[KS ? KS : 1];
-        if (KS) {
+    if (KS) {
+        for (int m = tid; m < T::BM; m += T::NTHREADS) {
+            const int gm = m0 + m;
+            float v[8] = {0, 0, 0, 0, 0, 0, 1.f, 0};
+            if (gm < M) {
 #pragma unroll
-            for (int i = 0; i < KS; ++i) w[i] = wr[i];
-        }
-        const float bias = p.dw_b ? p.dw_b[gm] : 0.f;
-        float gam = 1.f, bet = 0.f;
-        if (filmb) { const int band = gm / bw; gam = filmb[2 * band]; bet = filmb[2 * band + 1]; }
-        const float* hrow = Hs + m * HLD + p.off;
-        const size_t obase = ((size_t)b * M + gm) * p.Tout;
-        for (int o = lane; o < p.tto; o += 64) {
-            const int to = to0 + o;
-            if (to >= p.Tout) break;
-            const float* h = hrow + o * p.stride;
-            float y = bias;
-            if (KS) {
-#pragma unroll
-                for (int i = 0; i < KS; ++i) y = fmaf(w[i], h[i * p.dil], y);
-            } else {
-                for (int i = 0; i < ks; ++i) y = fmaf(wr[i], h[i * p.dil], y);
+                for (int i = 0; i < KS; ++i) v[i] = p.dw_w[(size_t)gm * KS + i];
+                v[5] = p.dw_b ? p.dw_b[gm] : 0.f;
+                if (filmb) { const int band = gm / bw; v[6] = filmb[2 * band]; v[7] = filmb[2 * band + 1]; }
             }
-            y = fmaf(y, gam, bet);
-            if (p.resid) y = fmaf(y, p.out_scale, p.resid[obase + to]);
-            if (p.post_elu) y = elu1(y * p.post_scale);
-            p.Y[obase + to] = y;
+            *reinterpret_cast<float4*>(Wl + m * 8) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(Wl + m * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        __syncthreads();
+    }
+    float* Yb = p.Y + (size_t)b * M * p.Tout;
+    const float* Rb = p.resid ? p.resid + (size_t)b * M * p.Tout : nullptr;
+
+    if (KS) {
+        // lane -> 4 consecutive outputs of one of the strip's two rows
+        const int o = 4 * q, to = to0 + o;
+        const bool act_lane = o < p.tto && to < p.Tout;
+        const bool vec = act_lane && to + 3 < p.Tout && o + 3 < p.tto && (p.Tout & 3) == 0;
+        auto row_of = [&](int r) { return 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half; };
+        float4 res[4];
+        auto load_res = [&](int r) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int gm = m0 + row_of(r);
+            if (Rb && act_lane && gm < M) {
+                const float* rp = Rb + (size_t)gm * p.Tout + to;
+                if (vec) v = *reinterpret_cast<const float4*>(rp);
+                else {
+                    v.x = rp[0];
+                    if (to + 1 < p.Tout) v.y = rp[1];
+                    if (to + 2 < p.Tout) v.z = rp[2];
+                    if (to + 3 < p.Tout) v.w = rp[3];
+                }
+            }
+            return v;
+        };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[r] = load_res(r);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int j = 0; j < T::NT; ++j) Hw[half * HLD + 32 * j + q] = acc[0][j][r];
+            const int row = row_of(r), gm = m0 + row;
+            const float4 rr = res[r & 3];
+            if (r + 4 < 16) res[r & 3] = load_res(r + 4);
+            if (act_lane && gm < M) {
+                const float4 h0 = *reinterpret_cast<const float4*>(Hw + half * HLD + o);
+                const float4 h1 = *reinterpret_cast<const float4*>(Hw + half * HLD + o + 4);
+                const float4 w0 = *reinterpret_cast<const float4*>(Wl + row * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(Wl + row * 8 + 4);
+                const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                const float rv[4] = {rr.x, rr.y, rr.z, rr.w};
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = w1.y;                                          // bias
+                    v = fmaf(w0.x, h[e], v); v = fmaf(w0.y, h[e + 1], v); v = fmaf(w0.z, h[e + 2], v);
+                    v = fmaf(w0.w, h[e + 3], v); v = fmaf(w1.x, h[e + 4], v);
+                    v = fmaf(v, w1.z, w1.w);                                 // FiLM (1, 0 when off)
+                    if (Rb) v = fmaf(v, p.out_scale, rv[e]);
+                    if (p.post_elu) v = elu1(v * p.post_scale);
+                    y[e] = v;
+                }
+                float* yp = Yb + (size_t)gm * p.Tout + to;
+                if (vec) *reinterpret_cast<float4*>(yp) = make_float4(y[0], y[1], y[2], y[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (o + e < p.tto && to + e < p.Tout) yp[e] = y[e];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the 64 accumulators in AGPRs until used
+        }
+    } else {
+        const int ks = p.ks;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int j = 0; j < T::NT; ++j) Hw[half * HLD + 32 * j + q] = acc[0][j][r];
+            const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half, gm = m0 + row;
+            if (gm < M) {
+                const float* wr = p.dw_w + (size_t)gm * ks;
+                const float bias = p.dw_b ? p.dw_b[gm] : 0.f;
+                float gam = 1.f, bet = 0.f;
+                if (filmb) { const int band = gm / bw; gam = filmb[2 * band]; bet = filmb[2 * band + 1]; }
+                const float* hrow = Hw + half * HLD + p.off;
+                for (int o = q; o < p.tto; o += 32) {
+                    const int to = to0 + o;
+                    if (to >= p.Tout) break;
+                    const float* h = hrow + o * p.stride;
+                    float y = bias;
+                    for (int i = 0; i < ks; ++i) y = fmaf(wr[i], h[i * p.dil], y);
+                    y = fmaf(y, gam, bet);
+                    if (Rb) y = fmaf(y, p.out_scale, Rb[(size_t)gm * p.Tout + to]);
+                    if (p.post_elu) y = elu1(y * p.post_scale);
+                    Yb[(size_t)gm * p.Tout + to] = y;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -601,6 +691,8 @@ __global__ __launch_bounds__(NT_) void film_kernel(FilmArgs p) {
 #include <string>
 #include <vector>
 namespace wv {
+static int g_debug_flags = 0;
+void set_debug_flags(int flags) { g_debug_flags = flags; }
 namespace prof {
 namespace {
 struct Rec { hipEvent_t a, b; int key; };
@@ -697,27 +789,22 @@ static bool pw_dw_geometry(PwDwArgs& a, int BN) {
 template <class T, int KS>
 static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     if (!pw_dw_geometry(a, T::BN)) return hipErrorInvalidValue;
+    a.dbg = g_debug_flags;
     size_t smem = stage_bytes<T>();
-    const size_t hb = (size_t)T::BM * (T::BN + 4) * sizeof(float);
-    if (hb > smem) smem = hb;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = set_smem(pw_dw_kernel<T, KS>, smem);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    const size_t eb = ((size_t)T::BM * 8 + (size_t)T::WM * 2 * (T::BN + 4)) * sizeof(float);
+    if (eb > smem) smem = eb;
     dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + a.tto - 1) / a.tto, a.B);
     static const std::string name = tile_name<T>(KS ? "pw_dw_k5" : "pw_dw");
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
     prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
                    4.0 * Bd * (K * a.Tin + M * a.Tout * (a.resid ? 2.0 : 1.0)));
-    hipLaunchKernelGGL((pw_dw_kernel<T, KS>), grid, dim3(NT_), smem, s, a);
+    hipLaunchKernelGGL((pw_dw_kernel<T, KS>), grid, dim3(T::NTHREADS), smem, s, a);
     return hipGetLastError();
 }
 
 template <class T>
 static hipError_t run_pw_dw(const PwDwArgs& a, hipStream_t s) {
-    if (a.ks == 5) return run_pw_dw_ks<T, 5>(a, s);
+    if (a.ks == 5 && a.stride == 1 && a.dil == 1 && a.pad == 4) return run_pw_dw_ks<T, 5>(a, s);
     return run_pw_dw_ks<T, 0>(a, s);
 }
 
@@ -735,15 +822,20 @@ hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
         return hipErrorInvalidValue;
     const int need = (a.ks - 1) * a.dil + 1;            // H columns one output needs
     const bool narrow = a.Tin + a.pad + 3 <= 64 && need + 3 <= 64;
+    const int bm = pick_bm(a.pw.M);
     if (narrow) {
-        if (pick_bm(a.pw.M) <= 64) return run_pw_dw<Tile<64, 64, 2, 2>>(a, s);
-        return run_pw_dw<Tile<128, 64, 2, 2>>(a, s);
+        switch (bm) {
+            case 32: return run_pw_dw<Tile<32, 64, 1, 1>>(a, s);
+            case 64: return run_pw_dw<Tile<64, 64, 2, 1>>(a, s);
+            case 96: return run_pw_dw<Tile<96, 64, 3, 1>>(a, s);
+            default: return run_pw_dw<Tile<128, 64, 4, 1>>(a, s);
+        }
     }
-    switch (pick_bm(a.pw.M)) {
-        case 32: return run_pw_dw<Tile<32, 128, 1, 4>>(a, s);
-        case 64: return run_pw_dw<Tile<64, 128, 1, 4>>(a, s);
-        case 96: return run_pw_dw<Tile<96, 128, 1, 4>>(a, s);
-        default: return run_pw_dw<Tile<128, 128, 1, 4>>(a, s);
+    switch (bm) {
+        case 32: return run_pw_dw<Tile<32, 128, 1, 1>>(a, s);
+        case 64: return run_pw_dw<Tile<64, 128, 2, 1>>(a, s);
+        case 96: return run_pw_dw<Tile<96, 128, 3, 1>>(a, s);
+        default: return run_pw_dw<Tile<128, 128, 4, 1>>(a, s);
     }
 }
 

@@ -783,6 +783,7 @@ int wv_locator_forward(wv_model* m, const float* x, float* logits, int B, int T,
     return run_head_model(m, x, logits, nullptr, B, T, ws, ws_bytes, stream);
 }
 
+int wv_debug_flags(int flags) { wv::set_debug_flags(flags); return WV_OK; }
 int wv_profile_enable(int on) { wv::prof::enable(on != 0); return WV_OK; }
 int wv_profile_reset(void) { wv::prof::reset(); return WV_OK; }
 int wv_profile_collect(int index, char* name_out, int name_cap, int64_t* launches, double* total_ms,
