@@ -31,8 +31,9 @@ if __name__ == "__main__":
     shapes = [(128, 8000, 256), (64, 16000, 256), (512, 400, 256), (768, 400, 256), (96, 16000, 256)]
     if len(sys.argv) == 4:
         shapes = [tuple(int(v) for v in sys.argv[1:4])]
-    names = {0: "full", 1: "no-epilogue", 9: "no-epi,no-Hspill", 3: "no-epi,no-mfma", 5: "no-epi,no-Xload",
-             7: "no-epi,no-mfma,no-Xload", 2: "no-mfma", 4: "no-Xload"}
+    names = {0: "full (stagger 4)", 255 << 8: "full, no stagger", (255 << 8) | 1: "no-epilogue", (255 << 8) | 2: "no-mfma"}
+    for st in (2, 8):
+        names[st << 8] = f"full, stagger {st}"
     for C, T, B in shapes:
         for fl, nm in names.items():
             us, tf, gb, k = run(C, T, B, flags=fl)

@@ -36,6 +36,7 @@ struct PwDwArgs {
     int post_elu;         //   y = post_elu ? ELU(post_scale*y) : y
     int dbg;              // ablation flags (tools/kbench.py): 1 skip stencil epilogue, 2 skip MFMA,
                           // 4 skip X loads, 8 skip H spill
+    int stagger, first_gen;   // de-phasing of the first workgroup generation (see kernel)
     int tto, off;         // filled by launch_pw_dw: outputs per time tile; stencil offset inside
                           // the 4-aligned H window
 };

@@ -217,6 +217,19 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
     const int to0 = blockIdx.y * p.tto;
     const int ti0 = to0 * p.stride - p.pad - p.off;
 
+    if (p.stagger > 0) {
+        // De-phase co-resident workgroups: the first generation (one per resident slot) starts
+        // together and, having identical work, would stay in lockstep -- all in the MFMA phase or
+        // all in the HBM-bound epilogue at once.  Delaying 1/3 and 2/3 of that first generation
+        // lets one workgroup's epilogue overlap another's matrix phase for the whole launch.
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin < (unsigned)p.first_gen) {
+            // consecutive ids round-robin over the 8 XCDs, then over an XCD's 32 CUs: ids that
+            // differ by 256 share a CU, so lin / 256 enumerates a CU's resident slots
+            const int slot = lin / 256;
+            for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     f32x16 acc[1][T::NT];
     zero_acc<T>(acc);
     WLoader la{p.pw.wt, p.pw.Mp, m0};
@@ -256,7 +269,8 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
         const bool act_lane = o < p.tto && to < p.Tout;
         const bool vec = act_lane && to + 3 < p.Tout && o + 3 < p.tto && (p.Tout & 3) == 0;
         auto row_of = [&](int r) { return 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half; };
-        float4 res[4];
+        constexpr int RP = 8;                                 // residual rows in flight per lane
+        float4 res[RP];
         auto load_res = [&](int r) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int gm = m0 + row_of(r);
@@ -273,14 +287,14 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
             return v;
         };
 #pragma unroll
-        for (int r = 0; r < 4; ++r) res[r] = load_res(r);
+        for (int r = 0; r < RP; ++r) res[r] = load_res(r);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #pragma unroll
             for (int j = 0; j < T::NT; ++j) Hw[half * HLD + 32 * j + q] = acc[0][j][r];
             const int row = row_of(r), gm = m0 + row;
-            const float4 rr = res[r & 3];
-            if (r + 4 < 16) res[r & 3] = load_res(r + 4);
+            const float4 rr = res[r % RP];
+            if (r + RP < 16) res[r % RP] = load_res(r + RP);
             if (act_lane && gm < M) {
                 const float4 h0 = *reinterpret_cast<const float4*>(Hw + half * HLD + o);
                 const float4 h1 = *reinterpret_cast<const float4*>(Hw + half * HLD + o + 4);
@@ -789,11 +803,23 @@ static bool pw_dw_geometry(PwDwArgs& a, int BN) {
 template <class T, int KS>
 static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     if (!pw_dw_geometry(a, T::BN)) return hipErrorInvalidValue;
-    a.dbg = g_debug_flags;
+    a.dbg = g_debug_flags & 15;
     size_t smem = stage_bytes<T>();
     const size_t eb = ((size_t)T::BM * 8 + (size_t)T::WM * 2 * (T::BN + 4)) * sizeof(float);
     if (eb > smem) smem = eb;
+    static int per_cu = -1;                               // resident workgroups per CU
+    if (per_cu < 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pw_dw_kernel<T, KS>, T::NTHREADS, smem) != hipSuccess || n < 1)
+            n = 1;
+        per_cu = n;
+    }
+    // de-phase the first generation of workgroups (see kernel); off for tiny grids
+    const int st_flag = (g_debug_flags >> 8) & 255;
+    a.stagger = st_flag == 255 ? 0 : (st_flag ? st_flag : 2);       // default 2 x s_sleep(127) per slot
+    a.first_gen = 256 * per_cu;
     dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + a.tto - 1) / a.tto, a.B);
+    if ((long long)grid.x * grid.y * grid.z < 4LL * a.first_gen) a.stagger = 0;
     static const std::string name = tile_name<T>(KS ? "pw_dw_k5" : "pw_dw");
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
     prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
