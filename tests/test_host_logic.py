@@ -1,0 +1,272 @@
+"""CPU-only tests of the host side: WatermarkID (against the reference's own answers), bit <-> tensor
+helpers, WAV I/O, metrics, checkpoint formats, parameter grammar, C-ABI exports, sharding."""
+import ctypes as C
+import json
+import os
+import re
+import struct
+import wave
+from datetime import datetime
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wv_oracle as O
+from waveverify_amd import WatermarkID
+from waveverify_amd import _lib, checkpoint, metrics, parallel, params, utils
+from waveverify_amd.config import default_config
+from waveverify_amd.init import random_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------- WatermarkID
+@pytest.fixture(scope="module")
+def wid_golden(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "watermark_ids.json")))
+
+
+def test_watermark_id_known_answers(wid_golden):
+    g = wid_golden
+    for s, bits in g["creator"].items():
+        assert WatermarkID.for_creator(s).bits == bits
+    for s, (bits, kind) in g["tracking"].items():
+        w = WatermarkID.for_tracking(s)
+        assert (w.bits, w.metadata["id_type"]) == (bits, kind)
+    for s, (bits, code, custom) in g["license"].items():
+        w = WatermarkID.for_license(s)
+        assert (w.bits, w.metadata["code"], w.metadata["is_custom"]) == (bits, code, custom)
+    for iso, bits in g["timestamp"].items():
+        assert WatermarkID.for_timestamp(datetime.fromisoformat(iso)).bits == bits
+    for rep, (bits, hx, iv, by, st) in g["custom"].items():
+        w = WatermarkID.custom(eval(rep))
+        assert (w.bits, w.to_hex(), w.to_int(), list(w.to_bytes()), str(w)) == (bits, hx, iv, by, st)
+    assert str(WatermarkID.for_creator("abc")) == g["str"]["creator"]
+    assert str(WatermarkID.for_license("MIT")) == g["str"]["license"]
+    assert str(WatermarkID.for_tracking("77")) == g["str"]["tracking"]
+    assert WatermarkID.custom(42).bits == "0000000000101010"
+
+
+def test_watermark_id_errors_and_identity():
+    for bad in ["101", "10101010101010102", "", 65536, -1, b"\x01", b"\x01\x02\x03"]:
+        with pytest.raises(ValueError):
+            WatermarkID.custom(bad)
+    for bad in [1.5, None, [1, 0]]:
+        with pytest.raises(TypeError):
+            WatermarkID.custom(bad)
+    with pytest.raises(TypeError):
+        WatermarkID(123)
+    with pytest.raises(ValueError):
+        WatermarkID.for_creator("")
+    with pytest.raises(ValueError):
+        WatermarkID.for_tracking("")
+    with pytest.raises(ValueError):
+        WatermarkID.for_timestamp(datetime(2023, 1, 1))
+    a, b = WatermarkID.custom(7), WatermarkID.custom("0000000000000111")
+    assert a == b and hash(a) == hash(b) and a != WatermarkID.custom(8) and a != "0000000000000111"
+    assert len({a, b}) == 1
+
+
+# ----------------------------------------------------------------------------- bits <-> tensors
+def test_message_tensor_roundtrip():
+    t = utils.message_to_tensor("1010101010101010")
+    assert t.shape == (1, 16) and t.dtype == torch.float32
+    assert utils.message_to_tensor([1, 0] * 8).tolist() == t.tolist()
+    for bad in ["101", "2" * 16]:
+        with pytest.raises(ValueError):
+            utils.message_to_tensor(bad)
+    with pytest.raises(TypeError):
+        utils.message_to_tensor(42)
+    probs = torch.zeros(2, 16, 50)
+    probs[0, ::2] = 0.9
+    probs[0, 1, :25] = 1.0                  # mean exactly 0.5 -> '1' (>= threshold)
+    assert utils.tensor_to_message(probs) == "1110" + "10" * 6
+    assert utils.tensor_to_message(probs.mean(2)) == utils.tensor_to_message(probs)
+    with pytest.raises(ValueError):
+        utils.tensor_to_message(probs, threshold=1.5)
+    with pytest.raises(TypeError):
+        utils.tensor_to_message(np.zeros(16))
+
+
+# ----------------------------------------------------------------------------- audio files
+def test_wav_io(tmp_path):
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(np.clip(rng.standard_normal((1, 4000)).astype(np.float32) * 0.5, -2, 2))
+    p = tmp_path / "a" / "f.wav"
+    utils.save_audio(x, p, 16000)                      # float32 WAV, clamped to [-1, 1]
+    y, sr = utils.load_audio(p)
+    assert sr == 16000 and y.shape == (1, 4000)
+    assert torch.equal(y, x.clamp(-1, 1))
+    # PCM16 stereo written by the stdlib -> mono mix-down
+    p16 = tmp_path / "s.wav"
+    pcm = (rng.standard_normal((1000, 2)) * 3000).astype("<i2")
+    with wave.open(str(p16), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    y, sr = utils.load_audio(p16)
+    assert y.shape == (1, 1000)
+    assert np.allclose(y.numpy()[0], pcm.astype(np.float32).mean(1) / 32768.0, atol=1e-7)
+    with pytest.raises(FileNotFoundError):
+        utils.load_audio(tmp_path / "missing.wav")
+    with pytest.raises(ValueError):
+        utils.load_audio(tmp_path)
+    bad = tmp_path / "bad.wav"
+    bad.write_bytes(b"RIFF\x00\x00\x00\x00WAVEjunk")
+    with pytest.raises(RuntimeError, match="Cannot load audio file"):
+        utils.load_audio(bad)
+    with pytest.raises(ValueError):
+        utils.save_audio(np.zeros(10), tmp_path / "x.wav")
+
+
+# ----------------------------------------------------------------------------- metrics
+def test_metrics_match_oracle():
+    rng = np.random.default_rng(1)
+    logits = rng.standard_normal((4, 16, 200)).astype(np.float32) * 2
+    bits = rng.integers(0, 2, (4, 16))
+    mask = (rng.random((4, 1, 200)) > 0.5).astype(np.float32)
+    mask[3] = 0
+    ber = metrics.BER()
+    assert abs(float(ber(torch.from_numpy(logits), torch.from_numpy(bits))) - O.ber(logits, bits)) < 1e-7
+    assert abs(float(ber(torch.from_numpy(logits), torch.from_numpy(bits), torch.from_numpy(mask)))
+               - O.ber(logits, bits, mask)) < 1e-7
+    assert float(ber(torch.from_numpy(logits), torch.from_numpy(bits), torch.zeros(4, 1, 200))) == 0.0
+    with pytest.raises(RuntimeError):
+        ber(torch.zeros(2, 16, 5), torch.zeros(2, 8))
+    p = rng.integers(0, 2, 500); g = rng.integers(0, 2, 500)
+    assert abs(metrics.MIOU()(p, g) - O.miou(p, g)) < 1e-12
+    assert metrics.MIOU()(np.zeros(5, int), np.zeros(5, int)) == 1.0
+    with pytest.raises(RuntimeError):
+        metrics.MIOU()(np.array([0, 2]), np.array([0, 1]))
+
+
+# ----------------------------------------------------------------------------- checkpoints
+def _torch_sd(cfg, seed, parametrized=False):
+    return {k: torch.from_numpy(v) for k, v in random_state_dict(cfg, seed, parametrized).items()}
+
+
+def test_checkpoint_formats(tmp_path):
+    cfgs = {k: default_config(k) for k in ("generator", "detector", "locator")}
+    models = {k: _torch_sd(c, 0) for k, c in cfgs.items()}
+    d = tmp_path / "run"
+    d.mkdir()
+    torch.save({"step": 1000, "models": models, "config": {"Generator.res_scale_enc": 0.5}}, d / "latest.pth")
+    torch.save({"step": 2000, "models": {"detector": models["detector"]}}, d / "best.pth")
+    assert checkpoint.is_atomic_checkpoint(d)
+    assert checkpoint.find_atomic_checkpoint_file(d).name == "best.pth"        # core.py:161-165
+    sds, got = checkpoint.load_checkpoint(d)
+    assert set(sds) == {"detector"} and got["detector"] == cfgs["detector"]
+    sds, got = checkpoint.load_checkpoint(d / "latest.pth")
+    assert set(sds) == set(cfgs)
+    assert got["detector"] == cfgs["detector"] and got["locator"] == cfgs["locator"]
+    assert got["generator"].res_scale_enc == 0.5 and got["generator"].channels_dec == 96
+    assert got["generator"].n_residual_dec == 3 and got["generator"].strides == [8, 5, 4, 2]
+    # legacy layout + parametrized tensors + a shrunk architecture
+    small = default_config("locator", channels_enc=4, dimension=8, strides=[2, 2], n_fft_base=16, output_dim=8)
+    leg = tmp_path / "legacy" / "locator"
+    leg.mkdir(parents=True)
+    torch.save(_torch_sd(small, 3, parametrized=True), leg / "model.pth")
+    assert not checkpoint.is_atomic_checkpoint(tmp_path / "legacy")
+    sds, got = checkpoint.load_checkpoint(tmp_path / "legacy")
+    assert got["locator"] == small
+    with pytest.raises(FileNotFoundError):
+        checkpoint.load_checkpoint(tmp_path / "nope")
+    with pytest.raises(NotImplementedError):
+        checkpoint.apply_argbind_config("generator", cfgs["generator"], {"Generator.causal": False})
+
+
+def test_infer_config_small_generator():
+    cfg = default_config("generator", channels_enc=8, channels_dec=8, n_residual_dec=2, dimension=16,
+                         strides=[2, 2], n_fft_base=16, zero_init=False)
+    assert checkpoint.infer_config("generator", random_state_dict(cfg, 1)) == cfg
+
+
+# ----------------------------------------------------------------------------- parameter grammar / C ABI
+def test_param_counts_match_reference_probe():
+    """9,588,507 / 4,312,541 / 132,470 parameters (zero_init=True)."""
+    # detector / locator also carry the unused message MLP + FiLM tensors (seanet.py:831-846)
+    assert params.param_count(default_config("generator")) == 9588507
+    assert params.param_count(default_config("detector")) == 4312541
+    assert params.param_count(default_config("locator")) == 132470
+
+
+def test_c_abi_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "waveverify_hip.h")).read()
+    declared = set(re.findall(r"\b(wv_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert b"gfx950" in lib.wv_version()
+
+
+@pytest.mark.parametrize("kind", ["generator", "detector", "locator"])
+def test_c_param_table_matches_python_grammar(kind):
+    """The library's parameter table (no GPU call involved) == params.param_specs == reference keys."""
+    from waveverify_amd.nets import _fill_config
+    lib = _lib.load()
+    for kw in ({}, {"zero_init": False}, {"strides": [2, 2], "channels_enc": 8, "n_fft_base": 16}):
+        cfg = default_config(kind, **kw)
+        h = C.c_void_p()
+        c = _fill_config(cfg)
+        _lib.check(lib.wv_model_create(C.byref(c), C.byref(h)))
+        try:
+            n = lib.wv_model_num_params(h)
+            name, shape = C.create_string_buffer(256), (C.c_int64 * 4)()
+            nd, wn = C.c_int(), C.c_int()
+            table = {}
+            for i in range(n):
+                _lib.check(lib.wv_model_param_info(h, i, name, 256, shape, C.byref(nd), C.byref(wn)))
+                table[name.value.decode()] = (tuple(shape[: nd.value]), bool(wn.value))
+            want = {k: (tuple(s), role == "wn") for k, s, role in params.param_specs(cfg)}
+            assert table == want
+            # errors are loud and typed
+            buf = (C.c_float * 4)()
+            assert lib.wv_model_set_param(h, b"no.such.key", buf, 4) == -2
+            assert b"unknown parameter" in lib.wv_last_error()
+            assert lib.wv_model_set_param(h, b"encoder.conv_pre.1.conv.conv.bias", buf, 3) == -1
+            assert lib.wv_model_finalize(h) == -2 and b"missing parameter" in lib.wv_last_error()
+            assert lib.wv_workspace_bytes(h, 4, 16000) > 0
+        finally:
+            lib.wv_model_destroy(h)
+
+
+def test_c_config_default_matches_python():
+    lib = _lib.load()
+    from waveverify_amd.nets import _fill_config
+    for kind, code in _lib.WV_KIND.items():
+        c = _lib.WvConfig()
+        _lib.check(lib.wv_config_default(code, C.byref(c)))
+        p = _fill_config(default_config(kind))
+        for f, _ in _lib.WvConfig._fields_:
+            a, b = getattr(c, f), getattr(p, f)
+            if hasattr(a, "__len__"):
+                assert [round(float(v), 6) for v in a][: p.n_strides] == [round(float(v), 6) for v in b][: p.n_strides], f
+            else:
+                assert a == pytest.approx(b), f
+
+
+def test_no_cpu_fallback():
+    from waveverify_amd import WaveVerify
+    from waveverify_amd.nets import HipNet
+    cfg = default_config("locator")
+    with pytest.raises(RuntimeError):
+        HipNet(cfg, random_state_dict(cfg, 0), device="cpu")
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="WaveVerify initialization failed"):
+            WaveVerify({"locator": random_state_dict(cfg, 0)})
+    with pytest.raises(RuntimeError, match="WaveVerify initialization failed"):
+        WaveVerify("base")                      # empty download URL upstream: cannot succeed there either
+
+
+# ----------------------------------------------------------------------------- sharding
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 256, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        parallel.shard_bounds(4, 2, 2)

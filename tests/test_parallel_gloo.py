@@ -1,0 +1,65 @@
+"""The N>1 path on CPU: two gloo ranks shard a clip batch, run embed -> detect on their shards
+(the numpy oracle on shrunk nets stands in for the GPU nets: the code under test is the
+sharding + gather of waveverify_amd/parallel.py, which has no data-path collective), and the
+gathered result must equal the unsharded run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import wv_oracle as O
+from waveverify_amd import parallel
+from waveverify_amd.config import default_config
+from waveverify_amd.init import random_state_dict, synthetic_clips
+
+SMALL = dict(channels_enc=8, dimension=16, strides=[2, 2], n_fft_base=16)
+
+
+def _nets():
+    cg = default_config("generator", channels_dec=8, n_residual_dec=2, **SMALL)
+    cd = default_config("detector", output_dim=8, nbits=16, **SMALL)
+    G, D = O._Net(cg, random_state_dict(cg, 7)), O._Net(cd, random_state_dict(cd, 7))
+    embed = lambda x, m: torch.from_numpy(O.embed(cg, G, x.numpy(), m.numpy()))
+    detect = lambda x: torch.from_numpy(O.mean_probabilities(O.detector_forward(cd, D, x.numpy())))
+    return embed, detect
+
+
+def _worker(rank, world, port, B, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        x, msg = synthetic_clips(B, 400, seed=11)
+        embed, detect = _nets()
+        wm, mp_local, mp_all = parallel.embed_detect_sharded(
+            embed, detect, torch.from_numpy(x), torch.from_numpy(msg), rank, world)
+        lo, hi = parallel.shard_bounds(B, rank, world)
+        assert wm.shape[0] == hi - lo == mp_local.shape[0]
+        np.save(os.path.join(out_dir, f"mp_all_{rank}.npy"), mp_all.numpy())
+        np.save(os.path.join(out_dir, f"wm_{rank}.npy"), wm.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [5, 4])
+def test_two_rank_sharding_matches_single_process(tmp_path, B):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    x, msg = synthetic_clips(B, 400, seed=11)
+    embed, detect = _nets()
+    wm_ref = embed(torch.from_numpy(x), torch.from_numpy(msg))
+    mp_ref = detect(wm_ref).numpy()
+    a, b = (np.load(tmp_path / f"mp_all_{r}.npy") for r in (0, 1))
+    assert a.shape == (B, 16) and np.array_equal(a, b)            # every rank holds the full result
+    # the numpy stand-in is only reproducible to BLAS blocking (which depends on the batch shape);
+    # the GPU nets are bit-identical per clip (tests/test_gpu_nets.py::test_batch_independence...)
+    assert np.abs(a - mp_ref).max() <= 1e-6
+    assert np.array_equal(a >= 0.5, mp_ref >= 0.5)
+    wm = np.concatenate([np.load(tmp_path / f"wm_{r}.npy") for r in (0, 1)])
+    assert wm.shape == wm_ref.shape and np.abs(wm - wm_ref.numpy()).max() <= 1e-6

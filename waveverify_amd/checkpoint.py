@@ -1,0 +1,168 @@
+"""Checkpoint reading: the reference's on-disk formats -> {kind: state_dict} + NetConfigs.
+
+Formats (all read with torch.load(..., weights_only=True): nothing in the file is executed):
+  * atomic: one .pth dict {step, models{generator,detector,locator,discriminator}, optimizers,
+    schedulers, tracker, config, ...} written by /root/reference/scripts/train.py:1589-1676;
+    loader waveverify/core.py:324-426; directory search order best.pth, latest.pth, first
+    (core.py:141-168).
+  * legacy: <dir>/{generator,detector,locator}/model.pth (core.py:428-469).
+State dicts may be in the stripped layout (plain `...weight`) or the live parametrized layout
+(`...parametrizations.weight.original0/1`); both are accepted downstream (nets.HipNet).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, Mapping, Optional, Tuple
+
+import torch
+
+from .config import NetConfig, default_config
+
+KINDS = ("generator", "detector", "locator")
+_CLASS = {"generator": "Generator", "detector": "Detector", "locator": "Locator"}
+_TAG = "parametrizations.weight.original"
+
+
+def _load(path: Path):
+    return torch.load(str(path), map_location="cpu", weights_only=True)
+
+
+def find_atomic_checkpoint_file(path: Path) -> Path:
+    path = Path(path)
+    if path.is_file() and path.suffix == ".pth":
+        return path
+    files = sorted(path.glob("*.pth"))
+    if not files:
+        raise FileNotFoundError(f"No atomic checkpoint files found in {path}")
+    for preferred in ("best.pth", "latest.pth"):
+        for f in files:
+            if f.name == preferred:
+                return f
+    return files[0]
+
+
+def is_atomic_checkpoint(path: Path) -> bool:
+    path = Path(path)
+    if path.is_file() and path.suffix == ".pth":
+        return True
+    if path.is_dir():
+        for f in sorted(path.glob("*.pth")):
+            try:
+                ck = _load(f)
+                if isinstance(ck, dict) and "models" in ck:
+                    return True
+            except Exception:
+                continue
+    return False
+
+
+def _plain_key(sd: Mapping[str, object], key: str):
+    """Shape of a possibly weight-normed tensor `key` ('...weight')."""
+    if key in sd:
+        return tuple(sd[key].shape)
+    base = key[: -len("weight")]
+    k1 = base + _TAG + "1"
+    return tuple(sd[k1].shape) if k1 in sd else None
+
+
+def infer_config(kind: str, sd: Mapping[str, object], base: Optional[NetConfig] = None) -> NetConfig:
+    """Recover the architecture hyper-parameters from tensor shapes (the reference needs the
+    argbind config for this; shapes carry the same information)."""
+    cfg = base or default_config(kind)
+    kw = cfg.to_dict()
+    pre = _plain_key(sd, "encoder.conv_pre.1.conv.conv.weight")
+    if pre is None:
+        raise KeyError("state dict has no encoder.conv_pre weight")
+    kw["channels_enc"], kw["kernel_size"] = pre[0], pre[2]
+    ratios, s = [], 0
+    while True:
+        shp = _plain_key(sd, f"encoder.downsample.{s}.3.conv.conv.weight")
+        if shp is None:
+            break
+        ratios.append(shp[2] // 2)
+        s += 1
+    kw["strides"] = list(reversed(ratios))                      # encoder walks them reversed
+    n = 0
+    while _plain_key(sd, f"encoder.blocks.0.{n}.block.1.conv.conv.weight") is not None:
+        n += 1
+    kw["n_residual_enc"] = n
+    kw["residual_kernel_size"] = _plain_key(sd, "encoder.blocks.0.0.block.2.conv.conv.weight")[2]
+    kw["n_fft_base"] = (_plain_key(sd, "encoder.spec_blocks.0.layer.conv.conv.weight")[1] - 1) * 2
+    post = _plain_key(sd, "encoder.conv_post.2.conv.conv.weight")
+    kw["dimension"] = post[0]
+    kw["last_kernel_size"] = _plain_key(sd, "encoder.conv_post.1.conv.conv.weight")[2]
+    kw["zero_init"] = "encoder.blocks.0.0.res_scale_param" in sd
+    if "encoder.msg_embedding.0.weight" in sd:
+        e = tuple(sd["encoder.msg_embedding.0.weight"].shape)
+        kw["embedding_dim"], kw["msg_dimension"] = e[0], e[1]
+        layers = 0
+        while f"encoder.msg_embedding.{1 + 2 * layers}.weight" in sd:
+            layers += 1
+        kw["embedding_layers"] = layers
+        b = 0
+        while f"encoder.film_layers.0.{b}.gamma_layer.weight" in sd:
+            b += 1
+        kw["freq_bands"] = b or kw["freq_bands"]
+    if kind == "generator":
+        last = max(int(k.split(".")[2]) for k in sd if k.startswith("decoder.model."))
+        kw["channels_dec"] = _plain_key(sd, f"decoder.model.{last}.conv.conv.weight")[1]
+        n_groups = len(kw["strides"])
+        kw["n_residual_dec"] = (last - 2 - 2) // n_groups - 4    # layout: seanet.py:1067-1204
+    else:
+        rev = tuple(sd["reverse_convolution.weight"].shape)
+        kw["output_dim"] = rev[1]
+        if kind == "detector":
+            kw["nbits"] = tuple(sd["last_layer.weight"].shape)[0]
+    return NetConfig(**kw)
+
+
+def apply_argbind_config(kind: str, cfg: NetConfig, flat: Optional[Mapping[str, object]]) -> NetConfig:
+    """Overlay an argbind-style flat dict ('Generator.res_scale_enc': ...) saved inside atomic
+    checkpoints (train.py:1652) for the scalars shapes cannot tell."""
+    if not flat:
+        return cfg
+    kw = cfg.to_dict()
+    prefix = _CLASS[kind] + "."
+    unsupported = {"norm": "weight_norm", "causal": True, "skip": "identity", "act_all": False,
+                   "activation": "ELU", "spec": "stft", "spec_compression": "log",
+                   "pad_mode": "constant", "inout_norm": True, "encoder_l2norm": True, "bias": True,
+                   "expansion": 1, "groups": -1}
+    for k, v in flat.items():
+        if not isinstance(k, str) or not k.startswith(prefix):
+            continue
+        name = k[len(prefix):]
+        if name in ("res_scale_enc", "res_scale_dec", "dilation_base"):
+            kw[name] = type(kw[name])(v)
+        elif name in unsupported and v != unsupported[name]:
+            raise NotImplementedError(
+                f"{k}={v!r}: only the configuration the reference ships ({name}={unsupported[name]!r}) "
+                "has a HIP path")
+    return NetConfig(**kw)
+
+
+def load_checkpoint(path) -> Tuple[Dict[str, dict], Dict[str, NetConfig]]:
+    """-> ({kind: state_dict}, {kind: NetConfig}) for whichever of generator/detector/locator the
+    checkpoint holds."""
+    path = Path(path)
+    if not path.exists():
+        raise FileNotFoundError(f"Checkpoint not found: {path}")
+    sds: Dict[str, dict] = {}
+    flat = None
+    if is_atomic_checkpoint(path):
+        ck = _load(find_atomic_checkpoint_file(path))
+        if not isinstance(ck, dict) or "models" not in ck:
+            raise ValueError("Invalid atomic checkpoint format - missing 'models' key")
+        flat = ck.get("config")
+        for k in KINDS:
+            if k in ck["models"]:
+                sds[k] = dict(ck["models"][k])
+    else:
+        for k in KINDS:
+            f = path / k / "model.pth"
+            if f.exists():
+                sds[k] = dict(_load(f))
+    if not sds:
+        raise FileNotFoundError(f"No generator/detector/locator weights found in {path}")
+    cfgs = {k: apply_argbind_config(k, infer_config(k, sd), flat if isinstance(flat, dict) else None)
+            for k, sd in sds.items()}
+    return sds, cfgs
