@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+                    help="GEMM core: exact f32 MFMA, or split-f16 (hi+lo, 3 f16 MFMAs, f32 accumulate)")
     return ap.parse_args()
 
 
@@ -79,7 +81,7 @@ def main():
     B = a.batch
     cfgG, cfgD = default_config("generator"), default_config("detector")
     sdG, sdD = random_state_dict(cfgG, 0), random_state_dict(cfgD, 0)
-    G, D = HipNet(cfgG, sdG, dev), HipNet(cfgD, sdD, dev)
+    G, D = HipNet(cfgG, sdG, dev, precision=a.precision), HipNet(cfgD, sdD, dev, precision=a.precision)
     x_np, msg_np = synthetic_clips(B, T, seed=1234 + rank)         # each rank owns its shard
     x, msg = torch.from_numpy(x_np).to(dev), torch.from_numpy(msg_np).to(dev)
 
@@ -149,7 +151,7 @@ def main():
     out = dict(metric="clips/sec embed+detect, 1s@16kHz bs=256", value=round(world * B * a.steps / elapsed, 2),
                unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                ms_per_step=round(elapsed / a.steps * 1e3, 3), higher_is_better=True, scaling="weak",
-               vs_baseline=None, dtype="f32", data="synthetic",
+               vs_baseline=None, dtype=a.precision, data="synthetic",
                config=dict(workload=f"embed+detect, {B} clips x {a.seconds:g} s @ 16 kHz per GPU "
                                     "(BASELINE.json configs[1]), generator+detector forward, seeded random weights",
                            batch_per_gpu=B, global_batch=B * world, clip_samples=T,

@@ -202,42 +202,13 @@ struct RowLoader {
 // Zero padding: X is staged as 0 outside [0,Tin) and the 1x1 has no bias, so H is 0 there,
 // which is exactly the zero pad SConv1d inserts between the 1x1 and the DW conv.
 // ------------------------------------------------------------------------------------------
+// K1 epilogue (shared by the f32 and the split-f16 GEMM cores): spill the wave's 32 x BN
+// accumulator strip two rows at a time, depth-wise stencil + bias (+FiLM | *scale + residual).
 template <class T, int KS>
-__global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ? 3 : 2) void pw_dw_kernel(PwDwArgs p) {
-    // Row-strip tile: WN == 1, every wave owns 32 channel rows x the whole BN-column window, so
-    // the depth-wise stencil never crosses a wave: accumulators are spilled two rows at a time
-    // into a wave-private LDS strip (no workgroup barrier), read back with time on the lanes and
-    // written with 16-byte stores.  KS == 5 is the ResnetBlock fast path (k5, stride 1, dil 1).
-    static_assert(T::WN == 1 && T::MT == 1, "row-strip tile");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void pw_dw_epilogue(f32x16 (&acc)[1][T::NT], const PwDwArgs& p, float* smem,
+                                               int m0, int b, int to0) {
     constexpr int HLD = T::BN + 4;
-    const int m0 = blockIdx.x * T::BM;
-    const int b = blockIdx.z;
-    const int M = p.pw.M, K = p.pw.K;
-    const int to0 = blockIdx.y * p.tto;
-    const int ti0 = to0 * p.stride - p.pad - p.off;
-
-    if (p.stagger > 0) {
-        // De-phase co-resident workgroups: the first generation (one per resident slot) starts
-        // together and, having identical work, would stay in lockstep -- all in the MFMA phase or
-        // all in the HBM-bound epilogue at once.  Delaying 1/3 and 2/3 of that first generation
-        // lets one workgroup's epilogue overlap another's matrix phase for the whole launch.
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (lin < (unsigned)p.first_gen) {
-            // consecutive ids round-robin over the 8 XCDs, then over an XCD's 32 CUs: ids that
-            // differ by 256 share a CU, so lin / 256 enumerates a CU's resident slots
-            const int slot = lin / 256;
-            for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
-    f32x16 acc[1][T::NT];
-    zero_acc<T>(acc);
-    WLoader la{p.pw.wt, p.pw.Mp, m0};
-    RowLoader lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu,
-                 nullptr, 0, false, false};
-    gemm_mainloop<T>(acc, la, lb, p.pw.Kp / BK, smem, p.dbg);
-    if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.Y[0] = 0.f; return; }
-
+    const int M = p.pw.M;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, q = lane & 31;
@@ -351,6 +322,209 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+
+template <class T, int KS>
+__global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ? 3 : 2) void pw_dw_kernel(PwDwArgs p) {
+    // Row-strip tile: WN == 1, every wave owns 32 channel rows x the whole BN-column window, so
+    // the depth-wise stencil never crosses a wave: accumulators are spilled two rows at a time
+    // into a wave-private LDS strip (no workgroup barrier), read back with time on the lanes and
+    // written with 16-byte stores.  KS == 5 is the ResnetBlock fast path (k5, stride 1, dil 1).
+    static_assert(T::WN == 1 && T::MT == 1, "row-strip tile");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HLD = T::BN + 4;
+    const int m0 = blockIdx.x * T::BM;
+    const int b = blockIdx.z;
+    const int M = p.pw.M, K = p.pw.K;
+    const int to0 = blockIdx.y * p.tto;
+    const int ti0 = to0 * p.stride - p.pad - p.off;
+
+    if (p.stagger > 0) {
+        // De-phase co-resident workgroups: the first generation (one per resident slot) starts
+        // together and, having identical work, would stay in lockstep -- all in the MFMA phase or
+        // all in the HBM-bound epilogue at once.  Delaying 1/3 and 2/3 of that first generation
+        // lets one workgroup's epilogue overlap another's matrix phase for the whole launch.
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin < (unsigned)p.first_gen) {
+            // consecutive ids round-robin over the 8 XCDs, then over an XCD's 32 CUs: ids that
+            // differ by 256 share a CU, so lin / 256 enumerates a CU's resident slots
+            const int slot = lin / 256;
+            for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+    f32x16 acc[1][T::NT];
+    zero_acc<T>(acc);
+    WLoader la{p.pw.wt, p.pw.Mp, m0};
+    RowLoader lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu,
+                 nullptr, 0, false, false};
+    gemm_mainloop<T>(acc, la, lb, p.pw.Kp / BK, smem, p.dbg);
+    if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.Y[0] = 0.f; return; }
+    pw_dw_epilogue<T, KS>(acc, p, smem, m0, b, to0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Split-f16 GEMM core ("f16x3").  x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 significant
+// bits.  a.b ~= ah.bh + ah.bl + al.bh on v_mfma_f32_32x32x16_f16 (f32 accumulate): three matrix
+// instructions at 16x the f32 matrix rate each = 5.3x the exact-f32 core, with a relative error
+// of ~2^-22 per product (the dropped al.bl term) -- float32-class results.  Values beyond the f16
+// range are clamped to +-65504 (never reached by audio-scale activations).
+// LDS holds 16-byte fragments (8 halfs along k): [kq][hi|lo][row]; a fragment is one MFMA
+// operand (lane l: row l&31, k = 8*(l>>5)+j), read by ds_read_b128 from consecutive slots.
+// A fragments are pre-split on the host; B is split at commit time.  B slots are XOR-swizzled
+// (n ^ ((n>>2)&3)) so a thread's four 16-byte column writes do not pile on four banks.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+template <class T>
+struct HT {
+    static constexpr int KB = BKH / 8;
+    static constexpr int NA = KB * 2 * T::BM;                 // A fragments per stage
+    static constexpr int CG = T::BN / 4;                      // column groups (4 columns each)
+    static constexpr int NBT = KB * CG;                       // B micro-tiles (8 k x 4 cols)
+    static constexpr int A_PER = (NA + T::NTHREADS - 1) / T::NTHREADS;
+    static constexpr int B_PER = (NBT + T::NTHREADS - 1) / T::NTHREADS;
+    static constexpr int STAGE = KB * 2 * (T::BM + T::BN);    // u32x4 per stage
+    static_assert(T::NTHREADS % CG == 0, "a thread keeps one column group");
+};
+
+struct RowLoaderH {                    // 8 consecutive k rows x 4 columns of a [K][ld] matrix
+    const float* base; int K, ld, ncols, c0; float scale; int elu;
+    const float* p; int c; bool full, vec;
+    __device__ __forceinline__ void init(int cg) {
+        c = c0 + 4 * cg;
+        full = c >= 0 && c + 3 < ncols;
+        vec = full && ((ld & 3) == 0) && ((c & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+        p = base + c;
+    }
+    __device__ __forceinline__ void fetch8(int k0, float (&raw)[32]) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + i;
+            if (k < K && vec) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * ld);
+                raw[4 * i] = v.x; raw[4 * i + 1] = v.y; raw[4 * i + 2] = v.z; raw[4 * i + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    raw[4 * i + j] = (k < K && c + j >= 0 && c + j < ncols) ? p[(size_t)k * ld + j] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ float xform(float v) const { return act(v, scale, elu); }
+};
+
+__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+template <class T, class LB>
+__device__ __forceinline__ void gemm_mainloop_h(f32x16 (&acc)[1][T::NT], const u32x4* __restrict__ wh,
+                                                int Mp, int m0, LB& lb, int nchunks, u32x4* smem) {
+    using H = HT<T>;
+    static_assert(T::WN == 1 && T::MT == 1, "row-strip tile");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = tid % H::CG;
+    u32x4 ra[H::A_PER];
+    float rb[H::B_PER][32];
+    lb.init(cg);
+
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < H::A_PER; ++r) {
+            const int idx = tid + r * T::NTHREADS;
+            if (H::NA % T::NTHREADS == 0 || idx < H::NA) {
+                const int m = idx % T::BM, rest = idx / T::BM;          // rest = kq*2 + hl
+                ra[r] = wh[(size_t)(c * H::KB * 2 + rest) * Mp + m0 + m];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < H::B_PER; ++r) {
+            const int idx = tid + r * T::NTHREADS;
+            if (H::NBT % T::NTHREADS == 0 || idx < H::NBT) lb.fetch8(c * BKH + (idx / H::CG) * 8, rb[r]);
+        }
+    };
+    auto commit = [&](u32x4* buf) {
+        u32x4* As = buf;
+        u32x4* Bs = buf + H::KB * 2 * T::BM;
+#pragma unroll
+        for (int r = 0; r < H::A_PER; ++r) {
+            const int idx = tid + r * T::NTHREADS;
+            if (H::NA % T::NTHREADS == 0 || idx < H::NA) As[idx] = ra[r];
+        }
+#pragma unroll
+        for (int r = 0; r < H::B_PER; ++r) {
+            const int idx = tid + r * T::NTHREADS;
+            if (!(H::NBT % T::NTHREADS == 0 || idx < H::NBT)) continue;
+            const int kq = idx / H::CG;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    half2v h2, l2;
+                    _Float16 h, l;
+                    split_f16(lb.xform(rb[r][4 * (2 * i) + j]), h, l);
+                    h2[0] = h; l2[0] = l;
+                    split_f16(lb.xform(rb[r][4 * (2 * i + 1) + j]), h, l);
+                    h2[1] = h; l2[1] = l;
+                    hw[i] = __builtin_bit_cast(unsigned, h2);
+                    lw[i] = __builtin_bit_cast(unsigned, l2);
+                }
+                const int slot = 4 * cg + (j ^ (cg & 3));
+                Bs[(kq * 2 + 0) * T::BN + slot] = u32x4{hw[0], hw[1], hw[2], hw[3]};
+                Bs[(kq * 2 + 1) * T::BN + slot] = u32x4{lw[0], lw[1], lw[2], lw[3]};
+            }
+        }
+    };
+
+    fetch(0);
+    commit(smem);
+    __syncthreads();
+    const int h = lane >> 5, i31 = lane & 31;
+    int bslot[T::NT];
+#pragma unroll
+    for (int j = 0; j < T::NT; ++j) { const int n = 32 * j + i31; bslot[j] = n ^ ((n >> 2) & 3); }
+    for (int c = 0; c < nchunks; ++c) {
+        const u32x4* As = smem + (c & 1) * H::STAGE;
+        const u32x4* Bs = As + H::KB * 2 * T::BM;
+        if (c + 1 < nchunks) fetch(c + 1);
+#pragma unroll
+        for (int s = 0; s < BKH / 16; ++s) {
+            const int kq = 2 * s + h;
+            const half8 ah = __builtin_bit_cast(half8, As[(kq * 2 + 0) * T::BM + 32 * wave + i31]);
+            const half8 al = __builtin_bit_cast(half8, As[(kq * 2 + 1) * T::BM + 32 * wave + i31]);
+#pragma unroll
+            for (int j = 0; j < T::NT; ++j) {
+                const half8 bh = __builtin_bit_cast(half8, Bs[(kq * 2 + 0) * T::BN + bslot[j]]);
+                const half8 bl = __builtin_bit_cast(half8, Bs[(kq * 2 + 1) * T::BN + bslot[j]]);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0][j], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) commit(smem + ((c + 1) & 1) * H::STAGE);
+        __syncthreads();
+    }
+}
+
+template <class T, int KS>
+__global__ __launch_bounds__(T::NTHREADS, 2) void pw_dw_h_kernel(PwDwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int m0 = blockIdx.x * T::BM;
+    const int b = blockIdx.z;
+    const int K = p.pw.K;
+    const int to0 = blockIdx.y * p.tto;
+    const int ti0 = to0 * p.stride - p.pad - p.off;
+    f32x16 acc[1][T::NT];
+    zero_acc<T>(acc);
+    RowLoaderH lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
+    gemm_mainloop_h<T>(acc, reinterpret_cast<const u32x4*>(p.pw.wh), p.pw.Mp, m0, lb, p.pw.Kh / BKH,
+                       reinterpret_cast<u32x4*>(smem));
+    pw_dw_epilogue<T, KS>(acc, p, smem, m0, b, to0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -822,6 +996,22 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     if ((long long)grid.x * grid.y * grid.z < 4LL * a.first_gen) a.stagger = 0;
     static const std::string name = tile_name<T>(KS ? "pw_dw_k5" : "pw_dw");
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
+    if (a.prec == PREC_F16X3 && a.pw.wh) {
+        size_t hs = 2 * (size_t)HT<T>::STAGE * 16;
+        if (eb > hs) hs = eb;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = set_smem(pw_dw_h_kernel<T, KS>, hs);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        a.stagger = 0;
+        static const std::string hname = tile_name<T>(KS ? "pw_dw_k5_h" : "pw_dw_h");
+        prof::Scope ph(s, hname.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
+                       4.0 * Bd * (K * a.Tin + M * a.Tout * (a.resid ? 2.0 : 1.0)));
+        hipLaunchKernelGGL((pw_dw_h_kernel<T, KS>), grid, dim3(T::NTHREADS), hs, s, a);
+        return hipGetLastError();
+    }
     prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
                    4.0 * Bd * (K * a.Tin + M * a.Tout * (a.resid ? 2.0 : 1.0)));
     hipLaunchKernelGGL((pw_dw_kernel<T, KS>), grid, dim3(T::NTHREADS), smem, s, a);

@@ -60,6 +60,7 @@ struct wv_model {
     std::unordered_map<std::string, int> index;
     std::unordered_map<std::string, std::vector<float>> stft_override;
     bool finalized = false;
+    int prec = wv::PREC_F32;                     // GEMM precision of the fused units
     std::vector<void*> dev;                      // owned device allocations
 
     // ---- encoder plan
@@ -221,6 +222,11 @@ struct Uploader {
         for (int mm = 0; mm < M; ++mm)
             for (int k = 0; k < K; ++k) t[(size_t)k * p.Mp + mm] = w[(size_t)mm * K + k];
         p.wt = up(t);
+        p.Kh = wv::round_up(K, wv::BKH);
+        const std::vector<uint16_t> hf = wv::pack_split_f16(w.data(), M, K, p.Mp, p.Kh);
+        std::vector<float> as_f(hf.size() / 2);
+        std::memcpy(as_f.data(), hf.data(), hf.size() * 2);
+        p.wh = up(as_f);
         return p;
     }
     PwWeight pw(const std::string& name) {
@@ -456,17 +462,17 @@ WsLayout layout(const wv_model* m, int B, int T) {
 
 struct Bufs { float *a, *b, *c; };   // a = current activation, b / c = scratch
 
-int run_resblock(const ResBlock& r, Bufs& bf, int B, int T, hipStream_t st, const char* role) {
+int run_resblock(const ResBlock& r, Bufs& bf, int B, int T, hipStream_t st, const char* role, int prec) {
     wv::prof::set_role(role);
     wv::PwDwArgs a{};
     a.X = bf.a; a.pw = r.pw1; a.dw_w = r.dw1_w; a.dw_b = r.dw1_b; a.Y = bf.b;
     a.B = B; a.Tin = T; a.Tout = T; a.ks = r.ks; a.stride = 1; a.dil = r.dil1; a.pad = (r.ks - 1) * r.dil1;
-    a.pre_scale = r.pre_scale; a.pre_elu = 1; a.out_scale = 1.f; a.bands = 1;
+    a.pre_scale = r.pre_scale; a.pre_elu = 1; a.out_scale = 1.f; a.bands = 1; a.prec = prec;
     LAUNCH(wv::launch_pw_dw(a, st));
     wv::PwDwArgs b{};
     b.X = bf.b; b.pw = r.pw2; b.dw_w = r.dw2_w; b.dw_b = r.dw2_b; b.resid = bf.a; b.Y = bf.c;
     b.B = B; b.Tin = T; b.Tout = T; b.ks = r.ks; b.stride = 1; b.dil = r.dil2; b.pad = (r.ks - 1) * r.dil2;
-    b.pre_scale = 1.f; b.pre_elu = 1; b.out_scale = r.out_scale; b.bands = 1;
+    b.pre_scale = 1.f; b.pre_elu = 1; b.out_scale = r.out_scale; b.bands = 1; b.prec = prec;
     LAUNCH(wv::launch_pw_dw(b, st));
     float* t = bf.a; bf.a = bf.c; bf.c = t;
     return WV_OK;
@@ -507,7 +513,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         const bool post = s == c.n_strides;
         if (!post)
             for (const ResBlock& r : m->enc_blocks[s]) {
-                int rc = run_resblock(r, bf, B, Tl, st, "enc.resblock");
+                int rc = run_resblock(r, bf, B, Tl, st, "enc.resblock", m->prec);
                 if (rc) return rc;
             }
         wv::prof::set_role("enc.spec");
@@ -532,6 +538,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         a.pre_scale = d.pre_scale; a.pre_elu = 1; a.out_scale = 1.f;
         a.bands = c.freq_bands; a.film_stride = film_stride;
         a.film = film ? film + (size_t)s * c.freq_bands * 2 : nullptr;
+        a.prec = m->prec;
         if (film && (2 * C) % c.freq_bands) return fail(WV_EINVAL, "channels not divisible by freq_bands");
         LAUNCH(wv::launch_pw_dw(a, st));
         float* t = bf.a; bf.a = bf.b; bf.b = t;
@@ -728,7 +735,7 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
     wv::PwDwArgs h{};
     h.X = latent; h.pw = m->dec_pw0; h.dw_w = m->dec_dw0_w; h.dw_b = m->dec_dw0_b; h.Y = bf.a;
     h.B = B; h.Tin = Fr; h.Tout = Fr; h.ks = c.kernel_size; h.stride = 1; h.dil = 1; h.pad = c.kernel_size - 1;
-    h.pre_scale = 1.f; h.pre_elu = 0; h.out_scale = 1.f; h.bands = 1;
+    h.pre_scale = 1.f; h.pre_elu = 0; h.out_scale = 1.f; h.bands = 1; h.prec = m->prec;
     LAUNCH(wv::launch_pw_dw(h, st));
     int Tl = Fr;
     for (const UpLayer& u : m->ups) {
@@ -741,7 +748,7 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
         float* t = bf.a; bf.a = bf.b; bf.b = t;
         Tl = a.Tout;
         for (const ResBlock& r : u.res) {
-            rc = run_resblock(r, bf, B, Tl, st, "dec.resblock");
+            rc = run_resblock(r, bf, B, Tl, st, "dec.resblock", m->prec);
             if (rc) return rc;
         }
     }
@@ -783,6 +790,11 @@ int wv_locator_forward(wv_model* m, const float* x, float* logits, int B, int T,
     return run_head_model(m, x, logits, nullptr, B, T, ws, ws_bytes, stream);
 }
 
+int wv_model_set_precision(wv_model* m, int prec) {
+    if (!m || (prec != wv::PREC_F32 && prec != wv::PREC_F16X3)) return fail(WV_EINVAL, "precision must be 0 (f32) or 1 (f16x3)");
+    m->prec = prec;
+    return WV_OK;
+}
 int wv_debug_flags(int flags) { wv::set_debug_flags(flags); return WV_OK; }
 int wv_profile_enable(int on) { wv::prof::enable(on != 0); return WV_OK; }
 int wv_profile_reset(void) { wv::prof::reset(); return WV_OK; }

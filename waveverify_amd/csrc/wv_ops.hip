@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,11 @@ struct Tmp {                       // scoped device uploads
         for (int m = 0; m < M; ++m)
             for (int k = 0; k < K; ++k) t[(size_t)k * p.Mp + m] = w[(size_t)m * K + k];
         p.wt = upv(t);
+        p.Kh = wv::round_up(K, wv::BKH);
+        const std::vector<uint16_t> hf = wv::pack_split_f16(w, M, K, p.Mp, p.Kh);
+        std::vector<float> as_f(hf.size() / 2);
+        std::memcpy(as_f.data(), hf.data(), hf.size() * 2);
+        p.wh = upv(as_f);
         return p;
     }
     ~Tmp() { (void)hipDeviceSynchronize(); for (void* p : d) (void)hipFree(p); }
@@ -46,7 +52,15 @@ int done(Tmp& t, hipError_t e, hipStream_t s) {
 
 }  // namespace
 
+static int g_op_prec = wv::PREC_F32;
+
 extern "C" {
+
+int wv_op_set_precision(int prec) {
+    if (prec != wv::PREC_F32 && prec != wv::PREC_F16X3) return WV_EINVAL;
+    g_op_prec = prec;
+    return WV_OK;
+}
 
 int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const float* dw_bias,
                 const float* film, const float* resid, float* Y, int B, int K, int M, int Tin,
@@ -61,6 +75,7 @@ int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const floa
     a.dil = dilation; a.pad = (ks - 1) * dilation - (stride - 1);
     a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = out_scale;
     a.bands = bands > 0 ? bands : 1; a.film_stride = 2 * a.bands;
+    a.prec = g_op_prec;
     if (a.pad < 0) return WV_EINVAL;
     return done(t, wv::launch_pw_dw(a, (hipStream_t)stream), (hipStream_t)stream);
 }
