@@ -6,7 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from waveverify_amd import ops, profile, _lib
 
-def run(C, T, B, M=None, ks=5, stride=1, resid=True, reps=5, flags=0, film=False):
+def run(C, T, B, M=None, ks=5, stride=1, resid=True, reps=5, flags=0, film=False, prec="f32"):
     M = M or C
     rng = np.random.default_rng(0)
     X = torch.randn(B, C, T, device="cuda")
@@ -16,12 +16,14 @@ def run(C, T, B, M=None, ks=5, stride=1, resid=True, reps=5, flags=0, film=False
     Tout = -(-T // stride)
     R = torch.randn(B, M, Tout, device="cuda") if resid else None
     _lib.load().wv_debug_flags(flags)
+    ops.set_precision(prec)
     profile.reset(); profile.enable(True)
     for _ in range(reps):
         ops.pw_dw(X, w_pw, w_dw, b, resid=R, stride=stride, pre_scale=0.87, pre_elu=True, out_scale=0.5)
     profile.enable(False)
     e = profile.collect()[0]
     _lib.load().wv_debug_flags(0)
+    ops.set_precision("f32")
     us = e["ms"] / e["launches"] * 1e3
     tf = e["flops"] / e["launches"] / (us * 1e-6) / 1e12
     gb = e["bytes"] / e["launches"] / (us * 1e-6) / 1e9
@@ -31,10 +33,8 @@ if __name__ == "__main__":
     shapes = [(128, 8000, 256), (64, 16000, 256), (512, 400, 256), (768, 400, 256), (96, 16000, 256)]
     if len(sys.argv) == 4:
         shapes = [tuple(int(v) for v in sys.argv[1:4])]
-    names = {0: "full (stagger 4)", 255 << 8: "full, no stagger", (255 << 8) | 1: "no-epilogue", (255 << 8) | 2: "no-mfma"}
-    for st in (2, 8):
-        names[st << 8] = f"full, stagger {st}"
+    names = {(255 << 8) | 64: "warmup", 255 << 8: "f32 full"}
     for C, T, B in shapes:
-        for fl, nm in names.items():
-            us, tf, gb, k = run(C, T, B, flags=fl)
-            print(f"C={C:4d} T={T:6d} {k:24s} {nm:26s} {us:9.1f} us  {tf:6.1f} TF/s {gb:7.1f} GB/s", flush=True)
+        for fl, nm in list(names.items()) + [((255 << 8) | 128, "f16x3 full")]:
+            us, tf, gb, k = run(C, T, B, flags=fl & ~128, prec="f16x3" if fl & 128 else "f32")
+            print(f"C={C:4d} T={T:6d} {k:24s} {nm:42s} {us:9.1f} us  {tf:6.1f} TF/s {gb:7.1f} GB/s", flush=True)

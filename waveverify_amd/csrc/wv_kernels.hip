@@ -202,127 +202,156 @@ struct RowLoader {
 // Zero padding: X is staged as 0 outside [0,Tin) and the 1x1 has no bias, so H is 0 there,
 // which is exactly the zero pad SConv1d inserts between the 1x1 and the DW conv.
 // ------------------------------------------------------------------------------------------
-// K1 epilogue (shared by the f32 and the split-f16 GEMM cores): spill the wave's 32 x BN
-// accumulator strip two rows at a time, depth-wise stencil + bias (+FiLM | *scale + residual).
-template <class T, int KS>
-__device__ __forceinline__ void pw_dw_epilogue(f32x16 (&acc)[1][T::NT], const PwDwArgs& p, float* smem,
-                                               int m0, int b, int to0) {
-    constexpr int HLD = T::BN + 4;
-    const int M = p.pw.M;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, q = lane & 31;
-    float* Wl = smem;                                        // [BM][8] taps / bias / gamma / beta
-    float* Hw = smem + T::BM * 8 + wave * (2 * HLD);         // this wave's 2-row strip
-    const int bw = p.film ? (M / p.bands) : 1;
-    const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
-    if (KS) {
-        for (int m = tid; m < T::BM; m += T::NTHREADS) {
-            const int gm = m0 + m;
-            float v[8] = {0, 0, 0, 0, 0, 0, 1.f, 0};
-            if (gm < M) {
-#pragma unroll
-                for (int i = 0; i < KS; ++i) v[i] = p.dw_w[(size_t)gm * KS + i];
-                v[5] = p.dw_b ? p.dw_b[gm] : 0.f;
-                if (filmb) { const int band = gm / bw; v[6] = filmb[2 * band]; v[7] = filmb[2 * band + 1]; }
-            }
-            *reinterpret_cast<float4*>(Wl + m * 8) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(Wl + m * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-        __syncthreads();
-    }
-    float* Yb = p.Y + (size_t)b * M * p.Tout;
-    const float* Rb = p.resid ? p.resid + (size_t)b * M * p.Tout : nullptr;
-
-    if (KS) {
-        // lane -> 4 consecutive outputs of one of the strip's two rows
-        const int o = 4 * q, to = to0 + o;
-        const bool act_lane = o < p.tto && to < p.Tout;
-        const bool vec = act_lane && to + 3 < p.Tout && o + 3 < p.tto && (p.Tout & 3) == 0;
-        auto row_of = [&](int r) { return 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half; };
-        constexpr int RP = 8;                                 // residual rows in flight per lane
-        float4 res[RP];
-        auto load_res = [&](int r) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int gm = m0 + row_of(r);
-            if (Rb && act_lane && gm < M) {
-                const float* rp = Rb + (size_t)gm * p.Tout + to;
-                if (vec) v = *reinterpret_cast<const float4*>(rp);
-                else {
-                    v.x = rp[0];
-                    if (to + 1 < p.Tout) v.y = rp[1];
-                    if (to + 2 < p.Tout) v.z = rp[2];
-                    if (to + 3 < p.Tout) v.w = rp[3];
-                }
-            }
-            return v;
-        };
-#pragma unroll
-        for (int r = 0; r < RP; ++r) res[r] = load_res(r);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-#pragma unroll
-            for (int j = 0; j < T::NT; ++j) Hw[half * HLD + 32 * j + q] = acc[0][j][r];
-            const int row = row_of(r), gm = m0 + row;
-            const float4 rr = res[r % RP];
-            if (r + RP < 16) res[r % RP] = load_res(r + RP);
-            if (act_lane && gm < M) {
-                const float4 h0 = *reinterpret_cast<const float4*>(Hw + half * HLD + o);
-                const float4 h1 = *reinterpret_cast<const float4*>(Hw + half * HLD + o + 4);
-                const float4 w0 = *reinterpret_cast<const float4*>(Wl + row * 8);
-                const float4 w1 = *reinterpret_cast<const float4*>(Wl + row * 8 + 4);
-                const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-                const float rv[4] = {rr.x, rr.y, rr.z, rr.w};
-                float y[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = w1.y;                                          // bias
-                    v = fmaf(w0.x, h[e], v); v = fmaf(w0.y, h[e + 1], v); v = fmaf(w0.z, h[e + 2], v);
-                    v = fmaf(w0.w, h[e + 3], v); v = fmaf(w1.x, h[e + 4], v);
-                    v = fmaf(v, w1.z, w1.w);                                 // FiLM (1, 0 when off)
-                    if (Rb) v = fmaf(v, p.out_scale, rv[e]);
-                    if (p.post_elu) v = elu1(v * p.post_scale);
-                    y[e] = v;
-                }
-                float* yp = Yb + (size_t)gm * p.Tout + to;
-                if (vec) *reinterpret_cast<float4*>(yp) = make_float4(y[0], y[1], y[2], y[3]);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (o + e < p.tto && to + e < p.Tout) yp[e] = y[e];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);      // keep the 64 accumulators in AGPRs until used
-        }
-    } else {
-        const int ks = p.ks;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-#pragma unroll
-            for (int j = 0; j < T::NT; ++j) Hw[half * HLD + 32 * j + q] = acc[0][j][r];
-            const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half, gm = m0 + row;
-            if (gm < M) {
-                const float* wr = p.dw_w + (size_t)gm * ks;
-                const float bias = p.dw_b ? p.dw_b[gm] : 0.f;
-                float gam = 1.f, bet = 0.f;
-                if (filmb) { const int band = gm / bw; gam = filmb[2 * band]; bet = filmb[2 * band + 1]; }
-                const float* hrow = Hw + half * HLD + p.off;
-                for (int o = q; o < p.tto; o += 32) {
-                    const int to = to0 + o;
-                    if (to >= p.Tout) break;
-                    const float* h = hrow + o * p.stride;
-                    float y = bias;
-                    for (int i = 0; i < ks; ++i) y = fmaf(wr[i], h[i * p.dil], y);
-                    y = fmaf(y, gam, bet);
-                    if (Rb) y = fmaf(y, p.out_scale, Rb[(size_t)gm * p.Tout + to]);
-                    if (p.post_elu) y = elu1(y * p.post_scale);
-                    Yb[(size_t)gm * p.Tout + to] = y;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+// XCD-aware tile mapping for K1.  Workgroup ids are dealt round-robin over the 8 XCDs (private
+// L2 each), so ids L, L+8, L+16, ... share an L2.  We enumerate, per XCD, the m-tiles of ONE
+// activation tile back to back: the X window is fetched into that L2 once and reused by all
+// M/BM m-tiles instead of crossing the fabric M/BM times.  (Speed only: any placement is correct.)
+struct TileId { int m_tile, t_tile, b; bool valid; };
+__device__ __forceinline__ TileId decode_tile(const PwDwArgs& p) {
+    const unsigned L = blockIdx.x;
+    const unsigned xcd = L & 7, j = L >> 3;
+    const unsigned m_tile = j % p.num_m, n_idx = (j / p.num_m) * 8 + xcd;
+    TileId t;
+    t.valid = n_idx < (unsigned)p.num_t * p.B;
+    t.m_tile = m_tile; t.t_tile = n_idx % p.num_t; t.b = n_idx / p.num_t;
+    return t;
 }
+
+// K1 epilogue (shared by the f32 and the split-f16 GEMM cores).  begin() runs BEFORE the GEMM:
+// it fills the per-row table (taps, bias, FiLM gamma/beta) in a dedicated LDS region and issues
+// the first residual loads, so none of the epilogue's global-memory latency is exposed after
+// the matrix phase.  finish() spills the wave's 32 x BN accumulator strip two rows at a time
+// into double-buffered wave-private LDS strips and applies stencil + bias (+FiLM | residual).
+template <class T, int KS, int RP_ = 8>
+struct PwDwEpi {
+    static constexpr int HLD = T::BN + 4;
+    static constexpr int RP = RP_;                            // residual rows in flight per lane
+    static constexpr int FLOATS = T::BM * 8 + T::WM * 4 * HLD;   // LDS floats this epilogue owns
+    int M, m0, b, to0, lane, wave, half, q, o, to;
+    bool act_lane, vec;
+    const float* Rb; float* Yb; float* Wl; float* Hw;
+    float4 res[RP];
+
+    __device__ __forceinline__ int row_of(int r) const { return 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half; }
+    __device__ __forceinline__ float4 load_res(const PwDwArgs& p, int r) const {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gm = m0 + row_of(r);
+        if (Rb && act_lane && gm < M) {
+            const float* rp = Rb + (size_t)gm * p.Tout + to;
+            if (vec) v = *reinterpret_cast<const float4*>(rp);
+            else {
+                v.x = rp[0];
+                if (to + 1 < p.Tout) v.y = rp[1];
+                if (to + 2 < p.Tout) v.z = rp[2];
+                if (to + 3 < p.Tout) v.w = rp[3];
+            }
+        }
+        return v;
+    }
+    // epi_smem: FLOATS floats not aliased with the GEMM stages.  A workgroup barrier must follow
+    // before finish() (the GEMM main loop has several).
+    __device__ __forceinline__ void begin(const PwDwArgs& p, float* epi_smem, int m0_, int b_, int to0_) {
+        M = p.pw.M; m0 = m0_; b = b_; to0 = to0_;
+        const int tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        half = lane >> 5; q = lane & 31;
+        Wl = epi_smem;
+        Hw = epi_smem + T::BM * 8 + wave * (4 * HLD);
+        Yb = p.Y + (size_t)b * M * p.Tout;
+        Rb = p.resid ? p.resid + (size_t)b * M * p.Tout : nullptr;
+        o = 4 * q; to = to0 + o;
+        act_lane = o < p.tto && to < p.Tout;
+        vec = act_lane && to + 3 < p.Tout && o + 3 < p.tto && (p.Tout & 3) == 0;
+        if (KS) {
+            const int bw = p.film ? (M / p.bands) : 1;
+            const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
+            for (int m = tid; m < T::BM; m += T::NTHREADS) {
+                const int gm = m0 + m;
+                float v[8] = {0, 0, 0, 0, 0, 0, 1.f, 0};
+                if (gm < M) {
+#pragma unroll
+                    for (int i = 0; i < KS; ++i) v[i] = p.dw_w[(size_t)gm * KS + i];
+                    v[5] = p.dw_b ? p.dw_b[gm] : 0.f;
+                    if (filmb) { const int band = gm / bw; v[6] = filmb[2 * band]; v[7] = filmb[2 * band + 1]; }
+                }
+                *reinterpret_cast<float4*>(Wl + m * 8) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(Wl + m * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+#pragma unroll
+            for (int r = 0; r < RP; ++r) res[r] = load_res(p, r);
+        }
+    }
+
+    __device__ __forceinline__ void finish(f32x16 (&acc)[1][T::NT], const PwDwArgs& p) {
+        if (KS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* strip = Hw + (r & 1) * 2 * HLD;           // double-buffered 2-row strip
+#pragma unroll
+                for (int j = 0; j < T::NT; ++j) strip[half * HLD + 32 * j + q] = acc[0][j][r];
+                const int row = row_of(r), gm = m0 + row;
+                const float4 rr = res[r % RP];
+                if (r + RP < 16) res[r % RP] = load_res(p, r + RP);
+                if (act_lane && gm < M) {
+                    const float4 h0 = *reinterpret_cast<const float4*>(strip + half * HLD + o);
+                    const float4 h1 = *reinterpret_cast<const float4*>(strip + half * HLD + o + 4);
+                    const float4 w0 = *reinterpret_cast<const float4*>(Wl + row * 8);
+                    const float4 w1 = *reinterpret_cast<const float4*>(Wl + row * 8 + 4);
+                    const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                    const float rv[4] = {rr.x, rr.y, rr.z, rr.w};
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = w1.y;                                          // bias
+                        v = fmaf(w0.x, h[e], v); v = fmaf(w0.y, h[e + 1], v); v = fmaf(w0.z, h[e + 2], v);
+                        v = fmaf(w0.w, h[e + 3], v); v = fmaf(w1.x, h[e + 4], v);
+                        v = fmaf(v, w1.z, w1.w);                                 // FiLM (1, 0 when off)
+                        if (Rb) v = fmaf(v, p.out_scale, rv[e]);
+                        if (p.post_elu) v = elu1(v * p.post_scale);
+                        y[e] = v;
+                    }
+                    float* yp = Yb + (size_t)gm * p.Tout + to;
+                    if (vec) *reinterpret_cast<float4*>(yp) = make_float4(y[0], y[1], y[2], y[3]);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (o + e < p.tto && to + e < p.Tout) yp[e] = y[e];
+                    }
+                }
+            }
+        } else {
+            const int ks = p.ks;
+            const int bw = p.film ? (M / p.bands) : 1;
+            const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* strip = Hw + (r & 1) * 2 * HLD;
+#pragma unroll
+                for (int j = 0; j < T::NT; ++j) strip[half * HLD + 32 * j + q] = acc[0][j][r];
+                const int gm = m0 + row_of(r);
+                if (gm < M) {
+                    const float* wr = p.dw_w + (size_t)gm * ks;
+                    const float bias = p.dw_b ? p.dw_b[gm] : 0.f;
+                    float gam = 1.f, bet = 0.f;
+                    if (filmb) { const int band = gm / bw; gam = filmb[2 * band]; bet = filmb[2 * band + 1]; }
+                    const float* hrow = strip + half * HLD + p.off;
+                    for (int oo = q; oo < p.tto; oo += 32) {
+                        const int t2 = to0 + oo;
+                        if (t2 >= p.Tout) break;
+                        const float* h = hrow + oo * p.stride;
+                        float y = bias;
+                        for (int i = 0; i < ks; ++i) y = fmaf(wr[i], h[i * p.dil], y);
+                        y = fmaf(y, gam, bet);
+                        if (Rb) y = fmaf(y, p.out_scale, Rb[(size_t)gm * p.Tout + t2]);
+                        if (p.post_elu) y = elu1(y * p.post_scale);
+                        Yb[(size_t)gm * p.Tout + t2] = y;
+                    }
+                }
+            }
+        }
+    }
+};
 
 template <class T, int KS>
 __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ? 3 : 2) void pw_dw_kernel(PwDwArgs p) {
@@ -333,10 +362,12 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
     static_assert(T::WN == 1 && T::MT == 1, "row-strip tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HLD = T::BN + 4;
-    const int m0 = blockIdx.x * T::BM;
-    const int b = blockIdx.z;
-    const int M = p.pw.M, K = p.pw.K;
-    const int to0 = blockIdx.y * p.tto;
+    const TileId tile = decode_tile(p);
+    if (!tile.valid) return;
+    const int m0 = tile.m_tile * T::BM;
+    const int b = tile.b;
+    const int K = p.pw.K;
+    const int to0 = tile.t_tile * p.tto;
     const int ti0 = to0 * p.stride - p.pad - p.off;
 
     if (p.stagger > 0) {
@@ -344,7 +375,7 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
         // together and, having identical work, would stay in lockstep -- all in the MFMA phase or
         // all in the HBM-bound epilogue at once.  Delaying 1/3 and 2/3 of that first generation
         // lets one workgroup's epilogue overlap another's matrix phase for the whole launch.
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned lin = blockIdx.x;
         if (lin < (unsigned)p.first_gen) {
             // consecutive ids round-robin over the 8 XCDs, then over an XCD's 32 CUs: ids that
             // differ by 256 share a CU, so lin / 256 enumerates a CU's resident slots
@@ -352,6 +383,8 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
             for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
         }
     }
+    PwDwEpi<T, KS> epi;
+    epi.begin(p, smem + 2 * T::STAGE, m0, b, to0);
     f32x16 acc[1][T::NT];
     zero_acc<T>(acc);
     WLoader la{p.pw.wt, p.pw.Mp, m0};
@@ -359,7 +392,7 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
                  nullptr, 0, false, false};
     gemm_mainloop<T>(acc, la, lb, p.pw.Kp / BK, smem, p.dbg);
     if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.Y[0] = 0.f; return; }
-    pw_dw_epilogue<T, KS>(acc, p, smem, m0, b, to0);
+    epi.finish(acc, p);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -381,36 +414,23 @@ template <class T>
 struct HT {
     static constexpr int KB = BKH / 8;
     static constexpr int NA = KB * 2 * T::BM;                 // A fragments per stage
-    static constexpr int CG = T::BN / 4;                      // column groups (4 columns each)
-    static constexpr int NBT = KB * CG;                       // B micro-tiles (8 k x 4 cols)
+    static constexpr int NBT = KB * T::BN;                    // B micro-tiles: 8 k rows x 1 column
     static constexpr int A_PER = (NA + T::NTHREADS - 1) / T::NTHREADS;
     static constexpr int B_PER = (NBT + T::NTHREADS - 1) / T::NTHREADS;
-    static constexpr int STAGE = KB * 2 * (T::BM + T::BN);    // u32x4 per stage
-    static_assert(T::NTHREADS % CG == 0, "a thread keeps one column group");
+    static constexpr int STAGE = KB * 2 * (T::BM + T::BN);    // 16-byte fragments per stage
 };
 
-struct RowLoaderH {                    // 8 consecutive k rows x 4 columns of a [K][ld] matrix
+// B operand rows for the split-f16 core: one column, 8 consecutive k rows per micro-tile.  Lanes
+// run along time, so the 4-byte loads of a wave are one contiguous 256-byte segment per row and
+// the fragment a thread builds (8 halfs along k for its column) lands in consecutive LDS slots.
+struct ColLoaderH {
     const float* base; int K, ld, ncols, c0; float scale; int elu;
-    const float* p; int c; bool full, vec;
-    __device__ __forceinline__ void init(int cg) {
-        c = c0 + 4 * cg;
-        full = c >= 0 && c + 3 < ncols;
-        vec = full && ((ld & 3) == 0) && ((c & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
-        p = base + c;
-    }
-    __device__ __forceinline__ void fetch8(int k0, float (&raw)[32]) const {
+    __device__ __forceinline__ void fetch8(int k0, int col, float (&raw)[8]) const {
+        const int c = c0 + col;
+        const bool inb = c >= 0 && c < ncols;
+        const float* p = base + (inb ? c : 0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = k0 + i;
-            if (k < K && vec) {
-                const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * ld);
-                raw[4 * i] = v.x; raw[4 * i + 1] = v.y; raw[4 * i + 2] = v.z; raw[4 * i + 3] = v.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    raw[4 * i + j] = (k < K && c + j >= 0 && c + j < ncols) ? p[(size_t)k * ld + j] : 0.f;
-            }
-        }
+        for (int i = 0; i < 8; ++i) raw[i] = (inb && k0 + i < K) ? p[(size_t)(k0 + i) * ld] : 0.f;
     }
     __device__ __forceinline__ float xform(float v) const { return act(v, scale, elu); }
 };
@@ -427,71 +447,57 @@ __device__ __forceinline__ void gemm_mainloop_h(f32x16 (&acc)[1][T::NT], const u
     using H = HT<T>;
     static_assert(T::WN == 1 && T::MT == 1, "row-strip tile");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cg = tid % H::CG;
-    u32x4 ra[H::A_PER];
-    float rb[H::B_PER][32];
-    lb.init(cg);
+    u32x4 ra[2][H::A_PER];
+    float rb[2][H::B_PER][8];
 
-    auto fetch = [&](int c) {
+    auto fetch = [&](int c, u32x4 (&xa)[H::A_PER], float (&xb)[H::B_PER][8]) {
 #pragma unroll
         for (int r = 0; r < H::A_PER; ++r) {
             const int idx = tid + r * T::NTHREADS;
             if (H::NA % T::NTHREADS == 0 || idx < H::NA) {
                 const int m = idx % T::BM, rest = idx / T::BM;          // rest = kq*2 + hl
-                ra[r] = wh[(size_t)(c * H::KB * 2 + rest) * Mp + m0 + m];
+                xa[r] = wh[(size_t)(c * H::KB * 2 + rest) * Mp + m0 + m];
             }
         }
 #pragma unroll
         for (int r = 0; r < H::B_PER; ++r) {
             const int idx = tid + r * T::NTHREADS;
-            if (H::NBT % T::NTHREADS == 0 || idx < H::NBT) lb.fetch8(c * BKH + (idx / H::CG) * 8, rb[r]);
+            if (H::NBT % T::NTHREADS == 0 || idx < H::NBT)
+                lb.fetch8(c * BKH + (idx / T::BN) * 8, idx % T::BN, xb[r]);
         }
     };
-    auto commit = [&](u32x4* buf) {
+    auto commit = [&](u32x4* buf, const u32x4 (&xa)[H::A_PER], const float (&xb)[H::B_PER][8]) {
         u32x4* As = buf;
         u32x4* Bs = buf + H::KB * 2 * T::BM;
 #pragma unroll
         for (int r = 0; r < H::A_PER; ++r) {
             const int idx = tid + r * T::NTHREADS;
-            if (H::NA % T::NTHREADS == 0 || idx < H::NA) As[idx] = ra[r];
+            if (H::NA % T::NTHREADS == 0 || idx < H::NA) As[idx] = xa[r];
         }
 #pragma unroll
         for (int r = 0; r < H::B_PER; ++r) {
             const int idx = tid + r * T::NTHREADS;
             if (!(H::NBT % T::NTHREADS == 0 || idx < H::NBT)) continue;
-            const int kq = idx / H::CG;
+            const int kq = idx / T::BN, col = idx % T::BN;
+            unsigned hw[4], lw[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                unsigned hw[4], lw[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    half2v h2, l2;
-                    _Float16 h, l;
-                    split_f16(lb.xform(rb[r][4 * (2 * i) + j]), h, l);
-                    h2[0] = h; l2[0] = l;
-                    split_f16(lb.xform(rb[r][4 * (2 * i + 1) + j]), h, l);
-                    h2[1] = h; l2[1] = l;
-                    hw[i] = __builtin_bit_cast(unsigned, h2);
-                    lw[i] = __builtin_bit_cast(unsigned, l2);
-                }
-                const int slot = 4 * cg + (j ^ (cg & 3));
-                Bs[(kq * 2 + 0) * T::BN + slot] = u32x4{hw[0], hw[1], hw[2], hw[3]};
-                Bs[(kq * 2 + 1) * T::BN + slot] = u32x4{lw[0], lw[1], lw[2], lw[3]};
+            for (int i = 0; i < 4; ++i) {
+                half2v h2, l2;
+                _Float16 h, l;
+                split_f16(lb.xform(xb[r][2 * i]), h, l);
+                h2[0] = h; l2[0] = l;
+                split_f16(lb.xform(xb[r][2 * i + 1]), h, l);
+                h2[1] = h; l2[1] = l;
+                hw[i] = __builtin_bit_cast(unsigned, h2);
+                lw[i] = __builtin_bit_cast(unsigned, l2);
             }
+            Bs[(kq * 2 + 0) * T::BN + col] = u32x4{hw[0], hw[1], hw[2], hw[3]};
+            Bs[(kq * 2 + 1) * T::BN + col] = u32x4{lw[0], lw[1], lw[2], lw[3]};
         }
     };
-
-    fetch(0);
-    commit(smem);
-    __syncthreads();
     const int h = lane >> 5, i31 = lane & 31;
-    int bslot[T::NT];
-#pragma unroll
-    for (int j = 0; j < T::NT; ++j) { const int n = 32 * j + i31; bslot[j] = n ^ ((n >> 2) & 3); }
-    for (int c = 0; c < nchunks; ++c) {
-        const u32x4* As = smem + (c & 1) * H::STAGE;
+    auto compute = [&](const u32x4* As) {
         const u32x4* Bs = As + H::KB * 2 * T::BM;
-        if (c + 1 < nchunks) fetch(c + 1);
 #pragma unroll
         for (int s = 0; s < BKH / 16; ++s) {
             const int kq = 2 * s + h;
@@ -499,14 +505,29 @@ __device__ __forceinline__ void gemm_mainloop_h(f32x16 (&acc)[1][T::NT], const u
             const half8 al = __builtin_bit_cast(half8, As[(kq * 2 + 1) * T::BM + 32 * wave + i31]);
 #pragma unroll
             for (int j = 0; j < T::NT; ++j) {
-                const half8 bh = __builtin_bit_cast(half8, Bs[(kq * 2 + 0) * T::BN + bslot[j]]);
-                const half8 bl = __builtin_bit_cast(half8, Bs[(kq * 2 + 1) * T::BN + bslot[j]]);
+                const half8 bh = __builtin_bit_cast(half8, Bs[(kq * 2 + 0) * T::BN + 32 * j + i31]);
+                const half8 bl = __builtin_bit_cast(half8, Bs[(kq * 2 + 1) * T::BN + 32 * j + i31]);
                 acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[0][j], 0, 0, 0);
                 acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[0][j], 0, 0, 0);
                 acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0][j], 0, 0, 0);
             }
         }
-        if (c + 1 < nchunks) commit(smem + ((c + 1) & 1) * H::STAGE);
+    };
+
+    // two register sets, two LDS stages: chunk c+2 is in flight across two matrix phases
+    fetch(0, ra[0], rb[0]);
+    commit(smem, ra[0], rb[0]);
+    if (nchunks > 1) fetch(1, ra[1], rb[1]);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 2 < nchunks) fetch(c + 2, ra[0], rb[0]);
+        compute(smem);
+        if (c + 1 < nchunks) commit(smem + H::STAGE, ra[1], rb[1]);
+        __syncthreads();
+        if (c + 1 >= nchunks) break;
+        if (c + 3 < nchunks) fetch(c + 3, ra[1], rb[1]);
+        compute(smem + H::STAGE);
+        if (c + 2 < nchunks) commit(smem, ra[0], rb[0]);
         __syncthreads();
     }
 }
@@ -514,17 +535,21 @@ __device__ __forceinline__ void gemm_mainloop_h(f32x16 (&acc)[1][T::NT], const u
 template <class T, int KS>
 __global__ __launch_bounds__(T::NTHREADS, 2) void pw_dw_h_kernel(PwDwArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int m0 = blockIdx.x * T::BM;
-    const int b = blockIdx.z;
+    const TileId tile = decode_tile(p);
+    if (!tile.valid) return;
+    const int m0 = tile.m_tile * T::BM;
+    const int b = tile.b;
     const int K = p.pw.K;
-    const int to0 = blockIdx.y * p.tto;
+    const int to0 = tile.t_tile * p.tto;
     const int ti0 = to0 * p.stride - p.pad - p.off;
+    PwDwEpi<T, KS, 2> epi;
+    epi.begin(p, smem + 2 * HT<T>::STAGE * 4, m0, b, to0);
     f32x16 acc[1][T::NT];
     zero_acc<T>(acc);
-    RowLoaderH lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
+    ColLoaderH lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu};
     gemm_mainloop_h<T>(acc, reinterpret_cast<const u32x4*>(p.pw.wh), p.pw.Mp, m0, lb, p.pw.Kh / BKH,
                        reinterpret_cast<u32x4*>(smem));
-    pw_dw_epilogue<T, KS>(acc, p, smem, m0, b, to0);
+    epi.finish(acc, p);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -977,10 +1002,15 @@ static bool pw_dw_geometry(PwDwArgs& a, int BN) {
 template <class T, int KS>
 static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     if (!pw_dw_geometry(a, T::BN)) return hipErrorInvalidValue;
-    a.dbg = g_debug_flags & 15;
-    size_t smem = stage_bytes<T>();
-    const size_t eb = ((size_t)T::BM * 8 + (size_t)T::WM * 2 * (T::BN + 4)) * sizeof(float);
-    if (eb > smem) smem = eb;
+    a.dbg = g_debug_flags & 31;
+    const size_t eb = (size_t)PwDwEpi<T, KS>::FLOATS * sizeof(float);
+    const size_t smem = stage_bytes<T>() + eb;
+    static bool attr_f32 = false;
+    if (!attr_f32) {
+        hipError_t e = set_smem(pw_dw_kernel<T, KS>, smem);
+        if (e != hipSuccess) return e;
+        attr_f32 = true;
+    }
     static int per_cu = -1;                               // resident workgroups per CU
     if (per_cu < 0) {
         int n = 0;
@@ -992,13 +1022,19 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     const int st_flag = (g_debug_flags >> 8) & 255;
     a.stagger = st_flag == 255 ? 0 : (st_flag ? st_flag : 2);       // default 2 x s_sleep(127) per slot
     a.first_gen = 256 * per_cu;
-    dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + a.tto - 1) / a.tto, a.B);
-    if ((long long)grid.x * grid.y * grid.z < 4LL * a.first_gen) a.stagger = 0;
+    a.num_m = (a.pw.M + T::BM - 1) / T::BM;
+    a.num_t = (a.Tout + a.tto - 1) / a.tto;
+    const long long n_act = (long long)a.num_t * a.B;
+    const long long nblk = ((n_act + 7) / 8) * 8 * a.num_m;
+    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)nblk);
+    if (nblk < 4LL * a.first_gen) a.stagger = 0;
     static const std::string name = tile_name<T>(KS ? "pw_dw_k5" : "pw_dw");
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
-    if (a.prec == PREC_F16X3 && a.pw.wh) {
-        size_t hs = 2 * (size_t)HT<T>::STAGE * 16;
-        if (eb > hs) hs = eb;
+    // the split-f16 core pays off for the 4-wave (BM = 128) tiles; smaller tiles (C <= 96 layers,
+    // HBM-bound anyway) stay on the f32 core
+    if constexpr (T::NTHREADS == 256 && T::BN == 64) if (a.prec == PREC_F16X3 && a.pw.wh && a.pw.K >= 256) {
+        const size_t hs = 2 * (size_t)HT<T>::STAGE * 16 + eb;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = set_smem(pw_dw_h_kernel<T, KS>, hs);
@@ -1037,8 +1073,20 @@ hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
     if (a.ks < 1 || a.stride < 1 || a.dil < 1 || a.pad < 0 || a.pw.Mp % M_ALIGN || a.pw.Kp % BK)
         return hipErrorInvalidValue;
     const int need = (a.ks - 1) * a.dil + 1;            // H columns one output needs
-    const bool narrow = a.Tin + a.pad + 3 <= 64 && need + 3 <= 64;
+    bool narrow = (a.Tin + a.pad + 3 <= 64 && need + 3 <= 64) || ((g_debug_flags & 32) && need + 3 <= 64);
+    if (!narrow && need + 3 <= 64) {
+        // pick the window width that computes the fewest columns for this Tout (tile quantisation:
+        // e.g. Tout = 400 needs 4 x 128 columns with 124-output tiles but only 7 x 64 with 60-output ones)
+        PwDwArgs g128 = a, g64 = a;
+        if (pw_dw_geometry(g128, 128) && pw_dw_geometry(g64, 64)) {
+            const long long c128 = (long long)((a.Tout + g128.tto - 1) / g128.tto) * 128;
+            const long long c64 = (long long)((a.Tout + g64.tto - 1) / g64.tto) * 64;
+            if (c64 * 100 < c128 * 95) narrow = true;
+        }
+    }
     const int bm = pick_bm(a.pw.M);
+    // split-f16 core: only where the layer is matrix-bound (K >= 256) and only on the 128 x 64 tile
+    if (a.prec == PREC_F16X3 && a.pw.wh && a.pw.K >= 256 && bm == 128 && need + 3 <= 64) narrow = true;
     if (narrow) {
         switch (bm) {
             case 32: return run_pw_dw<Tile<32, 64, 1, 1>>(a, s);
