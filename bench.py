@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="embed_detect", choices=["embed_detect", "longform", "detector_stress"],
+                    help="embed_detect = BASELINE configs[1] (the headline); longform = configs[3] "
+                         "(32 x 30 s, embed+locate+detect); detector_stress = configs[4] (1024 clips, detector only)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
                     help="GEMM core: exact f32 MFMA, or split-f16 (hi+lo, 3 f16 MFMAs, f32 accumulate)")
     return ap.parse_args()
@@ -77,16 +80,29 @@ def main():
     from waveverify_amd.init import random_state_dict, synthetic_clips
     from waveverify_amd.nets import HipNet
 
+    if a.workload == "longform":
+        a.batch, a.seconds = (32 if a.batch == 256 else a.batch), (30.0 if a.seconds == 1.0 else a.seconds)
+    elif a.workload == "detector_stress":
+        a.batch = 1024 if a.batch == 256 else a.batch
     T = int(round(a.seconds * 16000))
     B = a.batch
     cfgG, cfgD = default_config("generator"), default_config("detector")
     sdG, sdD = random_state_dict(cfgG, 0), random_state_dict(cfgD, 0)
     G, D = HipNet(cfgG, sdG, dev, precision=a.precision), HipNet(cfgD, sdD, dev, precision=a.precision)
+    Lnet = None
+    if a.workload == "longform":
+        cfgL = default_config("locator")
+        Lnet = HipNet(cfgL, random_state_dict(cfgL, 0), dev, precision=a.precision)
     x_np, msg_np = synthetic_clips(B, T, seed=1234 + rank)         # each rank owns its shard
     x, msg = torch.from_numpy(x_np).to(dev), torch.from_numpy(msg_np).to(dev)
 
     def step():
+        if a.workload == "detector_stress":
+            mp = D.detector_mean_prob(x)
+            return x, mp, mp >= 0.5
         wm = G.generator(x, msg, add_input=True)
+        if Lnet is not None:
+            Lnet.locator(wm)
         mp = D.detector_mean_prob(wm)
         return wm, mp, mp >= 0.5
 
@@ -148,17 +164,21 @@ def main():
                       for k, v in by_kernel.items()), key=lambda d: -d["ms_per_step"])
 
     # ---- parity beside the number: BER / waveform error vs the oracle on a sample --------------
-    out = dict(metric="clips/sec embed+detect, 1s@16kHz bs=256", value=round(world * B * a.steps / elapsed, 2),
+    metric = {"embed_detect": "clips/sec embed+detect, 1s@16kHz bs=256",
+              "longform": "clips/sec embed+locate+detect, 30s@16kHz bs=32",
+              "detector_stress": "clips/sec detect, 1s@16kHz bs=1024"}[a.workload]
+    out = dict(metric=metric, value=round(world * B * a.steps / elapsed, 2),
                unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                ms_per_step=round(elapsed / a.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                vs_baseline=None, dtype=a.precision, data="synthetic",
-               config=dict(workload=f"embed+detect, {B} clips x {a.seconds:g} s @ 16 kHz per GPU "
-                                    "(BASELINE.json configs[1]), generator+detector forward, seeded random weights",
+               config=dict(workload=f"{a.workload}: {B} clips x {a.seconds:g} s @ 16 kHz per GPU "
+                                    f"(BASELINE.json configs[{dict(embed_detect=1, longform=3, detector_stress=4)[a.workload]}]), "
+                                    "seeded random weights",
                            batch_per_gpu=B, global_batch=B * world, clip_samples=T,
                            parallelism=f"dp{world} (independent clip shards, no data-path collective)"),
                roofline=roofline, roofline_film=roofline_film, kernels=kernels[:8],
                kernel_time_ms_per_step=round(total_ms / a.steps, 3))
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and a.workload == "embed_detect":
         cb, wm_ref, mp_ref = cpu_baseline(cfgG, cfgD, sdG, sdD, x_np, msg_np, min(a.cpu_clips, B))
         n = wm_ref.shape[0]
         out["cpu_baseline"] = cb

@@ -1,0 +1,68 @@
+"""BASELINE.json configs[3] (long-form clips) and configs[4] (large-batch detector).  The kernels
+tile time themselves (every tile stages its causal halo through LDS), so long clips need no
+host-side chunker; these tests pin that claim: oracle parity on a 3 s clip, the causal prefix
+property on a 30 s clip (outputs before a hop boundary do not depend on later input),
+locator MIoU vs the oracle, and batch independence at B=1024."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wv_oracle as O
+from waveverify_amd.config import default_config
+from waveverify_amd.init import random_state_dict, synthetic_clips
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nets():
+    from waveverify_amd.nets import HipNet
+    return {k: HipNet(default_config(k), random_state_dict(default_config(k), 0))
+            for k in ("generator", "detector", "locator")}
+
+
+def test_three_second_clip_vs_oracle(nets):
+    x, msg = synthetic_clips(2, 48000, seed=21)
+    cfg = {k: n.cfg for k, n in nets.items()}
+    wm_ref = O.embed(cfg["generator"], random_state_dict(cfg["generator"], 0), x, msg)
+    wm = nets["generator"].generator(torch.from_numpy(x).cuda(), torch.from_numpy(msg).cuda(), add_input=True)
+    assert np.abs(wm.cpu().numpy() - wm_ref).max() <= 2e-5
+    loc_ref = O.locator_forward(cfg["locator"], random_state_dict(cfg["locator"], 0), wm_ref)
+    loc = nets["locator"].locator(torch.from_numpy(wm_ref).cuda()).cpu().numpy()
+    assert np.abs(loc - loc_ref).max() <= 2e-4
+    # MIOU on the raw locator output binarised at 0.5 (model/watermarking.py:717,797)
+    assert O.miou((loc > 0.5).astype(int), (loc_ref > 0.5).astype(int)) >= 0.9999
+    mp_ref = O.mean_probabilities(O.detector_forward(cfg["detector"], random_state_dict(cfg["detector"], 0), wm_ref))
+    mp = nets["detector"].detector_mean_prob(torch.from_numpy(wm_ref).cuda()).cpu().numpy()
+    assert np.abs(mp - mp_ref).max() <= 1e-5 and ((mp >= 0.5) == (mp_ref >= 0.5)).all()
+
+
+def test_thirty_second_clip_prefix_property(nets):
+    """30 s at 16 kHz (T = 480000).  Everything is causal up to the end of a hop frame, so the
+    first L samples (L a multiple of 320) of every output equal the outputs on the L-sample prefix."""
+    T, L = 480000, 96000
+    x, msg = synthetic_clips(1, T, seed=33)
+    xt, mt = torch.from_numpy(x).cuda(), torch.from_numpy(msg).cuda()
+    G, D, Lc = nets["generator"], nets["detector"], nets["locator"]
+    wm = G.generator(xt, mt, add_input=True)
+    assert wm.shape == (1, 1, T) and torch.isfinite(wm).all()
+    wm_p = G.generator(xt[..., :L], mt, add_input=True)
+    assert (wm[..., :L] - wm_p).abs().max().item() <= 1e-6
+    lg, lg_p = D.detector(wm), D.detector(wm[..., :L].contiguous())
+    assert (lg[..., :L] - lg_p).abs().max().item() <= 1e-4
+    lo, lo_p = Lc.locator(wm), Lc.locator(wm[..., :L].contiguous())
+    assert (lo[..., :L] - lo_p).abs().max().item() <= 1e-4
+    mp = D.detector_mean_prob(wm)
+    assert (mp - torch.sigmoid(lg).mean(dim=2)).abs().max().item() <= 1e-5
+
+
+def test_detector_batch_1024(nets):
+    """configs[4]: 1024 short clips through the detector; the fused sigmoid-mean head never stores the
+    [1024,16,16000] logits (1.05 GB).  Clips are independent: row i equals a batch-of-8 run."""
+    x, _ = synthetic_clips(1024, 16000, seed=4)
+    xt = torch.from_numpy(x).cuda()
+    D = nets["detector"]
+    mp = D.detector_mean_prob(xt)
+    assert mp.shape == (1024, 16) and torch.isfinite(mp).all()
+    for lo in (0, 512, 1016):
+        assert torch.equal(D.detector_mean_prob(xt[lo:lo + 8]), mp[lo:lo + 8])
