@@ -143,8 +143,17 @@ def main():
     dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
     dom_avg_s = dom["ms"] / dom["launches"] * 1e-3
     ach = dom["flops"] / dom["launches"] / dom_avg_s / 1e12
+    traffic, traffic_src = None, None
+    try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same workload
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if a.workload == "embed_detect" and B == 256 and dom_name in pmc["kernels"]:
+            traffic = round(pmc["kernels"][dom_name]["traffic_bytes_per_launch"] / 1e9, 3)
+            traffic_src = "profiles/r01_pmc_traffic.json: GB per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes"
+    except Exception:
+        pass
     roofline = dict(bound="mfma", kernel=dom_name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                    unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
+                    algorithmic_gb_per_launch=round(dom["bytes"] / dom["launches"] / 1e9, 3),
                     avg_launch_us=round(dom_avg_s * 1e6, 1), launches_per_step=dom["launches"] // a.steps,
                     share_of_kernel_time=round(dom["ms"] / total_ms, 3),
                     algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 2))
