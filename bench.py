@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=1.0)
-    ap.add_argument("--cpu-clips", type=int, default=8, help="clips of the CPU-baseline sample")
+    ap.add_argument("--cpu-clips", type=int, default=16, help="clips of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="embed_detect", choices=["embed_detect", "longform", "detector_stress"],
                     help="embed_detect = BASELINE configs[1] (the headline); longform = configs[3] "
@@ -47,18 +47,22 @@ def parse():
 
 
 def cpu_baseline(cfgG, cfgD, sdG, sdD, x, msg, n):
-    """The numpy oracle (a port of the reference CPU path) timed on this box's host cores on a
-    bounded sample of the same workload.  Reported beside the GPU number, never as it."""
-    from oracle import wv_oracle as O
-    G, D = O._Net(cfgG, sdG), O._Net(cfgD, sdD)
+    """The reference's CPU path, restated on torch.nn.functional (oracle/wv_oracle_torch.py, pinned to
+    the reference's outputs), timed on this box's host cores on a bounded sample of the same workload.
+    Reported beside the GPU number, never as it."""
+    from oracle import wv_oracle_torch as OT
+    threads = min(os.cpu_count() or 1, 16)            # a 1-GPU box's CPU share
+    torch.set_num_threads(threads)
+    G, D = OT.Net(cfgG, sdG), OT.Net(cfgD, sdD)
     xs, ms = x[:n], msg[:n]
+    OT.embed(G, xs[:1], ms[:1])                       # warm-up (oneDNN primitive creation)
     t0 = time.perf_counter()
-    wm = O.embed(cfgG, G, xs, ms)
-    mp = O.mean_probabilities(O.detector_forward(cfgD, D, wm))
+    wm = OT.embed(G, xs, ms)
+    mp = OT.mean_probabilities(OT.detector_logits(D, wm))
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="clips/s", cores=os.cpu_count(), kind="port",
-                sample=f"{n} clips x 1 s @ 16 kHz, one embed+detect pass of the numpy oracle "
-                       f"(OpenBLAS threads = all {os.cpu_count()} host cores), {dt:.1f} s"), wm, mp
+    return dict(value=n / dt, unit="clips/s", cores=threads, kind="port",
+                sample=f"{n} clips x 1 s @ 16 kHz, one embed+detect pass of the torch-CPU port of the "
+                       f"reference path (fp32, {threads} threads), {dt:.1f} s"), wm.numpy(), mp.numpy()
 
 
 def main():

@@ -134,3 +134,22 @@ def test_ber_and_miou_edge_cases():
     assert O.miou(z, z) == 1.0 and O.miou(o, o) == 1.0 and O.miou(z, o) == 0.0
     m = np.array([1, 1, 0, 0]); n = np.array([1, 0, 0, 0])
     assert abs(O.miou(m, n) - (0.5 + 2 / 3) / 2) < 1e-12
+
+
+def test_torch_flavoured_oracle_matches_reference(golden_dir):
+    """oracle/wv_oracle_torch.py (what bench.py times as the CPU baseline) is pinned like the numpy one."""
+    import torch
+    from oracle import wv_oracle_torch as OT
+    g = np.load(os.path.join(golden_dir, "full_T16001.npz"))
+    cg, cd, cl = (default_config(k) for k in ("generator", "detector", "locator"))
+    G = OT.Net(cg, random_state_dict(cg, 0, parametrized=True))
+    D = OT.Net(cd, random_state_dict(cd, 0))
+    L = OT.Net(cl, random_state_dict(cl, 0))
+    wm = OT.embed(G, g["x"], g["msg"]).numpy()
+    _close(wm, g["wm"], 1e-5, "wm (torch oracle)")
+    lg = OT.detector_logits(D, g["wm"])
+    _close(lg.numpy()[..., ::37], g["det_logits_sub"], 1e-4, "det logits (torch oracle)")
+    mp = OT.mean_probabilities(lg).numpy()
+    _close(mp, g["det_mean_prob"], 1e-5)
+    assert ((mp >= 0.5).astype(int) == g["det_bits"]).all()
+    _close(OT.detector_logits(L, g["wm"]).numpy()[..., ::7], g["loc_logits_sub"], 1e-4, "loc (torch oracle)")
