@@ -75,7 +75,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("WV_BENCH_FORCE_DIST") == "1":   # the latter: 1-rank rehearsal of the N>1 path
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)          # RCCL; used for barrier + MAX only
 

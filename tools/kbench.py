@@ -33,8 +33,9 @@ if __name__ == "__main__":
     shapes = [(128, 8000, 256), (64, 16000, 256), (512, 400, 256), (768, 400, 256), (96, 16000, 256)]
     if len(sys.argv) == 4:
         shapes = [tuple(int(v) for v in sys.argv[1:4])]
-    names = {(255 << 8) | 64: "warmup", 255 << 8: "f32 full"}
+    names = {(255 << 8) | 64: "warmup", 255 << 8: "f32 full", (255 << 8) | 17: "no-epi, no global loads (LDS+MFMA)",
+             (255 << 8) | 25: "no-epi, no loads, no LDS reads (MFMA only)"}
     for C, T, B in shapes:
-        for fl, nm in list(names.items()) + [((255 << 8) | 128, "f16x3 full")]:
+        for fl, nm in list(names.items()):
             us, tf, gb, k = run(C, T, B, flags=fl & ~128, prec="f16x3" if fl & 128 else "f32")
             print(f"C={C:4d} T={T:6d} {k:24s} {nm:42s} {us:9.1f} us  {tf:6.1f} TF/s {gb:7.1f} GB/s", flush=True)

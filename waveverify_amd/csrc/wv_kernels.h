@@ -23,6 +23,8 @@ struct PwWeight {
     // fragment (kb, m) = W[m][8kb .. 8kb+7]; Kh = roundup(K, 32), zero padded.  May be null.
     const void* wh = nullptr;
     int Kh = 0;
+    // k-inner f32 layout for the row-strip core: wq[Kp/4][Mp][4] (W[m][4kq .. 4kq+3]); may be null
+    const float* wq = nullptr;
 };
 constexpr int BKH = 32;         // K-chunk of the split-f16 core
 enum Precision { PREC_F32 = 0, PREC_F16X3 = 1 };

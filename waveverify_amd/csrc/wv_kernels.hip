@@ -15,6 +15,8 @@
 namespace wv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int NT_ = 256;   // threads per workgroup
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
@@ -118,22 +120,29 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::MT][T::NT], const
     for (int c = 0; c < nchunks; ++c) {
         const float* As = smem + (c & 1) * T::STAGE;
         const float* Bs = As + BK * T::BM;
-        if (c + 1 < nchunks) fetch(c + 1);
+        if (!(dbg & 16) && c + 1 < nchunks) fetch(c + 1);
         if (!(dbg & 2))
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[T::MT], b[T::NT];
+            if (dbg & 8) {                       // ablation: operands from registers, no LDS reads
+#pragma unroll
+                for (int i = 0; i < T::MT; ++i) a[i] = 0.5f + kk;
+#pragma unroll
+                for (int j = 0; j < T::NT; ++j) b[j] = 0.25f + j;
+            } else {
 #pragma unroll
             for (int i = 0; i < T::MT; ++i) a[i] = As[(kk + arow) * T::BM + acol + i * 32];
 #pragma unroll
             for (int j = 0; j < T::NT; ++j) b[j] = Bs[(kk + arow) * T::BN + bcol_f + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < T::MT; ++i)
 #pragma unroll
                 for (int j = 0; j < T::NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < nchunks) commit(c + 1, smem + ((c + 1) & 1) * T::STAGE);
+        if (!(dbg & 16) && c + 1 < nchunks) commit(c + 1, smem + ((c + 1) & 1) * T::STAGE);
         __syncthreads();
     }
 }
@@ -202,6 +211,139 @@ struct RowLoader {
 // Zero padding: X is staged as 0 outside [0,Tin) and the 1x1 has no bias, so H is 0 there,
 // which is exactly the zero pad SConv1d inserts between the 1x1 and the DW conv.
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// f32 GEMM core for the row-strip tiles, k-inner LDS layout.  LDS holds float4 fragments
+// [kq][row] = 4 consecutive k of one row/column, so a lane fetches the operands of FOUR MFMA
+// steps with one ds_read_b128 (the generic core needs four ds_read_b32): 10 LDS reads per
+// 16-deep chunk and wave instead of 40.  The k index is only a summation index, so the two
+// lane halves may take any disjoint k sets as long as A and B agree: half h owns fragments
+// kq = h and kq = h + 2, i.e. k in [4h, 4h+4) U [8+4h, 12+4h).
+// A fragments are pre-packed on the host (wq); B columns are loaded with time on the lanes
+// (four 4-byte loads per 4k x 1col micro-tile, 256-byte segments per wave) and written as one
+// conflict-free ds_write_b128.
+// ------------------------------------------------------------------------------------------
+template <class T>
+struct QT {
+    static constexpr int KQ = BK / 4;                         // fragments along k per chunk
+    static constexpr int NA = KQ * T::BM, NB = KQ * T::BN;    // f32x4 fragments per stage
+    static constexpr int CG = T::BN / 4;                      // column groups of 4
+    static constexpr int NBT = (BK / 2) * CG;                 // B micro-tiles: 2 k rows x 4 columns
+    static constexpr int A_PER = (NA + T::NTHREADS - 1) / T::NTHREADS;
+    static constexpr int B_PER = (NBT + T::NTHREADS - 1) / T::NTHREADS;
+    static constexpr int STAGE = NA + NB;                     // f32x4 per stage (== BK*(BM+BN) floats)
+    static_assert(T::NTHREADS % CG == 0, "a thread keeps its column group");
+};
+
+// B operand for the k-inner core: a thread owns a 2(k) x 4(time) micro-tile -- two 16-byte row
+// loads, exactly the coalescing of a plain row copy -- and scatters it as four 8-byte halves of
+// the [kq][col] fragments.  Column slots are XOR-swizzled inside each group of 4 so the 16 lanes
+// of a ds_write_b64 group land on 8 distinct bank pairs (2-way, free) instead of 2 (8-way).
+__device__ __forceinline__ int q_slot(int n) { return (n & ~3) | ((n & 3) ^ ((n >> 3) & 3)); }
+
+struct RowPairLoader {
+    const float* base; int K, ld, ncols, c0; float scale; int elu;
+    const float* p; int c; bool full, vec;
+    __device__ __forceinline__ void init(int cg) {
+        c = c0 + 4 * cg;
+        full = c >= 0 && c + 3 < ncols;
+        vec = full && ((ld & 3) == 0) && ((c & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+        p = base + c;
+    }
+    __device__ __forceinline__ void fetch2(int k0, float (&raw)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + i;
+            if (k < K && vec) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)k * ld);
+                raw[4 * i] = v.x; raw[4 * i + 1] = v.y; raw[4 * i + 2] = v.z; raw[4 * i + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    raw[4 * i + j] = (k < K && c + j >= 0 && c + j < ncols) ? p[(size_t)k * ld + j] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ float xform(float v) const { return act(v, scale, elu); }
+};
+
+template <class T, class LB>
+__device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f32x4* __restrict__ wq,
+                                                int Mp, int m0, LB& lb, int nchunks, f32x4* smem,
+                                                int dbg = 0) {
+    using Q = QT<T>;
+    static_assert(T::WN == 1 && T::MT == 1, "row-strip tile");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = tid % Q::CG;
+    f32x4 ra[Q::A_PER];
+    float rb[Q::B_PER][8];
+    lb.init(cg);
+
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < Q::A_PER; ++r) {
+            const int idx = tid + r * T::NTHREADS;
+            if (Q::NA % T::NTHREADS == 0 || idx < Q::NA)
+                ra[r] = wq[(size_t)(c * Q::KQ + idx / T::BM) * Mp + m0 + idx % T::BM];
+        }
+#pragma unroll
+        for (int r = 0; r < Q::B_PER; ++r) {
+            const int idx = tid + r * T::NTHREADS;
+            if (Q::NBT % T::NTHREADS == 0 || idx < Q::NBT) lb.fetch2(c * BK + (idx / Q::CG) * 2, rb[r]);
+        }
+    };
+    auto commit = [&](f32x4* buf) {
+#pragma unroll
+        for (int r = 0; r < Q::A_PER; ++r) {
+            const int idx = tid + r * T::NTHREADS;
+            if (Q::NA % T::NTHREADS == 0 || idx < Q::NA) buf[idx] = ra[r];
+        }
+        float* Bf = reinterpret_cast<float*>(buf + Q::NA);
+#pragma unroll
+        for (int r = 0; r < Q::B_PER; ++r) {
+            const int idx = tid + r * T::NTHREADS;
+            if (!(Q::NBT % T::NTHREADS == 0 || idx < Q::NBT)) continue;
+            const int kp = idx / Q::CG;                       // k rows 2kp, 2kp+1 of the chunk
+            const int kq = kp >> 1, kh = kp & 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int slot = q_slot(4 * cg + j);
+                f32x2 v{lb.xform(rb[r][j]), lb.xform(rb[r][4 + j])};
+                *reinterpret_cast<f32x2*>(Bf + ((size_t)(kq * T::BN + slot) * 4 + 2 * kh)) = v;
+            }
+        }
+    };
+    const int h = lane >> 5, i31 = lane & 31;
+    int bslot[T::NT];
+#pragma unroll
+    for (int j = 0; j < T::NT; ++j) bslot[j] = q_slot(32 * j + i31);
+    fetch(0);
+    commit(smem);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const f32x4* As = smem + (c & 1) * Q::STAGE;
+        const f32x4* Bs = As + Q::NA;
+        if (!(dbg & 16) && c + 1 < nchunks) fetch(c + 1);
+        if (!(dbg & 2)) {
+            const f32x4 a0 = As[h * T::BM + 32 * wave + i31];
+            const f32x4 a1 = As[(h + 2) * T::BM + 32 * wave + i31];
+            f32x4 b0[T::NT], b1[T::NT];
+#pragma unroll
+            for (int j = 0; j < T::NT; ++j) {
+                b0[j] = Bs[h * T::BN + bslot[j]];
+                b1[j] = Bs[(h + 2) * T::BN + bslot[j]];
+            }
+#define WV_QSTEP(AV, BQ, COMP)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < T::NT; ++j)                                              \
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BQ[j].COMP, acc[0][j], 0, 0, 0);
+            WV_QSTEP(a0.x, b0, x) WV_QSTEP(a0.y, b0, y) WV_QSTEP(a0.z, b0, z) WV_QSTEP(a0.w, b0, w)
+            WV_QSTEP(a1.x, b1, x) WV_QSTEP(a1.y, b1, y) WV_QSTEP(a1.z, b1, z) WV_QSTEP(a1.w, b1, w)
+#undef WV_QSTEP
+        }
+        if (!(dbg & 16) && c + 1 < nchunks) commit(smem + ((c + 1) & 1) * Q::STAGE);
+        __syncthreads();
+    }
+}
+
 // XCD-aware tile mapping for K1.  Workgroup ids are dealt round-robin over the 8 XCDs (private
 // L2 each), so ids L, L+8, L+16, ... share an L2.  We enumerate, per XCD, the m-tiles of ONE
 // activation tile back to back: the X window is fetched into that L2 once and reused by all
@@ -387,10 +529,9 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
     epi.begin(p, smem + 2 * T::STAGE, m0, b, to0);
     f32x16 acc[1][T::NT];
     zero_acc<T>(acc);
-    WLoader la{p.pw.wt, p.pw.Mp, m0};
-    RowLoader lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu,
-                 nullptr, 0, false, false};
-    gemm_mainloop<T>(acc, la, lb, p.pw.Kp / BK, smem, p.dbg);
+    RowPairLoader lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
+    gemm_mainloop_q<T>(acc, reinterpret_cast<const f32x4*>(p.pw.wq), p.pw.Mp, m0, lb, p.pw.Kp / BK,
+                       reinterpret_cast<f32x4*>(smem), p.dbg);
     if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.Y[0] = 0.f; return; }
     epi.finish(acc, p);
 }
@@ -1070,7 +1211,7 @@ static int pick_bm(int M) {
 }
 
 hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
-    if (a.ks < 1 || a.stride < 1 || a.dil < 1 || a.pad < 0 || a.pw.Mp % M_ALIGN || a.pw.Kp % BK)
+    if (a.ks < 1 || a.stride < 1 || a.dil < 1 || a.pad < 0 || a.pw.Mp % M_ALIGN || a.pw.Kp % BK || !a.pw.wq)
         return hipErrorInvalidValue;
     const int need = (a.ks - 1) * a.dil + 1;            // H columns one output needs
     bool narrow = (a.Tin + a.pad + 3 <= 64 && need + 3 <= 64) || ((g_debug_flags & 32) && need + 3 <= 64);

@@ -227,6 +227,10 @@ struct Uploader {
         std::vector<float> as_f(hf.size() / 2);
         std::memcpy(as_f.data(), hf.data(), hf.size() * 2);
         p.wh = up(as_f);
+        std::vector<float> q((size_t)p.Kp * p.Mp, 0.f);            // wq[Kp/4][Mp][4]
+        for (int mm = 0; mm < M; ++mm)
+            for (int k = 0; k < K; ++k) q[((size_t)(k / 4) * p.Mp + mm) * 4 + (k & 3)] = w[(size_t)mm * K + k];
+        p.wq = up(q);
         return p;
     }
     PwWeight pw(const std::string& name) {

@@ -39,6 +39,10 @@ struct Tmp {                       // scoped device uploads
         std::vector<float> as_f(hf.size() / 2);
         std::memcpy(as_f.data(), hf.data(), hf.size() * 2);
         p.wh = upv(as_f);
+        std::vector<float> q((size_t)p.Kp * p.Mp, 0.f);            // wq[Kp/4][Mp][4]
+        for (int mm = 0; mm < M; ++mm)
+            for (int k = 0; k < K; ++k) q[((size_t)(k / 4) * p.Mp + mm) * 4 + (k & 3)] = w[(size_t)mm * K + k];
+        p.wq = upv(q);
         return p;
     }
     ~Tmp() { (void)hipDeviceSynchronize(); for (void* p : d) (void)hipFree(p); }
