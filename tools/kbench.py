@@ -30,6 +30,13 @@ def run(C, T, B, M=None, ks=5, stride=1, resid=True, reps=5, flags=0, film=False
     return us, tf, gb, e["kernel"]
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "down":
+        for C, T, r in ((64, 16000, 2), (128, 8000, 4), (256, 2000, 5), (512, 400, 8)):
+            for fl, nm in (((255 << 8) | 64, "warmup"), (255 << 8, "full"), ((255 << 8) | 1, "no-epilogue")):
+                us, tf, gb, k = run(C, T, 256, M=2 * C, ks=2 * r, stride=r, resid=False, flags=fl)
+                if nm != "warmup":
+                    print(f"down C={C:4d}->{2*C:4d} T={T:6d} r={r} {k:22s} {nm:14s} {us:9.1f} us  {tf:6.1f} TF/s {gb:7.1f} GB/s", flush=True)
+        sys.exit(0)
     shapes = [(128, 8000, 256), (64, 16000, 256), (512, 400, 256), (768, 400, 256), (96, 16000, 256)]
     if len(sys.argv) == 4:
         shapes = [tuple(int(v) for v in sys.argv[1:4])]

@@ -368,7 +368,8 @@ template <class T, int KS, int RP_ = 8>
 struct PwDwEpi {
     static constexpr int HLD = T::BN + 4;
     static constexpr int RP = RP_;                            // residual rows in flight per lane
-    static constexpr int FLOATS = T::BM * 8 + T::WM * 4 * HLD;   // LDS floats this epilogue owns
+    static constexpr int WLD = KS ? 8 : 20;                   // per-row table: taps, bias, gamma, beta
+    static constexpr int FLOATS = T::BM * WLD + T::WM * 4 * HLD; // LDS floats this epilogue owns
     int M, m0, b, to0, lane, wave, half, q, o, to;
     bool act_lane, vec;
     const float* Rb; float* Yb; float* Wl; float* Hw;
@@ -399,7 +400,7 @@ struct PwDwEpi {
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         half = lane >> 5; q = lane & 31;
         Wl = epi_smem;
-        Hw = epi_smem + T::BM * 8 + wave * (4 * HLD);
+        Hw = epi_smem + T::BM * WLD + wave * (4 * HLD);
         Yb = p.Y + (size_t)b * M * p.Tout;
         Rb = p.resid ? p.resid + (size_t)b * M * p.Tout : nullptr;
         o = 4 * q; to = to0 + o;
@@ -422,6 +423,19 @@ struct PwDwEpi {
             }
 #pragma unroll
             for (int r = 0; r < RP; ++r) res[r] = load_res(p, r);
+        } else {
+            // generic stencil (strided downsample etc.): taps [0,16), bias 16, FiLM gamma 17, beta 18
+            const int bw = p.film ? (M / p.bands) : 1;
+            const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
+            for (int m = tid; m < T::BM; m += T::NTHREADS) {
+                const int gm = m0 + m;
+                float* row = Wl + m * WLD;
+                for (int i = 0; i < 16; ++i) row[i] = (gm < M && i < p.ks) ? p.dw_w[(size_t)gm * p.ks + i] : 0.f;
+                row[16] = (gm < M && p.dw_b) ? p.dw_b[gm] : 0.f;
+                float gam = 1.f, bet = 0.f;
+                if (filmb && gm < M) { const int band = gm / bw; gam = filmb[2 * band]; bet = filmb[2 * band + 1]; }
+                row[17] = gam; row[18] = bet; row[19] = 0.f;
+            }
         }
     }
 
@@ -464,31 +478,46 @@ struct PwDwEpi {
             }
         } else {
             const int ks = p.ks;
-            const int bw = p.film ? (M / p.bands) : 1;
-            const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
+            const int no = (p.tto + 31) / 32;                 // consecutive outputs per lane
+            const bool pair2 = no == 2 && p.stride == 2 && ks == 4 && p.dil == 1 && (p.off & 1) == 0 &&
+                               (p.Tout & 1) == 0 && (to0 & 1) == 0;   // the r = 2 downsample: 8-byte LDS reads + stores
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float* strip = Hw + (r & 1) * 2 * HLD;
 #pragma unroll
                 for (int j = 0; j < T::NT; ++j) strip[half * HLD + 32 * j + q] = acc[0][j][r];
-                const int gm = m0 + row_of(r);
-                if (gm < M) {
-                    const float* wr = p.dw_w + (size_t)gm * ks;
-                    const float bias = p.dw_b ? p.dw_b[gm] : 0.f;
-                    float gam = 1.f, bet = 0.f;
-                    if (filmb) { const int band = gm / bw; gam = filmb[2 * band]; bet = filmb[2 * band + 1]; }
-                    const float* hrow = strip + half * HLD + p.off;
-                    for (int oo = q; oo < p.tto; oo += 32) {
-                        const int t2 = to0 + oo;
-                        if (t2 >= p.Tout) break;
-                        const float* h = hrow + oo * p.stride;
-                        float y = bias;
-                        for (int i = 0; i < ks; ++i) y = fmaf(wr[i], h[i * p.dil], y);
-                        y = fmaf(y, gam, bet);
-                        if (Rb) y = fmaf(y, p.out_scale, Rb[(size_t)gm * p.Tout + t2]);
-                        if (p.post_elu) y = elu1(y * p.post_scale);
-                        Yb[(size_t)gm * p.Tout + t2] = y;
+                const int row = row_of(r), gm = m0 + row;
+                if (gm >= M) continue;
+                const float* wt = Wl + row * WLD;
+                const float bias = wt[16], gam = wt[17], bet = wt[18];
+                const float* hrow = strip + half * HLD + p.off;
+                float* yrow = Yb + (size_t)gm * p.Tout + to0;
+                const float* rrow = Rb ? Rb + (size_t)gm * p.Tout + to0 : nullptr;
+                if (pair2) {
+                    const int o0 = 2 * q;
+                    if (o0 + 1 < p.tto && to0 + o0 + 1 < p.Tout) {
+                        const f32x2 ha = *reinterpret_cast<const f32x2*>(hrow + 2 * o0);
+                        const f32x2 hb = *reinterpret_cast<const f32x2*>(hrow + 2 * o0 + 2);
+                        const f32x2 hc = *reinterpret_cast<const f32x2*>(hrow + 2 * o0 + 4);
+                        float y0 = fmaf(wt[3], hb.y, fmaf(wt[2], hb.x, fmaf(wt[1], ha.y, fmaf(wt[0], ha.x, bias))));
+                        float y1 = fmaf(wt[3], hc.y, fmaf(wt[2], hc.x, fmaf(wt[1], hb.y, fmaf(wt[0], hb.x, bias))));
+                        y0 = fmaf(y0, gam, bet); y1 = fmaf(y1, gam, bet);
+                        if (rrow) { y0 = fmaf(y0, p.out_scale, rrow[o0]); y1 = fmaf(y1, p.out_scale, rrow[o0 + 1]); }
+                        if (p.post_elu) { y0 = elu1(y0 * p.post_scale); y1 = elu1(y1 * p.post_scale); }
+                        *reinterpret_cast<f32x2*>(yrow + o0) = f32x2{y0, y1};
+                        continue;
                     }
+                }
+                for (int e = 0; e < no; ++e) {
+                    const int oo = q * no + e;
+                    if (oo >= p.tto || to0 + oo >= p.Tout) break;
+                    const float* h = hrow + oo * p.stride;
+                    float y = bias;
+                    for (int i = 0; i < ks; ++i) y = fmaf(wt[i], h[i * p.dil], y);
+                    y = fmaf(y, gam, bet);
+                    if (rrow) y = fmaf(y, p.out_scale, rrow[oo]);
+                    if (p.post_elu) y = elu1(y * p.post_scale);
+                    yrow[oo] = y;
                 }
             }
         }
@@ -1211,7 +1240,7 @@ static int pick_bm(int M) {
 }
 
 hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
-    if (a.ks < 1 || a.stride < 1 || a.dil < 1 || a.pad < 0 || a.pw.Mp % M_ALIGN || a.pw.Kp % BK || !a.pw.wq)
+    if (a.ks < 1 || a.ks > 16 || a.stride < 1 || a.dil < 1 || a.pad < 0 || a.pw.Mp % M_ALIGN || a.pw.Kp % BK || !a.pw.wq)
         return hipErrorInvalidValue;
     const int need = (a.ks - 1) * a.dil + 1;            // H columns one output needs
     bool narrow = (a.Tin + a.pad + 3 <= 64 && need + 3 <= 64) || ((g_debug_flags & 32) && need + 3 <= 64);

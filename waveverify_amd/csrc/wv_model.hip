@@ -605,7 +605,7 @@ int wv_model_create(const wv_config* cfg, wv_model** out) {
     if (cfg->kind < 0 || cfg->kind > 2) return fail(WV_EINVAL, "bad kind");
     if (cfg->n_strides < 1 || cfg->n_strides > WV_MAX_STRIDES) return fail(WV_EINVAL, "bad n_strides");
     for (int i = 0; i < cfg->n_strides; ++i)
-        if (cfg->strides[i] < 1 || 2 * cfg->strides[i] > 64) return fail(WV_EINVAL, "stride out of range (1..32)");
+        if (cfg->strides[i] < 1 || 2 * cfg->strides[i] > 16) return fail(WV_EINVAL, "stride out of range (1..8)");
     if (cfg->channels_enc < 1 || cfg->dimension < 1 || cfg->n_fft_base < 2 || (cfg->n_fft_base & 1))
         return fail(WV_EINVAL, "bad channel / fft sizes");
     if (cfg->embedding_dim > 256 || cfg->freq_bands < 1) return fail(WV_EINVAL, "bad embedding_dim / freq_bands");
