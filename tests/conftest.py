@@ -14,6 +14,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _hip_library():
+    """Make sure libwaveverify_hip.so exists (hipcc cross-compiles gfx950 without a GPU)."""
+    from waveverify_amd.build import build
+    build(force=False, verbose=False)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
