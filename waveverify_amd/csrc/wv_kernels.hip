@@ -813,7 +813,44 @@ __device__ __forceinline__ void dw_pw_body(const DwPwArgs& p, LB& lb, float* sme
         }
         __syncthreads();
     }
-    for (int m = wave; m < T::BM; m += 4) {              // wave-uniform row, time on the lanes
+    // Full, 16-byte aligned tiles: float4 rows, LPR lanes per row, U passes batched so the
+    // read-modify-write of an accumulate layer has U independent loads in flight per lane.
+    if (ncol == T::BN && (p.Tout & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0) {
+        constexpr int LPR = T::BN / 4, RPP = 64 / LPR, RPW = T::BM / 4, NP = RPW / RPP;
+        constexpr int U = NP % 8 == 0 ? 8 : (NP % 4 == 0 ? 4 : (NP % 2 == 0 ? 2 : 1));
+        static_assert(RPW % RPP == 0, "rows per wave");
+        const int sub = lane / LPR, c4 = (lane % LPR) * 4;
+        f32x4 sc{1.f, 1.f, 1.f, 1.f};
+        if (p.l2norm) sc = *reinterpret_cast<const f32x4*>(inv + c4);
+        for (int p0 = 0; p0 < NP; p0 += U) {
+            f32x4 y[U];
+            if (p.accumulate) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int gm = m0 + wave * RPW + (p0 + u) * RPP + sub;
+                    y[u] = gm < M ? *reinterpret_cast<const f32x4*>(Yb + (size_t)gm * p.Tout + t0 + c4)
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = wave * RPW + (p0 + u) * RPP + sub, gm = m0 + row;
+                if (gm >= M) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Hs + row * HLD + c4);
+                if (p.accumulate) {
+                    v.x = fmaf(p.out_scale, v.x, y[u].x); v.y = fmaf(p.out_scale, v.y, y[u].y);
+                    v.z = fmaf(p.out_scale, v.z, y[u].z); v.w = fmaf(p.out_scale, v.w, y[u].w);
+                } else {
+                    const float bias = p.bias ? p.bias[gm] : 0.f;
+                    v.x += bias; v.y += bias; v.z += bias; v.w += bias;
+                }
+                if (p.l2norm) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+                *reinterpret_cast<f32x4*>(Yb + (size_t)gm * p.Tout + t0 + c4) = v;
+            }
+        }
+        return;
+    }
+    for (int m = wave; m < T::BM; m += 4) {              // ragged tiles: wave-uniform row, time on the lanes
         const int gm = m0 + m;
         if (gm >= M) break;
         const float bias = p.bias ? p.bias[gm] : 0.f;
@@ -830,7 +867,7 @@ __device__ __forceinline__ void dw_pw_body(const DwPwArgs& p, LB& lb, float* sme
 }
 
 template <class T, int MODE>
-__global__ __launch_bounds__(NT_) void dw_pw_kernel(DwPwArgs p) {
+__global__ __launch_bounds__(NT_, (MODE == 2 && T::BM * T::BN >= 96 * 128) ? 3 : 1) void dw_pw_kernel(DwPwArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int m0 = blockIdx.x * T::BM;
     const int t0 = blockIdx.y * T::BN;
