@@ -68,7 +68,6 @@ struct PwDwArgs {
                           // 4 skip X loads, 8 skip H spill
     int num_m, num_t;         // tile counts (filled by launch_pw_dw; XCD-aware 1-D grid)
     int stagger, first_gen;   // de-phasing of the first workgroup generation (see kernel)
-    int n_lin;                // persistent kernel: number of linear tile ids (incl. padding ids)
     int tto, off;         // filled by launch_pw_dw: outputs per time tile; stencil offset inside
                           // the 4-aligned H window
 };

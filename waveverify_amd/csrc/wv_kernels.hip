@@ -566,297 +566,6 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
 }
 
 // ------------------------------------------------------------------------------------------
-// K1p: persistent, software-pipelined form of the ResnetBlock unit (k5, stride 1).
-// A workgroup walks tiles L, L+G, L+2G, ... (G = grid size, a multiple of 8, so it stays on its
-// XCD).  While the matrix instructions of tile i run, the SAME wave retires the stencil epilogue
-// of tile i-1 out of a second accumulator set: the epilogue is wave-private (row-strip tile), so
-// this needs no extra barrier, and its LDS / VALU / global-memory instructions sit in the shadow
-// of the 64-cycle MFMAs instead of forming a phase of their own.  The 16 accumulator rows of a
-// lane retire S per chunk during the first 16/S chunks of the next tile; those chunk iterations
-// are unrolled copies of the loop body (static accumulator indices, one basic block with the
-// MFMAs), the remaining chunks run in a plain loop.  Operand prefetch runs across tile
-// boundaries (the first chunk of tile i+1 is fetched during the last chunk of tile i), so there
-// is no per-tile pipeline fill either.  All operand / residual loads are branch-free (clamped
-// address + select) so that s_waitcnt counts stay exact.
-// Requires (launcher): Tin = Tout, Tout % 4 == 0, 16-byte aligned X / Y / resid, Kp/BK >= 16/S.
-// ------------------------------------------------------------------------------------------
-struct RowPairLoaderBF {               // branch-free RowPairLoader for 4-aligned windows
-    const float* base; const float* dummy; int K, ld, ncols; float scale; int elu;
-    const float* p; bool colok;
-    __device__ __forceinline__ void set_tile(const float* b, int c0, int cg) {
-        const int c = c0 + 4 * cg;
-        colok = c >= 0 && c < ncols;                             // groups of 4 are all-in or all-out
-        p = b + (colok ? c : 0);
-    }
-    // raw loads only (no use of the data here: the zero-select happens at commit time, so no
-    // s_waitcnt lands between the loads and the matrix work)
-    __device__ __forceinline__ void fetch2(int k0, f32x4 (&raw)[2]) const {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool ok = colok && k0 + i < K;
-            raw[i] = *reinterpret_cast<const f32x4*>(ok ? p + (size_t)(k0 + i) * ld : dummy);
-        }
-    }
-    __device__ __forceinline__ float xform(float v, bool ok) const { return act(ok ? v : 0.f, scale, elu); }  // act(0) == 0
-};
-
-template <class T, int S>
-__global__ __launch_bounds__(T::NTHREADS, 2) void pw_dw_pipe_kernel(PwDwArgs p) {
-    using Q = QT<T>;
-    static_assert(T::WN == 1 && T::MT == 1, "row-strip tile");
-    static_assert(S == 1 || S == 2 || S == 4, "steps per chunk");
-    constexpr int HLD = T::BN + 4, NT = T::NT, RP = 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* const stage = reinterpret_cast<f32x4*>(smem);
-    float* const Wtab = smem + 2 * T::STAGE;                   // [2][BM][8] per-row taps, bias, FiLM
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* const Hw = Wtab + 2 * T::BM * 8 + wave * (4 * HLD);  // wave-private strips
-    const int half = lane >> 5, q = lane & 31, o = 4 * q;
-    const int o_rd = o < T::BN ? o : 0;                          // lanes past the window read column 0
-    const int M = p.pw.M, K = p.pw.K, Mp = p.pw.Mp, nch = p.pw.Kp / BK;
-    const f32x4* __restrict__ wq = reinterpret_cast<const f32x4*>(p.pw.wq);
-    const unsigned n_lin = (unsigned)p.n_lin, n_act = (unsigned)p.num_t * p.B;
-    const int cg = tid % Q::CG;
-
-    auto decode = [&](unsigned L, int& m0, int& to0, int& b) -> bool {
-        if (L >= n_lin) return false;
-        const unsigned xcd = L & 7, j = L >> 3;
-        const unsigned n_idx = (j / p.num_m) * 8 + xcd;
-        if (n_idx >= n_act) return false;
-        m0 = (int)(j % p.num_m) * T::BM;
-        to0 = (int)(n_idx % p.num_t) * p.tto;
-        b = (int)(n_idx / p.num_t);
-        return true;
-    };
-    auto write_table = [&](int buf, int m0, int b) {
-        const int bw = p.film ? (M / p.bands) : 1;
-        const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
-        float* Wl = Wtab + buf * (T::BM * 8);
-        for (int m = tid; m < T::BM; m += T::NTHREADS) {
-            const int gm = m0 + m;
-            float v[8] = {0, 0, 0, 0, 0, 0, 1.f, 0};
-            if (gm < M) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) v[i] = p.dw_w[(size_t)gm * 5 + i];
-                v[5] = p.dw_b ? p.dw_b[gm] : 0.f;
-                if (filmb) { const int band = gm / bw; v[6] = filmb[2 * band]; v[7] = filmb[2 * band + 1]; }
-            }
-            *reinterpret_cast<float4*>(Wl + m * 8) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(Wl + m * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-    };
-
-    // ---- operand staging (the fetch side may already be on the next tile) ----
-    RowPairLoaderBF lb{p.X, p.X, K, p.Tin, p.Tin, p.pre_scale, p.pre_elu, p.X, false};
-    int m0f = 0;
-    f32x4 ra[Q::A_PER];
-    f32x4 rb[Q::B_PER][2];
-    int kfetch = 0;                                               // first k row of the fetched chunk
-    auto fetch = [&](int c) {
-        kfetch = c * BK;
-#pragma unroll
-        for (int r = 0; r < Q::A_PER; ++r) {
-            const int idx = tid + r * T::NTHREADS;
-            if (Q::NA % T::NTHREADS == 0 || idx < Q::NA)
-                ra[r] = wq[(size_t)(c * Q::KQ + idx / T::BM) * Mp + m0f + idx % T::BM];
-        }
-#pragma unroll
-        for (int r = 0; r < Q::B_PER; ++r) {
-            const int idx = tid + r * T::NTHREADS;
-            if (Q::NBT % T::NTHREADS == 0 || idx < Q::NBT) lb.fetch2(c * BK + (idx / Q::CG) * 2, rb[r]);
-        }
-    };
-    auto commit = [&](f32x4* buf) {
-#pragma unroll
-        for (int r = 0; r < Q::A_PER; ++r) {
-            const int idx = tid + r * T::NTHREADS;
-            if (Q::NA % T::NTHREADS == 0 || idx < Q::NA) buf[idx] = ra[r];
-        }
-        float* Bf = reinterpret_cast<float*>(buf + Q::NA);
-#pragma unroll
-        for (int r = 0; r < Q::B_PER; ++r) {
-            const int idx = tid + r * T::NTHREADS;
-            if (!(Q::NBT % T::NTHREADS == 0 || idx < Q::NBT)) continue;
-            const int kp = idx / Q::CG;
-            const int kq = kp >> 1, kh = kp & 1;
-            const bool ok0 = lb.colok && kfetch + 2 * kp < K, ok1 = lb.colok && kfetch + 2 * kp + 1 < K;
-            const float r0[4] = {rb[r][0].x, rb[r][0].y, rb[r][0].z, rb[r][0].w};
-            const float r1[4] = {rb[r][1].x, rb[r][1].y, rb[r][1].z, rb[r][1].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int slot = q_slot(4 * cg + j);
-                f32x2 v{lb.xform(r0[j], ok0), lb.xform(r1[j], ok1)};
-                *reinterpret_cast<f32x2*>(Bf + ((size_t)(kq * T::BN + slot) * 4 + 2 * kh)) = v;
-            }
-        }
-    };
-    auto set_fetch_tile = [&](int m0, int to0, int b) {
-        m0f = m0;
-        lb.set_tile(p.X + (size_t)b * K * p.Tin, to0 - 4, cg);  // ti0 = to0 - pad (k5: pad 4, off 0)
-    };
-
-    // ---- tiles ----
-    unsigned L = blockIdx.x;
-    int m0c, to0c, bc;
-    if (!decode(L, m0c, to0c, bc)) return;
-    set_fetch_tile(m0c, to0c, bc);
-    int par = 0;
-    write_table(0, m0c, bc);
-    fetch(0);
-    commit(stage);
-    __syncthreads();
-
-    f32x16 acc[NT], accp[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[j][i] = 0.f; accp[j][i] = 0.f; }
-
-    // ---- epilogue-side state (tile i-1) ----
-    bool have_prev = false;
-    int m0p = 0, to_p = 0;
-    bool act_p = false;
-    const float* Rp = p.X;                                       // residual base of the previous tile (or dummy)
-    float* Yp = p.Y;
-    const float* Wlp = Wtab;
-    const bool has_res = p.resid != nullptr;
-    f32x4 res[RP];
-#pragma unroll
-    for (int e = 0; e < RP; ++e) res[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto row_of = [&](int r) { return 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half; };
-    // Branch-free: a lane without a live residual row reads a dummy (valid, aligned) address.
-    auto load_res = [&](int r) -> f32x4 {
-        const int gm = m0p + row_of(r);
-        const bool on = has_res && act_p && gm < M;
-        return *reinterpret_cast<const f32x4*>(on ? Rp + (size_t)gm * p.Tout + to_p : p.X);
-    };
-    // Retire accumulator row r of the previous tile: strip -> stencil -> (+residual); returns y.
-    auto step = [&](auto r_tag) -> f32x4 {
-        constexpr int r = decltype(r_tag)::value;
-        float* strip = Hw + (r & 1) * 2 * HLD;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) strip[half * HLD + 32 * j + q] = accp[j][r];
-        const int row = row_of(r);
-        const f32x4 h0 = *reinterpret_cast<const f32x4*>(strip + half * HLD + o_rd);
-        const f32x4 h1 = *reinterpret_cast<const f32x4*>(strip + half * HLD + o_rd + 4);
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wlp + row * 8);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wlp + row * 8 + 4);
-        const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-        const f32x4 rr = res[r % RP];
-        const float rv[4] = {rr.x, rr.y, rr.z, rr.w};
-        float yy[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v = w1.y;
-            v = fmaf(w0.x, h[t], v); v = fmaf(w0.y, h[t + 1], v); v = fmaf(w0.z, h[t + 2], v);
-            v = fmaf(w0.w, h[t + 3], v); v = fmaf(w1.x, h[t + 4], v);
-            v = fmaf(v, w1.z, w1.w);
-            yy[t] = has_res ? fmaf(v, p.out_scale, rv[t]) : v;
-        }
-        if (r + RP < 16) res[r % RP] = load_res(r + RP);
-        return f32x4{yy[0], yy[1], yy[2], yy[3]};
-    };
-    auto store_row = [&](int r, const f32x4& y) {
-        const int gm = m0p + row_of(r);
-        if (act_p && gm < M) *reinterpret_cast<f32x4*>(Yp + (size_t)gm * p.Tout + to_p) = y;
-    };
-
-    const int h = half, i31 = q;
-    int bslot[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bslot[j] = q_slot(32 * j + i31);
-    auto mfma_chunk = [&](const f32x4* As) {
-        const f32x4* Bs = As + Q::NA;
-        const f32x4 a0 = As[h * T::BM + 32 * wave + i31];
-        const f32x4 a1 = As[(h + 2) * T::BM + 32 * wave + i31];
-        f32x4 b0[NT], b1[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            b0[j] = Bs[h * T::BN + bslot[j]];
-            b1[j] = Bs[(h + 2) * T::BN + bslot[j]];
-        }
-#define WV_QSTEP(AV, BQ, COMP)                                                                     \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                 \
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BQ[j].COMP, acc[j], 0, 0, 0);
-        WV_QSTEP(a0.x, b0, x) WV_QSTEP(a0.y, b0, y) WV_QSTEP(a0.z, b0, z) WV_QSTEP(a0.w, b0, w)
-        WV_QSTEP(a1.x, b1, x) WV_QSTEP(a1.y, b1, y) WV_QSTEP(a1.z, b1, z) WV_QSTEP(a1.w, b1, w)
-#undef WV_QSTEP
-    };
-
-    unsigned g = 0;
-    int m0n = 0, to0n = 0, bn = 0;
-    bool has_next = false;
-    // one chunk iteration; R0 >= 0: it also retires rows R0 .. R0+S-1 of the previous tile
-    auto chunk = [&](auto r0_tag, int c) {
-        constexpr int R0 = decltype(r0_tag)::value;
-        bool do_fetch = true;
-        int kc = c + 1;
-        if (kc == nch) {
-            kc = 0;
-            if (has_next) set_fetch_tile(m0n, to0n, bn);
-            else do_fetch = false;
-        }
-        if (do_fetch) fetch(kc);
-        mfma_chunk(stage + (g & 1) * Q::STAGE);
-        if constexpr (R0 >= 0) {
-            f32x4 y[S];
-            y[0] = step(std::integral_constant<int, R0>{});
-            if constexpr (S >= 2) y[1] = step(std::integral_constant<int, R0 + 1>{});
-            if constexpr (S >= 4) {
-                y[2] = step(std::integral_constant<int, R0 + 2>{});
-                y[3] = step(std::integral_constant<int, R0 + 3>{});
-            }
-#pragma unroll
-            for (int e = 0; e < S; ++e) store_row(R0 + e, y[e]);
-        }
-        if (do_fetch) commit(stage + ((g + 1) & 1) * Q::STAGE);
-        __syncthreads();
-        ++g;
-    };
-#define WV_CH(R) chunk(std::integral_constant<int, (R)>{}, c++);
-    for (;;) {
-        has_next = decode(L + gridDim.x, m0n, to0n, bn);
-        int c = 0;
-        if (have_prev) {
-            if constexpr (S == 1) { WV_CH(0) WV_CH(1) WV_CH(2) WV_CH(3) WV_CH(4) WV_CH(5) WV_CH(6) WV_CH(7)
-                                    WV_CH(8) WV_CH(9) WV_CH(10) WV_CH(11) WV_CH(12) WV_CH(13) WV_CH(14) WV_CH(15) }
-            if constexpr (S == 2) { WV_CH(0) WV_CH(2) WV_CH(4) WV_CH(6) WV_CH(8) WV_CH(10) WV_CH(12) WV_CH(14) }
-            if constexpr (S == 4) { WV_CH(0) WV_CH(4) WV_CH(8) WV_CH(12) }
-        }
-        for (; c < nch; ++c) chunk(std::integral_constant<int, -1>{}, c);
-        // ---- tile boundary: the finished tile becomes the epilogue-side tile ----
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            accp[j] = acc[j];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-        }
-        have_prev = true;
-        m0p = m0c;
-        to_p = to0c + o;
-        act_p = o < p.tto && to_p < p.Tout;
-        Yp = p.Y + (size_t)bc * M * p.Tout;
-        Rp = has_res ? p.resid + (size_t)bc * M * p.Tout : p.X;
-        Wlp = Wtab + par * (T::BM * 8);
-#pragma unroll
-        for (int e = 0; e < RP; ++e) res[e] = load_res(e);
-        if (!has_next) break;
-        L += gridDim.x;
-        m0c = m0n; to0c = to0n; bc = bn;
-        par ^= 1;
-        write_table(par, m0c, bc);
-    }
-#undef WV_CH
-    // ---- drain: epilogue of the last tile ----
-#define WV_ST(R) store_row((R), step(std::integral_constant<int, (R)>{}));
-    WV_ST(0) WV_ST(1) WV_ST(2) WV_ST(3) WV_ST(4) WV_ST(5) WV_ST(6) WV_ST(7)
-    WV_ST(8) WV_ST(9) WV_ST(10) WV_ST(11) WV_ST(12) WV_ST(13) WV_ST(14) WV_ST(15)
-#undef WV_ST
-}
-
-// ------------------------------------------------------------------------------------------
 // Split-f16 GEMM core ("f16x3").  x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 significant
 // bits.  a.b ~= ah.bh + ah.bl + al.bh on v_mfma_f32_32x32x16_f16 (f32 accumulate): three matrix
 // instructions at 16x the f32 matrix rate each = 5.3x the exact-f32 core, with a relative error
@@ -1497,31 +1206,6 @@ static bool pw_dw_geometry(PwDwArgs& a, int BN) {
     return tto >= 1;
 }
 
-// whole float4 outputs per lane, 16-byte aligned tensors, plain k5 stencil (see pw_dw_pipe_kernel)
-static bool pipe_eligible(const PwDwArgs& a) {
-    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    return a.ks == 5 && a.stride == 1 && a.dil == 1 && a.pad == 4 && a.Tin == a.Tout && (a.Tout & 3) == 0 &&
-           !a.post_elu && a.prec == PREC_F32 && al(a.X) && al(a.Y) && (!a.resid || al(a.resid));
-}
-
-template <class T, int S>
-static hipError_t run_pw_dw_pipe(const PwDwArgs& a, long long nblk, hipStream_t s) {
-    const size_t bytes = stage_bytes<T>() + (2 * (size_t)T::BM * 8 + (size_t)T::WM * 4 * (T::BN + 4)) * sizeof(float);
-    static int slots = 0;                                     // resident workgroups on the device
-    if (!slots) {
-        hipError_t e = set_smem(pw_dw_pipe_kernel<T, S>, bytes);
-        if (e != hipSuccess) return e;
-        int n = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pw_dw_pipe_kernel<T, S>, T::NTHREADS, bytes) != hipSuccess || n < 1) n = 1;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        slots = std::max(8, n * cus / 8 * 8);
-    }
-    const unsigned G = (unsigned)std::min<long long>(nblk, slots);
-    hipLaunchKernelGGL((pw_dw_pipe_kernel<T, S>), dim3(G), dim3(T::NTHREADS), bytes, s, a);
-    return hipGetLastError();
-}
-
 template <class T, int KS>
 static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     if (!pw_dw_geometry(a, T::BN)) return hipErrorInvalidValue;
@@ -1571,20 +1255,6 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
         hipLaunchKernelGGL((pw_dw_h_kernel<T, KS>), grid, dim3(T::NTHREADS), hs, s, a);
         return hipGetLastError();
     }
-    // Persistent software-pipelined form (pw_dw_pipe_kernel).  Measured on MI355X it wins where
-    // the unit has few K chunks (short matrix phase, epilogue and pipeline fill dominate): K = 64
-    // on the 64 x 64 tile (-11%) and K = 128 on the 128 x 128 tile (-16%); from K = 256 up the
-    // three-waves-per-SIMD classic kernel is as fast or faster, so those stay on it.
-    if constexpr (KS == 5 && ((T::BM == 64 && T::BN == 64) || (T::BM == 128 && T::BN == 128))) {
-        constexpr int S = T::BM == 64 ? 4 : 2;
-        const int nchunks = a.pw.Kp / BK;
-        if (pipe_eligible(a) && nchunks >= 16 / S && nchunks < 32 / S && !(g_debug_flags & 32)) {
-            a.n_lin = (int)nblk;
-            prof::Scope pp(s, tile_name<T>("pw_dw_k5_pipe").c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
-                           4.0 * Bd * (K * a.Tin + M * a.Tout * (a.resid ? 2.0 : 1.0)));
-            return run_pw_dw_pipe<T, S>(a, nblk, s);
-        }
-    }
     prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
                    4.0 * Bd * (K * a.Tin + M * a.Tout * (a.resid ? 2.0 : 1.0)));
     hipLaunchKernelGGL((pw_dw_kernel<T, KS>), grid, dim3(T::NTHREADS), smem, s, a);
@@ -1610,7 +1280,7 @@ hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
     if (a.ks < 1 || a.ks > 16 || a.stride < 1 || a.dil < 1 || a.pad < 0 || a.pw.Mp % M_ALIGN || a.pw.Kp % BK || !a.pw.wq)
         return hipErrorInvalidValue;
     const int need = (a.ks - 1) * a.dil + 1;            // H columns one output needs
-    bool narrow = (a.Tin + a.pad + 3 <= 64 || (g_debug_flags & 64)) && need + 3 <= 64;
+    bool narrow = a.Tin + a.pad + 3 <= 64 && need + 3 <= 64;
     if (!narrow && need + 3 <= 64) {
         // pick the window width that computes the fewest columns for this Tout (tile quantisation:
         // e.g. Tout = 400 needs 4 x 128 columns with 124-output tiles but only 7 x 64 with 60-output ones)
@@ -1622,8 +1292,6 @@ hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
         }
     }
     const int bm = pick_bm(a.pw.M);
-    // K = 64 units run the persistent pipelined kernel, which lives on the 64 x 64 tile
-    if (bm == 64 && a.pw.Kp / BK >= 4 && a.pw.Kp / BK < 8 && pipe_eligible(a) && !(g_debug_flags & 32)) narrow = true;
     // split-f16 core: only where the layer is matrix-bound (K >= 256) and only on the 128 x 64 tile
     if (a.prec == PREC_F16X3 && a.pw.wh && a.pw.K >= 256 && bm == 128 && need + 3 <= 64) narrow = true;
     if (narrow) {
