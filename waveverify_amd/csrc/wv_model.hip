@@ -45,6 +45,7 @@ struct ResBlock {
 struct SpecLayer {
     const float* basis_t; int n_fft, hop, F, Mp; float mean, inv_std;
     PwWeight pw; float scale;
+    const float* id_taps;      // [C][5] = (0,0,0,0,1): the spec add runs on K1 with an identity stencil
 };
 struct DownLayer { PwWeight pw; const float *dw_w, *dw_b; int ratio; float pre_scale; };
 struct UpLayer {
@@ -319,6 +320,11 @@ int pack_model(wv_model* m) {
         (void)mi;
         sp.pw = U.pw(pre + ".layer.conv.conv.weight");
         sp.scale = U.scalar_or(pre + ".scale_param", 1.f) * rs;            // seanet.py:500-502
+        {
+            std::vector<float> taps((size_t)sp.pw.M * 5, 0.f);
+            for (int mm = 0; mm < sp.pw.M; ++mm) taps[(size_t)mm * 5 + 4] = 1.f;
+            sp.id_taps = U.up(taps);
+        }
         m->specs.push_back(sp);
         if (!post) {
             DownLayer d{};
@@ -528,10 +534,22 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         sa.mean = sp.mean; sa.inv_std = sp.inv_std;
         if (sa.Tf != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");
         LAUNCH(wv::launch_stft_logmag(sa, st));
-        wv::DwPwArgs acc{};                                                 // x += scale * W @ P
-        acc.X = P; acc.pw = sp.pw; acc.Y = bf.a; acc.B = B; acc.Tin = Tl; acc.Tout = Tl; acc.mode = 0;
-        acc.pre_scale = 1.f; acc.pre_elu = 0; acc.accumulate = 1; acc.out_scale = sp.scale;
-        LAUNCH(wv::launch_dw_pw(acc, st));
+        // x += scale * (W @ P)  (seanet.py:500-502).  Runs on K1's k-inner core with an identity
+        // stencil (taps 0,0,0,0,1 are exact: fmaf(0,h,0) = 0, fmaf(1,h,0) = h) and x as the
+        // residual operand, written in place: every element is read and then written by the
+        // same lane, and the halo columns of a tile are only ever read from P.
+        if (sp.pw.M < 128) {                  // small layers: the plain 1x1 kernel streams better
+            wv::DwPwArgs k2{};
+            k2.X = P; k2.pw = sp.pw; k2.Y = bf.a; k2.B = B; k2.Tin = Tl; k2.Tout = Tl; k2.mode = 0;
+            k2.pre_scale = 1.f; k2.pre_elu = 0; k2.accumulate = 1; k2.out_scale = sp.scale;
+            LAUNCH(wv::launch_dw_pw(k2, st));
+        } else {
+        wv::PwDwArgs acc{};
+        acc.X = P; acc.pw = sp.pw; acc.dw_w = sp.id_taps; acc.dw_b = nullptr; acc.resid = bf.a; acc.Y = bf.a;
+        acc.B = B; acc.Tin = Tl; acc.Tout = Tl; acc.ks = 5; acc.stride = 1; acc.dil = 1; acc.pad = 4;
+        acc.pre_scale = 1.f; acc.pre_elu = 0; acc.out_scale = sp.scale; acc.bands = 1; acc.prec = wv::PREC_F32;
+        LAUNCH(wv::launch_pw_dw(acc, st));
+        }
         if (post) break;
         const DownLayer& d = m->downs[s];
         wv::prof::set_role(film ? "enc.down_film" : "enc.down");
