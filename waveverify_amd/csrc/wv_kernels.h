@@ -70,17 +70,27 @@ struct PwDwArgs {
     int stagger, first_gen;   // de-phasing of the first workgroup generation (see kernel)
     int tto, off;         // filled by launch_pw_dw: outputs per time tile; stencil offset inside
                           // the 4-aligned H window
+    const float* ct_w;    // upsample unit only: DW ConvTranspose taps [K, 2*ratio] and ratio; X is then
+    int ratio;            //   [B, K, Tin], Tout = Tin*ratio
+    const float* ct_wt;   // the same taps transposed and zero padded, [2*ratio][pw.Kp] (pack_ct_wt)
 };
 hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s);
+// host: ConvTranspose taps [K][2r] -> [2r][Kp], zero padded
+inline std::vector<float> pack_ct_wt(const float* w, int K, int Kp, int ratio) {
+    std::vector<float> t((size_t)2 * ratio * Kp, 0.f);
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < 2 * ratio; ++i) t[(size_t)i * Kp + k] = w[(size_t)k * 2 * ratio + i];
+    return t;
+}
 
-// ---- K2: (identity | DW conv | DW conv-transpose) producer -> 1x1 GEMM -> epilogue ---------
+// ---- K2: (identity | DW conv) producer -> 1x1 GEMM -> epilogue --------------------------------
 struct DwPwArgs {
     const float* X;       // [B, K, Tin]
-    const float* dw_w;    // mode 1: [K, ks]; mode 2: [K, 2r]; mode 0: unused
+    const float* dw_w;    // mode 1: [K, ks]; mode 0: unused
     PwWeight pw;
     const float* bias;    // [M] or null
     float* Y;             // [B, M, Tout]
-    int B, Tin, Tout, mode, ks, ratio;
+    int B, Tin, Tout, mode, ks;
     float pre_scale;
     int pre_elu;
     int l2norm;           // normalise over channels * sqrt(M) (needs M <= 128)

@@ -264,6 +264,99 @@ struct RowPairLoader {
         }
     }
     __device__ __forceinline__ float xform(float v) const { return act(v, scale, elu); }
+    static constexpr int NRAW = 8;
+    // raw 2(k) x 4(t) micro-tile -> staged values o[4*i + j] = B[k0+i][t+j]
+    __device__ __forceinline__ void finish2(int, const float (&raw)[8], float (&o)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = xform(raw[i]);
+    }
+};
+
+// B operand of the upsample unit for the k-inner core: act(s*x) -> depth-wise ConvTranspose1d(2r, r),
+// right-trimmed (modules/conv.py SConvTranspose1d causal trim), produced on the fly:
+//   B[k][t] = a(x[k][l]) * w[k][ph] + a(x[k][l-1]) * w[k][ph + r],   l = t / r, ph = t % r.
+// A thread owns 2 channels x 4 consecutive output times t (t0 a multiple of 4).  RM picks the
+// addressing: RM = 4 (r % 4 == 0): the four times share l and their taps are one aligned float4
+// pair -> 2 scalar + 2 vector loads and 2 activations per channel;  RM = 2 (r == 2): three inputs
+// and one float4 of taps;  RM = 0: any ratio, per-time scalar gathers.  Loads go to clamped
+// (always valid) addresses and the zero-selects happen in finish2, at commit time, so that no
+// s_waitcnt sits between issuing the loads and the matrix work.
+template <int RM>
+struct ConvTrPair {
+    static constexpr int NRAW = RM == 4 ? 20 : (RM == 2 ? 14 : (RM == 1 ? 14 : 22));
+    const float* Xb; const float* ct_w; const float* ct_wt; int K, Kt, Tin, Tout, c0, ratio; float scale; int elu;
+    int t, l0, ph[4], dl[4];
+    __device__ __forceinline__ void init(int cg) {
+        t = c0 + 4 * cg;                                          // first output time of the micro-tile
+        l0 = min(max(t, 0) / ratio, Tin - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int te = max(t + e, 0), le = te / ratio;
+            ph[e] = te - le * ratio;
+            dl[e] = min(le, Tin - 1) - l0;                         // 0 or 1 for ratio >= 2
+        }
+    }
+    __device__ __forceinline__ void fetch2(int k0, float (&raw)[NRAW]) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = min(k0 + i, K - 1);
+            const float* xr = Xb + (size_t)k * Tin;
+            const float* w = ct_w + (size_t)k * 2 * ratio;
+            float* r = raw + i * (NRAW / 2);
+            if (RM == 4) {                                         // one input pair, aligned tap vectors
+                r[0] = xr[l0]; r[1] = xr[max(l0 - 1, 0)];
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + ph[0]);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + ph[0] + ratio);
+                r[2] = w0.x; r[3] = w0.y; r[4] = w0.z; r[5] = w0.w;
+                r[6] = w1.x; r[7] = w1.y; r[8] = w1.z; r[9] = w1.w;
+            } else if (RM == 2) {                                  // inputs l0-1, l0, l0+1; w = (w0[0], w0[1], w1[0], w1[1])
+                r[0] = xr[max(l0 - 1, 0)]; r[1] = xr[l0]; r[2] = xr[min(l0 + 1, Tin - 1)];
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w);
+                r[3] = wv.x; r[4] = wv.y; r[5] = wv.z; r[6] = wv.w;
+            } else if (RM == 1) {                                  // ratio 1: five inputs, two taps
+#pragma unroll
+                for (int e = 0; e < 5; ++e) r[e] = xr[min(max(l0 - 1 + e, 0), Tin - 1)];
+                r[5] = w[0]; r[6] = w[1];
+            } else {                                               // any ratio >= 2: three inputs, per-time taps
+                r[0] = xr[max(l0 - 1, 0)]; r[1] = xr[l0]; r[2] = xr[min(l0 + 1, Tin - 1)];
+            }
+        }
+        if (RM == 0) {
+            // taps from the transposed copy ct_wt[2r][Kt] (channels contiguous): the two channel rows
+            // of a (tap, time) pair are one 8-byte load (k0 is even, Kt is even)
+            const int k = min(k0, Kt - 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 a = *reinterpret_cast<const f32x2*>(ct_wt + (size_t)ph[e] * Kt + k);
+                const f32x2 b = *reinterpret_cast<const f32x2*>(ct_wt + (size_t)(ph[e] + ratio) * Kt + k);
+                raw[3 + e] = a.x; raw[NRAW / 2 + 3 + e] = a.y;
+                raw[7 + e] = b.x; raw[NRAW / 2 + 7 + e] = b.y;
+            }
+        }
+    }
+    __device__ __forceinline__ void finish2(int k0, const float (&raw)[NRAW], float (&o)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool kv = k0 + i < K;
+            const float* r = raw + i * (NRAW / 2);
+            float a[5];                                            // activated inputs (each computed once)
+            constexpr int NX = RM == 4 ? 2 : (RM == 1 ? 5 : 3);
+#pragma unroll
+            for (int e = 0; e < NX; ++e) a[e] = act(r[e], scale, elu);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int te = t + e;
+                const bool ok = kv && te >= 0 && te < Tout;
+                float xa, xb, w0, w1;
+                if (RM == 4) { xa = a[0]; xb = a[1]; w0 = r[2 + e]; w1 = r[6 + e]; }
+                else if (RM == 2) { xa = a[1 + (e >> 1)]; xb = a[e >> 1]; w0 = r[3 + (e & 1)]; w1 = r[5 + (e & 1)]; }
+                else if (RM == 1) { xa = a[1 + e]; xb = a[e]; w0 = r[5]; w1 = r[6]; }
+                else { xa = dl[e] ? a[2] : a[1]; xb = dl[e] ? a[1] : a[0]; w0 = r[3 + e]; w1 = r[7 + e]; }
+                const float v = fmaf(te >= ratio ? xb : 0.f, w1, xa * w0);
+                o[4 * i + e] = ok ? v : 0.f;
+            }
+        }
+    }
 };
 
 template <class T, class LB>
@@ -275,7 +368,7 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cg = tid % Q::CG;
     f32x4 ra[Q::A_PER];
-    float rb[Q::B_PER][8];
+    float rb[Q::B_PER][LB::NRAW];
     lb.init(cg);
 
     auto fetch = [&](int c) {
@@ -291,7 +384,7 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
             if (Q::NBT % T::NTHREADS == 0 || idx < Q::NBT) lb.fetch2(c * BK + (idx / Q::CG) * 2, rb[r]);
         }
     };
-    auto commit = [&](f32x4* buf) {
+    auto commit = [&](int c, f32x4* buf) {
 #pragma unroll
         for (int r = 0; r < Q::A_PER; ++r) {
             const int idx = tid + r * T::NTHREADS;
@@ -304,10 +397,12 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
             if (!(Q::NBT % T::NTHREADS == 0 || idx < Q::NBT)) continue;
             const int kp = idx / Q::CG;                       // k rows 2kp, 2kp+1 of the chunk
             const int kq = kp >> 1, kh = kp & 1;
+            float o[8];
+            lb.finish2(c * BK + 2 * kp, rb[r], o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int slot = q_slot(4 * cg + j);
-                f32x2 v{lb.xform(rb[r][j]), lb.xform(rb[r][4 + j])};
+                f32x2 v{o[j], o[4 + j]};
                 *reinterpret_cast<f32x2*>(Bf + ((size_t)(kq * T::BN + slot) * 4 + 2 * kh)) = v;
             }
         }
@@ -317,7 +412,7 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
 #pragma unroll
     for (int j = 0; j < T::NT; ++j) bslot[j] = q_slot(32 * j + i31);
     fetch(0);
-    commit(smem);
+    commit(0, smem);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const f32x4* As = smem + (c & 1) * Q::STAGE;
@@ -339,7 +434,7 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
             WV_QSTEP(a1.x, b1, x) WV_QSTEP(a1.y, b1, y) WV_QSTEP(a1.z, b1, z) WV_QSTEP(a1.w, b1, w)
 #undef WV_QSTEP
         }
-        if (!(dbg & 16) && c + 1 < nchunks) commit(smem + ((c + 1) & 1) * Q::STAGE);
+        if (!(dbg & 16) && c + 1 < nchunks) commit(c + 1, smem + ((c + 1) & 1) * Q::STAGE);
         __syncthreads();
     }
 }
@@ -369,11 +464,12 @@ struct PwDwEpi {
     static constexpr int HLD = T::BN + 4;
     static constexpr int RP = RP_;                            // residual rows in flight per lane
     static constexpr int WLD = KS ? 8 : 20;                   // per-row table: taps, bias, gamma, beta
-    static constexpr int FLOATS = T::BM * WLD + T::WM * 4 * HLD; // LDS floats this epilogue owns
+    static constexpr int FLOATS = T::BM * WLD;                // LDS floats this epilogue owns (the row table)
+    static constexpr int STRIP_FLOATS = T::WM * 4 * HLD;      // wave-private strips: alias the GEMM stages
     int M, m0, b, to0, lane, wave, half, q, o, to;
     bool act_lane, vec;
     const float* Rb; float* Yb; float* Wl; float* Hw;
-    float4 res[RP];
+    float4 res[RP ? RP : 1];                                  // RP == 0: a unit without residual operand
 
     __device__ __forceinline__ int row_of(int r) const { return 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half; }
     __device__ __forceinline__ float4 load_res(const PwDwArgs& p, int r) const {
@@ -393,14 +489,16 @@ struct PwDwEpi {
     }
     // epi_smem: FLOATS floats not aliased with the GEMM stages.  A workgroup barrier must follow
     // before finish() (the GEMM main loop has several).
-    __device__ __forceinline__ void begin(const PwDwArgs& p, float* epi_smem, int m0_, int b_, int to0_) {
+    // strip_smem may alias the GEMM stage buffers: it is only touched in finish(), and both main
+    // loops end with a workgroup barrier after their last LDS read.
+    __device__ __forceinline__ void begin(const PwDwArgs& p, float* epi_smem, float* strip_smem, int m0_, int b_, int to0_) {
         M = p.pw.M; m0 = m0_; b = b_; to0 = to0_;
         const int tid = threadIdx.x;
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         half = lane >> 5; q = lane & 31;
         Wl = epi_smem;
-        Hw = epi_smem + T::BM * WLD + wave * (4 * HLD);
+        Hw = strip_smem + wave * (4 * HLD);
         Yb = p.Y + (size_t)b * M * p.Tout;
         Rb = p.resid ? p.resid + (size_t)b * M * p.Tout : nullptr;
         o = 4 * q; to = to0 + o;
@@ -421,8 +519,10 @@ struct PwDwEpi {
                 *reinterpret_cast<float4*>(Wl + m * 8) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(Wl + m * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
+            if constexpr (RP > 0) {
 #pragma unroll
-            for (int r = 0; r < RP; ++r) res[r] = load_res(p, r);
+                for (int r = 0; r < RP; ++r) res[r] = load_res(p, r);
+            }
         } else {
             // generic stencil (strided downsample etc.): taps [0,16), bias 16, FiLM gamma 17, beta 18
             const int bw = p.film ? (M / p.bands) : 1;
@@ -447,8 +547,11 @@ struct PwDwEpi {
 #pragma unroll
                 for (int j = 0; j < T::NT; ++j) strip[half * HLD + 32 * j + q] = acc[0][j][r];
                 const int row = row_of(r), gm = m0 + row;
-                const float4 rr = res[r % RP];
-                if (r + RP < 16) res[r % RP] = load_res(p, r + RP);
+                float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (RP > 0) {
+                    rr = res[r % RP];
+                    if (r + RP < 16) res[r % RP] = load_res(p, r + RP);
+                }
                 if (act_lane && gm < M) {
                     const float4 h0 = *reinterpret_cast<const float4*>(strip + half * HLD + o);
                     const float4 h1 = *reinterpret_cast<const float4*>(strip + half * HLD + o + 4);
@@ -463,7 +566,7 @@ struct PwDwEpi {
                         v = fmaf(w0.x, h[e], v); v = fmaf(w0.y, h[e + 1], v); v = fmaf(w0.z, h[e + 2], v);
                         v = fmaf(w0.w, h[e + 3], v); v = fmaf(w1.x, h[e + 4], v);
                         v = fmaf(v, w1.z, w1.w);                                 // FiLM (1, 0 when off)
-                        if (Rb) v = fmaf(v, p.out_scale, rv[e]);
+                        if (RP > 0 && Rb) v = fmaf(v, p.out_scale, rv[e]);
                         if (p.post_elu) v = elu1(v * p.post_scale);
                         y[e] = v;
                     }
@@ -524,7 +627,12 @@ struct PwDwEpi {
     }
 };
 
-template <class T, int KS>
+// RM < 0: the B operand is act(s*X) (ResnetBlock / downsample / spec add).  RM >= 0: the upsample
+// unit -- B is the depth-wise ConvTranspose of act(s*X) built by ConvTrPair<RM>, the stencil is the
+// identity (taps 0,0,0,0,1, exact) and the "DW bias" is the 1x1 bias.
+// RES = false: instantiation for units without a residual operand (first half of a ResnetBlock): it
+// does not carry the residual-prefetch registers.
+template <class T, int KS, int RM = -1, bool RES = true>
 __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ? 3 : 2) void pw_dw_kernel(PwDwArgs p) {
     // Row-strip tile: WN == 1, every wave owns 32 channel rows x the whole BN-column window, so
     // the depth-wise stencil never crosses a wave: accumulators are spilled two rows at a time
@@ -554,13 +662,20 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
             for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
         }
     }
-    PwDwEpi<T, KS> epi;
-    epi.begin(p, smem + 2 * T::STAGE, m0, b, to0);
+    PwDwEpi<T, KS, (RM < 0 && RES) ? 8 : 0> epi;              // the upsample unit has no residual operand
+    epi.begin(p, smem + 2 * T::STAGE, smem, m0, b, to0);
+    static_assert(PwDwEpi<T, KS>::STRIP_FLOATS <= 2 * T::STAGE, "strips alias the stages");
     f32x16 acc[1][T::NT];
     zero_acc<T>(acc);
-    RowPairLoader lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
-    gemm_mainloop_q<T>(acc, reinterpret_cast<const f32x4*>(p.pw.wq), p.pw.Mp, m0, lb, p.pw.Kp / BK,
-                       reinterpret_cast<f32x4*>(smem), p.dbg);
+    if constexpr (RM < 0) {
+        RowPairLoader lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
+        gemm_mainloop_q<T>(acc, reinterpret_cast<const f32x4*>(p.pw.wq), p.pw.Mp, m0, lb, p.pw.Kp / BK,
+                           reinterpret_cast<f32x4*>(smem), p.dbg);
+    } else {
+        ConvTrPair<RM> lb{p.X + (size_t)b * K * p.Tin, p.ct_w, p.ct_wt, K, p.pw.Kp, p.Tin, p.Tout, ti0, p.ratio, p.pre_scale, p.pre_elu, 0, 0, {}, {}};
+        gemm_mainloop_q<T>(acc, reinterpret_cast<const f32x4*>(p.pw.wq), p.pw.Mp, m0, lb, p.pw.Kp / BK,
+                           reinterpret_cast<f32x4*>(smem), p.dbg);
+    }
     if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.Y[0] = 0.f; return; }
     epi.finish(acc, p);
 }
@@ -713,7 +828,8 @@ __global__ __launch_bounds__(T::NTHREADS, 2) void pw_dw_h_kernel(PwDwArgs p) {
     const int to0 = tile.t_tile * p.tto;
     const int ti0 = to0 * p.stride - p.pad - p.off;
     PwDwEpi<T, KS, 2> epi;
-    epi.begin(p, smem + 2 * HT<T>::STAGE * 4, m0, b, to0);
+    epi.begin(p, smem + 2 * HT<T>::STAGE * 4, smem, m0, b, to0);
+    static_assert(PwDwEpi<T, KS>::STRIP_FLOATS <= 2 * HT<T>::STAGE * 4, "strips alias the stages");
     f32x16 acc[1][T::NT];
     zero_acc<T>(acc);
     ColLoaderH lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu};
@@ -724,7 +840,8 @@ __global__ __launch_bounds__(T::NTHREADS, 2) void pw_dw_h_kernel(PwDwArgs p) {
 
 // ------------------------------------------------------------------------------------------
 // K2  dw_pw:  Y = epi( W @ producer(X) + b ), producer fused into the B-operand loader.
-//   MODE 0: act(s*X)   MODE 1: causal DW conv k of act(s*X)   MODE 2: DW ConvTranspose(2r, r)
+//   MODE 0: act(s*X)   MODE 1: causal DW conv k of act(s*X)
+// (the upsample unit -- DW ConvTranspose producer -- runs on the K1 kernel, see ConvTrPair)
 // ------------------------------------------------------------------------------------------
 struct ConvLoader {                    // MODE 1 (conv_post only: tiny layer, computed at commit)
     static constexpr int NRAW = 1;
@@ -745,39 +862,6 @@ struct ConvLoader {                    // MODE 1 (conv_post only: tiny layer, co
             }
             o[c] = v;
         }
-    }
-};
-
-struct ConvTrLoader {                  // MODE 2: polyphase depth-wise ConvTranspose, right-trimmed
-    static constexpr int NRAW = 4;     // x[l], x[l-1], w[ph], w[ph+r] per column
-    const float* Xb; const float* dw_w; int K, Tin, Tout, t0, ratio; float scale; int elu;
-    int l[4], ph[4]; bool inb[4];
-    __device__ __forceinline__ void init(int col4) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int t = t0 + col4 + c;
-            inb[c] = t < Tout;
-            l[c] = t / ratio; ph[c] = t - l[c] * ratio;
-        }
-    }
-    __device__ __forceinline__ void fetch(int k, float (&raw)[16]) const {
-        const bool kv = k < K;
-        const float* xr = Xb + (size_t)(kv ? k : 0) * Tin;
-        const float* w = dw_w + (size_t)(kv ? k : 0) * 2 * ratio;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const bool v = kv && inb[c];
-            raw[4 * c + 0] = v ? xr[l[c]] : 0.f;
-            raw[4 * c + 1] = (v && l[c] >= 1) ? xr[l[c] - 1] : 0.f;
-            raw[4 * c + 2] = v ? w[ph[c]] : 0.f;
-            raw[4 * c + 3] = v ? w[ph[c] + ratio] : 0.f;
-        }
-    }
-    __device__ __forceinline__ void finish(int, const float (&raw)[16], float (&o)[4]) const {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            o[c] = fmaf(act(raw[4 * c + 1], scale, elu), raw[4 * c + 3],
-                        act(raw[4 * c], scale, elu) * raw[4 * c + 2]);
     }
 };
 
@@ -867,7 +951,7 @@ __device__ __forceinline__ void dw_pw_body(const DwPwArgs& p, LB& lb, float* sme
 }
 
 template <class T, int MODE>
-__global__ __launch_bounds__(NT_, (MODE == 2 && T::BM * T::BN >= 96 * 128) ? 3 : 1) void dw_pw_kernel(DwPwArgs p) {
+__global__ __launch_bounds__(NT_) void dw_pw_kernel(DwPwArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int m0 = blockIdx.x * T::BM;
     const int t0 = blockIdx.y * T::BN;
@@ -877,11 +961,8 @@ __global__ __launch_bounds__(NT_, (MODE == 2 && T::BM * T::BN >= 96 * 128) ? 3 :
     if (MODE == 0) {
         RowLoader lb{Xb, K, p.Tin, p.Tin, t0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
         dw_pw_body<T>(p, lb, smem, m0, t0, b);
-    } else if (MODE == 1) {
-        ConvLoader lb{Xb, p.dw_w, K, p.Tin, t0, p.ks, p.pre_scale, p.pre_elu, 0};
-        dw_pw_body<T>(p, lb, smem, m0, t0, b);
     } else {
-        ConvTrLoader lb{Xb, p.dw_w, K, p.Tin, p.Tout, t0, p.ratio, p.pre_scale, p.pre_elu, {}, {}, {}};
+        ConvLoader lb{Xb, p.dw_w, K, p.Tin, t0, p.ks, p.pre_scale, p.pre_elu, 0};
         dw_pw_body<T>(p, lb, smem, m0, t0, b);
     }
 }
@@ -1240,7 +1321,7 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
     // the split-f16 core pays off for the 4-wave (BM = 128) tiles; smaller tiles (C <= 96 layers,
     // HBM-bound anyway) stay on the f32 core
-    if constexpr (T::NTHREADS == 256 && T::BN == 64) if (a.prec == PREC_F16X3 && a.pw.wh && a.pw.K >= 256) {
+    if constexpr (T::NTHREADS == 256 && T::BN == 64) if (a.prec == PREC_F16X3 && a.pw.wh && a.pw.K >= 256 && !a.ct_w) {
         const size_t hs = 2 * (size_t)HT<T>::STAGE * 16 + eb;
         static bool attr_done = false;
         if (!attr_done) {
@@ -1255,8 +1336,37 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
         hipLaunchKernelGGL((pw_dw_h_kernel<T, KS>), grid, dim3(T::NTHREADS), hs, s, a);
         return hipGetLastError();
     }
+    if constexpr (KS == 5) if (a.ct_w) {
+        // upsample unit: ConvTranspose producer in the B loader, identity stencil (see pw_dw_kernel)
+        static const std::string cname = tile_name<T>("convtr_pw");
+        prof::Scope pc(s, cname.c_str(), 2.0 * Bd * a.Tout * K * (M + 2.0), 4.0 * Bd * (K * a.Tin + M * a.Tout));
+        static bool attr_ct = false;
+        if (!attr_ct) {
+            hipError_t e = set_smem(pw_dw_kernel<T, 5, 4>, smem);
+            if (e == hipSuccess) e = set_smem(pw_dw_kernel<T, 5, 2>, smem);
+            if (e == hipSuccess) e = set_smem(pw_dw_kernel<T, 5, 1>, smem);
+            if (e == hipSuccess) e = set_smem(pw_dw_kernel<T, 5, 0>, smem);
+            if (e != hipSuccess) return e;
+            attr_ct = true;
+        }
+        if (a.ratio % 4 == 0) hipLaunchKernelGGL((pw_dw_kernel<T, 5, 4>), grid, dim3(T::NTHREADS), smem, s, a);
+        else if (a.ratio == 2) hipLaunchKernelGGL((pw_dw_kernel<T, 5, 2>), grid, dim3(T::NTHREADS), smem, s, a);
+        else if (a.ratio == 1) hipLaunchKernelGGL((pw_dw_kernel<T, 5, 1>), grid, dim3(T::NTHREADS), smem, s, a);
+        else hipLaunchKernelGGL((pw_dw_kernel<T, 5, 0>), grid, dim3(T::NTHREADS), smem, s, a);
+        return hipGetLastError();
+    }
     prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
                    4.0 * Bd * (K * a.Tin + M * a.Tout * (a.resid ? 2.0 : 1.0)));
+    if constexpr (KS == 5) if (!a.resid) {
+        static bool attr_nr = false;
+        if (!attr_nr) {
+            hipError_t e = set_smem(pw_dw_kernel<T, 5, -1, false>, smem);
+            if (e != hipSuccess) return e;
+            attr_nr = true;
+        }
+        hipLaunchKernelGGL((pw_dw_kernel<T, 5, -1, false>), grid, dim3(T::NTHREADS), smem, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((pw_dw_kernel<T, KS>), grid, dim3(T::NTHREADS), smem, s, a);
     return hipGetLastError();
 }
@@ -1277,6 +1387,9 @@ static int pick_bm(int M) {
 }
 
 hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
+    if (a.ct_w && (!a.ct_wt || (reinterpret_cast<uintptr_t>(a.ct_wt) & 7) || a.ratio < 1 || a.Tout != a.Tin * a.ratio || a.ks != 5 || a.stride != 1 || a.dil != 1 || a.pad != 4 ||
+                   (reinterpret_cast<uintptr_t>(a.ct_w) & 15)))
+        return hipErrorInvalidValue;
     if (a.ks < 1 || a.ks > 16 || a.stride < 1 || a.dil < 1 || a.pad < 0 || a.pw.Mp % M_ALIGN || a.pw.Kp % BK || !a.pw.wq)
         return hipErrorInvalidValue;
     const int need = (a.ks - 1) * a.dil + 1;            // H columns one output needs
@@ -1293,7 +1406,7 @@ hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
     }
     const int bm = pick_bm(a.pw.M);
     // split-f16 core: only where the layer is matrix-bound (K >= 256) and only on the 128 x 64 tile
-    if (a.prec == PREC_F16X3 && a.pw.wh && a.pw.K >= 256 && bm == 128 && need + 3 <= 64) narrow = true;
+    if (a.prec == PREC_F16X3 && a.pw.wh && a.pw.K >= 256 && bm == 128 && need + 3 <= 64 && !a.ct_w) narrow = true;
     if (narrow) {
         switch (bm) {
             case 32: return run_pw_dw<Tile<32, 64, 1, 1>>(a, s);
@@ -1323,9 +1436,9 @@ static hipError_t run_dw_pw_mode(const DwPwArgs& a, hipStream_t s) {
     }
     if (a.l2norm && a.pw.M > T::BM) return hipErrorInvalidValue;
     dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + T::BN - 1) / T::BN, a.B);
-    static const std::string name = tile_name<T>(MODE == 0 ? "pw" : (MODE == 1 ? "dwconv_pw" : "convtr_pw"));
+    static const std::string name = tile_name<T>(MODE == 0 ? "pw" : "dwconv_pw");
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
-    const double stencil = a.mode == 1 ? 2.0 * a.ks : (a.mode == 2 ? 4.0 : 0.0);
+    const double stencil = a.mode == 1 ? 2.0 * a.ks : 0.0;
     prof::Scope ps(s, name.c_str(), Bd * a.Tout * (2.0 * M * K + stencil * K),
                    4.0 * Bd * (K * a.Tin + M * a.Tout * (a.accumulate ? 2.0 : 1.0)));
     hipLaunchKernelGGL((dw_pw_kernel<T, MODE>), grid, dim3(NT_), smem, s, a);
@@ -1335,14 +1448,11 @@ static hipError_t run_dw_pw_mode(const DwPwArgs& a, hipStream_t s) {
 template <class T>
 static hipError_t run_dw_pw(const DwPwArgs& a, hipStream_t s) {
     if (a.mode == 0) return run_dw_pw_mode<T, 0>(a, s);
-    if (a.mode == 1) return run_dw_pw_mode<T, 1>(a, s);
-    return run_dw_pw_mode<T, 2>(a, s);
+    return run_dw_pw_mode<T, 1>(a, s);
 }
 
 hipError_t launch_dw_pw(const DwPwArgs& a, hipStream_t s) {
-    if (a.pw.Mp % M_ALIGN || a.pw.Kp % BK || a.mode < 0 || a.mode > 2) return hipErrorInvalidValue;
-    if (a.mode == 2 && (a.Tout != a.Tin * a.ratio || a.ratio < 1)) return hipErrorInvalidValue;
-    if (a.mode != 2 && a.Tout != a.Tin) return hipErrorInvalidValue;
+    if (a.pw.Mp % M_ALIGN || a.pw.Kp % BK || a.mode < 0 || a.mode > 1 || a.Tout != a.Tin) return hipErrorInvalidValue;
     int bm = pick_bm(a.pw.M);
     if (a.l2norm) bm = a.pw.M <= 64 ? 64 : 128;
     if (a.Tout <= 64) {

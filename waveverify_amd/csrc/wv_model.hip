@@ -50,6 +50,8 @@ struct SpecLayer {
 struct DownLayer { PwWeight pw; const float *dw_w, *dw_b; int ratio; float pre_scale; };
 struct UpLayer {
     const float* ct_w; int ratio; PwWeight pw; const float* pw_b; float pre_scale;
+    const float* id_taps;      // [M][5] = (0,0,0,0,1): identity stencil of the K1 form
+    const float* ct_wt;        // ct_w transposed [2r][Kp]
     std::vector<ResBlock> res;
 };
 
@@ -381,6 +383,13 @@ int pack_model(wv_model* m) {
             u.ct_w = U.plain("decoder.model." + std::to_string(n + 2) + ".convtr.convtr.weight");
             u.pw = U.pw("decoder.model." + std::to_string(n + 3) + ".conv.conv.weight");
             u.pw_b = U.plain("decoder.model." + std::to_string(n + 3) + ".conv.conv.bias");
+            {
+                std::vector<float> taps((size_t)u.pw.M * 5, 0.f);
+                for (int mm = 0; mm < u.pw.M; ++mm) taps[(size_t)mm * 5 + 4] = 1.f;
+                u.id_taps = U.up(taps);
+                const std::vector<float>& cw = U.host("decoder.model." + std::to_string(n + 2) + ".convtr.convtr.weight");
+                u.ct_wt = U.up(wv::pack_ct_wt(cw.data(), u.pw.K, u.pw.Kp, u.ratio));
+            }
             u.pre_scale = i > 0 ? m->dec_post : 1.f;
             for (int j = 0; j < c.n_residual_dec; ++j)                     // idx = j (seanet.py:1159)
                 u.res.push_back(pack_resblock(U, "decoder.model." + std::to_string(n + 4 + j), j, rd,
@@ -762,11 +771,13 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
     int Tl = Fr;
     for (const UpLayer& u : m->ups) {
         wv::prof::set_role("dec.upsample");
-        wv::DwPwArgs a{};
-        a.X = bf.a; a.dw_w = u.ct_w; a.pw = u.pw; a.bias = u.pw_b; a.Y = bf.b;
-        a.B = B; a.Tin = Tl; a.Tout = Tl * u.ratio; a.mode = 2; a.ratio = u.ratio;
-        a.pre_scale = u.pre_scale; a.pre_elu = 1;
-        LAUNCH(wv::launch_dw_pw(a, st));
+        // [Scale] -> ELU -> DW ConvTranspose(2r, r), trimmed -> 1x1 + bias (seanet.py:1147-1170): the
+        // K1 kernel with the ConvTranspose built in its B-operand loader and an identity stencil.
+        wv::PwDwArgs a{};
+        a.X = bf.a; a.ct_w = u.ct_w; a.ct_wt = u.ct_wt; a.ratio = u.ratio; a.pw = u.pw; a.dw_w = u.id_taps; a.dw_b = u.pw_b; a.Y = bf.b;
+        a.B = B; a.Tin = Tl; a.Tout = Tl * u.ratio; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
+        a.pre_scale = u.pre_scale; a.pre_elu = 1; a.out_scale = 1.f; a.bands = 1; a.prec = wv::PREC_F32;
+        LAUNCH(wv::launch_pw_dw(a, st));
         float* t = bf.a; bf.a = bf.b; bf.b = t;
         Tl = a.Tout;
         for (const ResBlock& r : u.res) {

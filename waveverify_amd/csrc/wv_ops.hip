@@ -88,12 +88,27 @@ int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const floa
                 int B, int K, int M, int Tin, int mode, int ks_or_ratio, float pre_scale, int pre_elu,
                 int l2norm, int accumulate, float out_scale, void* stream) {
     if (!X || !w_pw || !Y || B < 1 || K < 1 || M < 1 || Tin < 1) return WV_EINVAL;
+    if (mode == 2 && !l2norm && !accumulate) {
+        // upsample unit = K1 kernel with the ConvTranspose producer in its loader (as the model runs it)
+        if (!w_dw || ks_or_ratio < 1) return WV_EINVAL;
+        Tmp t;
+        std::vector<float> taps((size_t)M * 5, 0.f);
+        for (int m = 0; m < M; ++m) taps[(size_t)m * 5 + 4] = 1.f;
+        wv::PwDwArgs a{};
+        a.X = X; a.pw = t.pw(w_pw, M, K); a.ct_w = t.up(w_dw, (size_t)K * 2 * ks_or_ratio); a.ratio = ks_or_ratio;
+        a.ct_wt = t.upv(wv::pack_ct_wt(w_dw, K, a.pw.Kp, ks_or_ratio));
+        a.dw_w = t.upv(taps); a.dw_b = t.up(bias, M); a.Y = Y;
+        a.B = B; a.Tin = Tin; a.Tout = Tin * ks_or_ratio; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
+        a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1;
+        a.film_stride = 2; a.prec = wv::PREC_F32;
+        return done(t, wv::launch_pw_dw(a, (hipStream_t)stream), (hipStream_t)stream);
+    }
     Tmp t;
     wv::DwPwArgs a{};
     a.X = X; a.pw = t.pw(w_pw, M, K); a.bias = t.up(bias, M); a.Y = Y;
     a.B = B; a.Tin = Tin; a.mode = mode; a.Tout = Tin;
+    if (mode == 2) return WV_EINVAL;                  // the upsample unit has neither L2-norm nor accumulate
     if (mode == 1) { a.ks = ks_or_ratio; a.dw_w = t.up(w_dw, (size_t)K * a.ks); }
-    if (mode == 2) { a.ratio = ks_or_ratio; a.Tout = Tin * a.ratio; a.dw_w = t.up(w_dw, (size_t)K * 2 * a.ratio); }
     a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.l2norm = l2norm; a.accumulate = accumulate;
     a.out_scale = out_scale;
     return done(t, wv::launch_dw_pw(a, (hipStream_t)stream), (hipStream_t)stream);
