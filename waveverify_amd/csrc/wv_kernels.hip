@@ -662,7 +662,9 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
             for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
         }
     }
-    PwDwEpi<T, KS, (RM < 0 && RES) ? 8 : 0> epi;              // the upsample unit has no residual operand
+    // residual rows in flight per lane: 8 on the 128 x 128 tile; 4 on the others, where the 16
+    // registers saved buy one more wave per SIMD (or remove the spill of the 96-row tile)
+    PwDwEpi<T, KS, (RM < 0 && RES) ? ((T::BN == 64 || T::BM <= 96) ? 4 : 8) : 0> epi;
     epi.begin(p, smem + 2 * T::STAGE, smem, m0, b, to0);
     static_assert(PwDwEpi<T, KS>::STRIP_FLOATS <= 2 * T::STAGE, "strips alias the stages");
     f32x16 acc[1][T::NT];
