@@ -84,7 +84,10 @@ def test_pw_dw_no_prologue_no_bias(ops):
 
 
 @pytest.mark.parametrize("K,M,Tin,r", [(1536, 768, 50, 8), (768, 384, 400, 5), (384, 192, 333, 4),
-                                       (192, 96, 1000, 2), (16, 8, 9, 2), (24, 12, 1, 3)])
+                                       (192, 96, 1000, 2), (16, 8, 9, 2), (24, 12, 1, 3),
+                                       # every addressing mode of the ConvTranspose loader, ragged and tiny shapes
+                                       (40, 24, 37, 1), (18, 130, 65, 3), (32, 64, 31, 6), (64, 32, 3, 8),
+                                       (20, 20, 129, 4), (12, 100, 2, 2), (8, 8, 200, 7)])
 def test_upsample_convtr_pw(ops, K, M, Tin, r):
     rng = np.random.default_rng(K + r)
     X = rnd(rng, 2, K, Tin)
