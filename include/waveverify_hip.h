@@ -158,7 +158,9 @@ int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const floa
  *   mode 1: producer = causal DW conv k (no bias) of act(pre_scale*X)    (conv_post, seanet.py:797-823)
  *   mode 2: producer = causal DW ConvTranspose k=2r,s=r of act(pre_scale*X), right-trimmed by r
  *           (upsample, seanet.py:1112-1138; SConvTranspose1d conv.py:838-881); Tout = Tin*r
- *   accumulate != 0: Y += out_scale * (W @ producer(X))  (SpecBlock add, seanet.py:500-505). */
+ *   accumulate != 0: Y += out_scale * (W @ producer(X))  (SpecBlock add, seanet.py:500-505).
+ * Routing mirrors the model's: mode 2 and the accumulate form with M >= 128 run on the pw_dw kernel
+ * (ConvTranspose producer in its operand loader / identity stencil with Y as the residual operand). */
 int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const float* bias, float* Y,
                 int B, int K, int M, int Tin, int mode, int ks_or_ratio,
                 float pre_scale, int pre_elu, int l2norm, int accumulate, float out_scale,

@@ -115,7 +115,8 @@ def test_conv_post_l2norm(ops, K, M, Tin):
     close(got, ref, what="conv_post")
 
 
-@pytest.mark.parametrize("F,C,T", [(33, 64, 1000), (513, 1024, 50), (129, 256, 300), (9, 8, 33)])
+@pytest.mark.parametrize("F,C,T", [(33, 64, 1000), (513, 1024, 50), (129, 256, 300), (9, 8, 33),
+                                   (65, 128, 8000), (257, 512, 401), (17, 128, 3)])
 def test_pointwise_accumulate(ops, F, C, T):
     """SpecBlock tail: x += scale * (W @ P) (seanet.py:497-505)."""
     rng = np.random.default_rng(F)

@@ -16,15 +16,27 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    m = re.match(r"void wv::(\w+)_kernel<wv::Tile<(\d+), (\d+), (\d+), (\d+)>(?:, (\d+))?\s*>", name)
+    """Kernel symbol -> the name the library's profiler (and bench.py) uses."""
+    m = re.match(r"void wv::(\w+)_kernel<wv::Tile<(\d+), (\d+), (\d+), (\d+)>((?:, [-\w]+)*)\s*>", name)
     if not m:
         m2 = re.match(r"(?:void )?wv::(\w+)_kernel", name)
         return m2.group(1) if m2 else name
     base, bm, bn, wm, wn, extra = m.groups()
+    ex = [e.strip() for e in extra.split(",") if e.strip()]
     if base == "dw_pw":
-        base = {"0": "pw", "1": "dwconv_pw", "2": "convtr_pw"}.get(extra, base)
-    elif base in ("pw_dw", "pw_dw_h") and extra == "5":
-        base = base.replace("pw_dw", "pw_dw_k5")
+        base = {"0": "pw", "1": "dwconv_pw"}.get(ex[0] if ex else "", base)
+    elif base == "pw_dw":
+        ks = ex[0] if ex else "0"
+        rm = ex[1] if len(ex) > 1 else "-1"
+        res = ex[2] if len(ex) > 2 else "true"
+        if rm == "-2":
+            base = "spec_add"
+        elif rm != "-1":
+            base = "convtr_pw"
+        elif ks == "5":
+            base = "pw_dw_k5" if res in ("true", "1") else "pw_dw_k5_nr"
+    elif base == "pw_dw_h":
+        base = "pw_dw_k5_h" if ex and ex[0] == "5" else "pw_dw_h"
     return f"{base}<{bm},{bn},{wm},{wn}>"
 
 

@@ -70,6 +70,7 @@ struct PwDwArgs {
     int stagger, first_gen;   // de-phasing of the first workgroup generation (see kernel)
     int tto, off;         // filled by launch_pw_dw: outputs per time tile; stencil offset inside
                           // the 4-aligned H window
+    int spec_add;         // 1: the SpecBlock add (identity stencil, resid == Y): own kernel instantiation
     const float* ct_w;    // upsample unit only: DW ConvTranspose taps [K, 2*ratio] and ratio; X is then
     int ratio;            //   [B, K, Tin], Tout = Tin*ratio
     const float* ct_wt;   // the same taps transposed and zero padded, [2*ratio][pw.Kp] (pack_ct_wt)

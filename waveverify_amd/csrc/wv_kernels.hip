@@ -1357,9 +1357,25 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
         else hipLaunchKernelGGL((pw_dw_kernel<T, 5, 0>), grid, dim3(T::NTHREADS), smem, s, a);
         return hipGetLastError();
     }
-    prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
+    if constexpr (KS == 5) if (a.spec_add && a.resid) {
+        // same code as the residual unit; a separate instantiation (RM = -2) so that profiles keep
+        // this HBM-bound launch apart from the matrix-bound ResnetBlock halves
+        static const std::string sname = tile_name<T>("spec_add");
+        prof::Scope pa(s, sname.c_str(), 2.0 * Bd * M * K * a.Tin, 4.0 * Bd * (K * a.Tin + 2.0 * M * a.Tout));
+        static bool attr_sa = false;
+        if (!attr_sa) {
+            hipError_t e = set_smem(pw_dw_kernel<T, 5, -2>, smem);
+            if (e != hipSuccess) return e;
+            attr_sa = true;
+        }
+        hipLaunchKernelGGL((pw_dw_kernel<T, 5, -2>), grid, dim3(T::NTHREADS), smem, s, a);
+        return hipGetLastError();
+    }
+    static const std::string name_nr = tile_name<T>("pw_dw_k5_nr");    // no-residual instantiation
+    const bool nores = KS == 5 && !a.resid;
+    prof::Scope ps(s, nores ? name_nr.c_str() : name.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
                    4.0 * Bd * (K * a.Tin + M * a.Tout * (a.resid ? 2.0 : 1.0)));
-    if constexpr (KS == 5) if (!a.resid) {
+    if constexpr (KS == 5) if (nores) {
         static bool attr_nr = false;
         if (!attr_nr) {
             hipError_t e = set_smem(pw_dw_kernel<T, 5, -1, false>, smem);

@@ -557,6 +557,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         acc.X = P; acc.pw = sp.pw; acc.dw_w = sp.id_taps; acc.dw_b = nullptr; acc.resid = bf.a; acc.Y = bf.a;
         acc.B = B; acc.Tin = Tl; acc.Tout = Tl; acc.ks = 5; acc.stride = 1; acc.dil = 1; acc.pad = 4;
         acc.pre_scale = 1.f; acc.pre_elu = 0; acc.out_scale = sp.scale; acc.bands = 1; acc.prec = wv::PREC_F32;
+        acc.spec_add = 1;
         LAUNCH(wv::launch_pw_dw(acc, st));
         }
         if (post) break;

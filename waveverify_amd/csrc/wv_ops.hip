@@ -108,6 +108,18 @@ int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const floa
     a.X = X; a.pw = t.pw(w_pw, M, K); a.bias = t.up(bias, M); a.Y = Y;
     a.B = B; a.Tin = Tin; a.mode = mode; a.Tout = Tin;
     if (mode == 2) return WV_EINVAL;                  // the upsample unit has neither L2-norm nor accumulate
+    if (mode == 0 && accumulate && !l2norm && !bias && M >= 128) {
+        // SpecBlock add as the model runs it for M >= 128: K1 kernel, identity stencil, Y as residual
+        Tmp t;
+        std::vector<float> taps((size_t)M * 5, 0.f);
+        for (int m = 0; m < M; ++m) taps[(size_t)m * 5 + 4] = 1.f;
+        wv::PwDwArgs a{};
+        a.X = X; a.pw = t.pw(w_pw, M, K); a.dw_w = t.upv(taps); a.resid = Y; a.Y = Y;
+        a.B = B; a.Tin = Tin; a.Tout = Tin; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
+        a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = out_scale; a.bands = 1; a.film_stride = 2;
+        a.prec = wv::PREC_F32; a.spec_add = 1;
+        return done(t, wv::launch_pw_dw(a, (hipStream_t)stream), (hipStream_t)stream);
+    }
     if (mode == 1) { a.ks = ks_or_ratio; a.dw_w = t.up(w_dw, (size_t)K * a.ks); }
     a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.l2norm = l2norm; a.accumulate = accumulate;
     a.out_scale = out_scale;
