@@ -101,14 +101,37 @@ struct DwPwArgs {
 hipError_t launch_dw_pw(const DwPwArgs& a, hipStream_t s);
 
 // ---- K3a: causal STFT log-magnitude ---------------------------------------------------------
-// basis_t[n_fft][Mp]: column 2f = windowed cos row f, column 2f+1 = windowed sin row f.
+// The 2F = n_fft + 2 basis rows are laid out so that the matrix part has exactly n_fft rows (no
+// padding for n_fft = 64 * 2^s): row 0 = cos_0 (DC), row 1 = cos_{F-1} (Nyquist), rows 2f / 2f+1
+// = cos_f / sin_f for f = 1 .. F-2.  The two remaining rows, sin_0 (identically zero for a
+// reference-built basis) and sin_{F-1} (rounding-level values), are applied as two plain dot
+// products per frame next to the matrix loop (`side`), so nothing of the reference's arithmetic
+// is dropped.  basis_t[Kp][Mp] is the transposed, zero padded matrix part.
 struct StftArgs {
     const float* wav;     // [B, 1, T]
-    const float* basis_t;
+    const float* basis_t; // [Kp][Mp]
+    const float* side;    // [2][n_fft]: sin_0 row, sin_{F-1} row
     float* P;             // [B, F, Tf]
     int B, T, Tf, n_fft, hop, F, Mp;
     float mean, inv_std;
 };
+// host: basis [2F][n_fft] (cos rows, then sin rows; modules/conv.py:1003-1026) -> basis_t, side
+inline void pack_stft_basis(const float* basis, int n_fft, std::vector<float>& bt, std::vector<float>& side, int* Mp_out) {
+    const int F = n_fft / 2 + 1, Mp = round_up(n_fft, M_ALIGN), Kp = round_up(n_fft, BK);
+    bt.assign((size_t)Kp * Mp, 0.f);
+    side.assign((size_t)2 * n_fft, 0.f);
+    for (int n = 0; n < n_fft; ++n) {
+        bt[(size_t)n * Mp + 0] = basis[(size_t)0 * n_fft + n];
+        bt[(size_t)n * Mp + 1] = basis[(size_t)(F - 1) * n_fft + n];
+        for (int f = 1; f + 1 < F; ++f) {
+            bt[(size_t)n * Mp + 2 * f] = basis[(size_t)f * n_fft + n];
+            bt[(size_t)n * Mp + 2 * f + 1] = basis[(size_t)(F + f) * n_fft + n];
+        }
+        side[n] = basis[(size_t)F * n_fft + n];
+        side[(size_t)n_fft + n] = basis[(size_t)(2 * F - 1) * n_fft + n];
+    }
+    if (Mp_out) *Mp_out = Mp;
+}
 hipError_t launch_stft_logmag(const StftArgs& a, hipStream_t s);
 
 // ---- K4: conv_pre ---------------------------------------------------------------------------

@@ -63,9 +63,13 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[T::MT][T::NT]) {
 
 // LA: float4 load4(int k, int m)                      m multiple of 4, in [0,BM)
 // LB: NRAW; init(col4); fetch(k, raw[4*NRAW]); finish(k, raw, out[4])   4 consecutive columns
-template <class T, class LA, class LB>
+struct NoSide { __device__ __forceinline__ void operator()(int, const float*) const {} };
+
+// SD: optional per-chunk hook side(c, Bs) with the staged B chunk Bs[BK][BN] (valid until the
+// chunk's barrier); used by the STFT for its two vector-side rows.
+template <class T, class LA, class LB, class SD = NoSide>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::MT][T::NT], const LA& la, LB& lb,
-                                              int nchunks, float* smem, int dbg = 0) {
+                                              int nchunks, float* smem, int dbg = 0, SD&& side = SD()) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN;
@@ -143,6 +147,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::MT][T::NT], const
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (!(dbg & 16) && c + 1 < nchunks) commit(c + 1, smem + ((c + 1) & 1) * T::STAGE);
+        side(c, Bs);
         __syncthreads();
     }
 }
@@ -1000,6 +1005,23 @@ struct FrameLoader {
     }
 };
 
+// the two vector-side rows (sin_0, sin_{F-1}): thread `col` of the first m-tile keeps the two dot
+// products of its frame, fed from the staged B chunk
+template <int BN>
+struct StftSide {
+    const float* s0; const float* s1; int n_fft; bool on; int col; float d0, d1;
+    __device__ __forceinline__ void operator()(int c, const float* Bs) {
+        if (!on) return;
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            const int k = min(c * BK + kk, n_fft - 1);            // staged rows past n_fft are zero
+            const float v = Bs[kk * BN + col];
+            d0 = fmaf(s0[k], v, d0);
+            d1 = fmaf(s1[k], v, d1);
+        }
+    }
+};
+
 template <class T>
 __global__ __launch_bounds__(NT_) void stft_logmag_kernel(StftArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1010,7 +1032,12 @@ __global__ __launch_bounds__(NT_) void stft_logmag_kernel(StftArgs p) {
     zero_acc<T>(acc);
     WLoader la{p.basis_t, p.Mp, m0};
     FrameLoader lb{p.wav + (size_t)b * p.T, p.T, p.Tf, p.n_fft, p.hop, t0, {}, {}};
-    gemm_mainloop<T>(acc, la, lb, (p.n_fft + BK - 1) / BK, smem);
+    StftSide<T::BN> side{p.side, p.side + p.n_fft, p.n_fft, blockIdx.x == 0 && (int)threadIdx.x < T::BN,
+                         (int)threadIdx.x % T::BN, 0.f, 0.f};
+    gemm_mainloop<T>(acc, la, lb, (p.n_fft + BK - 1) / BK, smem, 0, side);
+    float* sd = smem;                                        // [2][BN] (stages are free after the last barrier)
+    if (side.on) { sd[side.col] = side.d0; sd[T::BN + side.col] = side.d1; }
+    if (blockIdx.x == 0) __syncthreads();
 
     float* Pb = p.P + (size_t)b * p.F * p.Tf;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1022,12 +1049,19 @@ __global__ __launch_bounds__(NT_) void stft_logmag_kernel(StftArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const int row = m0 + wm * T::MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int t = t0 + wn * T::NT * 32 + j * 32 + (lane & 31);
-                const int f = row >> 1;                  // row even: (re, im) = regs (r, r+1)
-                if (f < p.F && t < p.Tf) {
-                    const float re = acc[i][j][r], im = acc[i][j][r + 1];
-                    const float mag = sqrtf(fmaxf(fmaf(re, re, im * im), 1e-12f));   // conv.py:1078
-                    Pb[(size_t)f * p.Tf + t] = (__logf(fmaxf(mag, 1e-5f)) - p.mean) * p.inv_std;
+                const int col = wn * T::NT * 32 + j * 32 + (lane & 31);
+                const int t = t0 + col;
+                if (row >= p.n_fft || t >= p.Tf) continue;
+                const float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
+                auto logmag = [&](float re, float im) {
+                    const float mag = sqrtf(fmaxf(fmaf(re, re, im * im), 1e-12f));       // conv.py:1078
+                    return (__logf(fmaxf(mag, 1e-5f)) - p.mean) * p.inv_std;
+                };
+                if (row == 0) {                          // (cos_0, cos_{F-1}) + the vector-side sin rows
+                    Pb[t] = logmag(v0, sd[col]);
+                    Pb[(size_t)(p.F - 1) * p.Tf + t] = logmag(v1, sd[T::BN + col]);
+                } else {                                 // row = 2f: (re, im) of bin f
+                    Pb[(size_t)(row >> 1) * p.Tf + t] = logmag(v0, v1);
                 }
             }
 }
@@ -1487,7 +1521,7 @@ hipError_t launch_dw_pw(const DwPwArgs& a, hipStream_t s) {
 
 template <class T>
 static hipError_t run_stft(const StftArgs& a, hipStream_t s) {
-    dim3 grid((2 * a.F + T::BM - 1) / T::BM, (a.Tf + T::BN - 1) / T::BN, a.B);
+    dim3 grid((a.n_fft + T::BM - 1) / T::BM, (a.Tf + T::BN - 1) / T::BN, a.B);
     static const std::string name = tile_name<T>("stft_logmag");
     prof::Scope ps(s, name.c_str(), 2.0 * a.B * (2.0 * a.F) * a.n_fft * a.Tf,
                    4.0 * a.B * ((double)a.T + (double)a.F * a.Tf));
@@ -1496,11 +1530,12 @@ static hipError_t run_stft(const StftArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_stft_logmag(const StftArgs& a, hipStream_t s) {
-    if (a.Mp % M_ALIGN || a.Mp < 2 * a.F) return hipErrorInvalidValue;
+    if (a.Mp % M_ALIGN || a.Mp < a.n_fft || a.n_fft < 4 || (a.n_fft & 1) || a.F != a.n_fft / 2 + 1 || !a.side)
+        return hipErrorInvalidValue;
     if (a.Tf <= 64) return run_stft<Tile<128, 64, 2, 2>>(a, s);
-    if (2 * a.F <= 64) return run_stft<Tile<64, 128, 1, 4>>(a, s);
-    // 2F = n_fft + 2 rows: pick the tile height that pads them least (130 -> 2x96, not 2x128)
-    if (round_up(2 * a.F, 96) < round_up(2 * a.F, 128)) return run_stft<Tile<96, 128, 1, 4>>(a, s);
+    if (a.n_fft <= 64) return run_stft<Tile<64, 128, 1, 4>>(a, s);
+    // n_fft rows: pick the tile height that pads them least
+    if (round_up(a.n_fft, 96) < round_up(a.n_fft, 128)) return run_stft<Tile<96, 128, 1, 4>>(a, s);
     return run_stft<Tile<128, 128, 1, 4>>(a, s);
 }
 

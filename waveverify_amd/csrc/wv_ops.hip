@@ -146,16 +146,13 @@ int wv_op_stft_logmag(const float* wav, const float* host_basis, float* P, int B
             }
         }
     }
-    const int Mp = wv::round_up(2 * F, wv::M_ALIGN), Kp = wv::round_up(n_fft, wv::BK);
-    std::vector<float> bt((size_t)Kp * Mp, 0.f);
-    for (int f = 0; f < F; ++f)
-        for (int n = 0; n < n_fft; ++n) {
-            bt[(size_t)n * Mp + 2 * f] = basis[(size_t)f * n_fft + n];
-            bt[(size_t)n * Mp + 2 * f + 1] = basis[(size_t)(F + f) * n_fft + n];
-        }
+    if (n_fft < 4 || (n_fft & 1)) return WV_EINVAL;
+    std::vector<float> bt, side;
+    int Mp = 0;
+    wv::pack_stft_basis(basis.data(), n_fft, bt, side, &Mp);
     Tmp t;
     wv::StftArgs a{};
-    a.wav = wav; a.basis_t = t.upv(bt); a.P = P; a.B = B; a.T = T; a.Tf = (T + hop - 1) / hop;
+    a.wav = wav; a.basis_t = t.upv(bt); a.side = t.upv(side); a.P = P; a.B = B; a.T = T; a.Tf = (T + hop - 1) / hop;
     a.n_fft = n_fft; a.hop = hop; a.F = F; a.Mp = Mp; a.mean = mean; a.inv_std = 1.f / std;
     return done(t, wv::launch_stft_logmag(a, (hipStream_t)stream), (hipStream_t)stream);
 }
