@@ -82,3 +82,28 @@ def test_checkpoint_roundtrip(tmp_path, wv):
     assert torch.equal(other.embed_batch(x, msg), wv.embed_batch(x, msg))
     assert torch.equal(other.detect_batch(x)[1], wv.detect_batch(x)[1])
     assert torch.allclose(other.locate_batch(x), wv.locate_batch(x), atol=1e-6)
+
+
+def test_forward_captures_into_a_hip_graph(wv):
+    """The forward passes are plain launches on the caller's stream (no allocation, no sync):
+    they capture into a HIP graph and replay bit-identically."""
+    x = (torch.randn(2, 1, 3200) * 0.1).clamp(-1, 1).cuda()
+    msg = torch.tensor([[1, 0] * 8, [0, 1] * 8], dtype=torch.float32).cuda()
+    gen, det = wv.model.generator, wv.model.detector
+
+    def step():
+        wm = gen.generator(x, msg, add_input=True)
+        return wm, det.detector_mean_prob(wm)
+
+    wm0, p0 = step()                                   # eager (also sizes the workspaces)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        wm1, p1 = step()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(wm1, wm0) and torch.equal(p1, p0)
