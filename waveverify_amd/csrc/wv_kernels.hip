@@ -206,15 +206,17 @@ struct RowLoader {
 };
 
 // ------------------------------------------------------------------------------------------
-// K1  pw_dw:  Y = epi( DWconv(W @ act(s*X)) + b )
+// K1  pw_dw:  Y = epi( DWconv(W @ producer(X)) + b )
 // One workgroup: (m-tile, time-tile, clip).  The GEMM produces H[BM][BN] for the input-time
 // window the output tile needs (halo = (ks-1)*d - (s-1) on the left, recomputed per tile; the
-// window start is 4-aligned so X rows are read with 16-byte loads); H goes to LDS (aliasing the
-// staging buffers) and the depth-wise stencil + FiLM / residual epilogue reads it back one
-// channel row per wave: the row's taps, bias and FiLM scalars are wave-uniform (SGPRs), time is
-// on the lanes, global stores are 256-byte coalesced.
+// window start is 4-aligned so X rows are read with 16-byte loads).  Row-strip tiles: every wave
+// owns 32 output channels x the whole window, so the depth-wise stencil never leaves the wave:
+// accumulator rows go through wave-private LDS strips (no workgroup barrier) and come back with
+// time on the lanes for the stencil + FiLM / residual epilogue (PwDwEpi).
 // Zero padding: X is staged as 0 outside [0,Tin) and the 1x1 has no bias, so H is 0 there,
 // which is exactly the zero pad SConv1d inserts between the 1x1 and the DW conv.
+// producer(X) is act(s*X) (ResnetBlock halves, downsample, SpecBlock add) or the depth-wise
+// ConvTranspose of act(s*X) (upsample unit, identity stencil): see pw_dw_kernel.
 // ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
 // f32 GEMM core for the row-strip tiles, k-inner LDS layout.  LDS holds float4 fragments
