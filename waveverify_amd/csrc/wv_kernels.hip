@@ -225,19 +225,17 @@ struct RowLoader {
 // 16-deep chunk and wave instead of 40.  The k index is only a summation index, so the two
 // lane halves may take any disjoint k sets as long as A and B agree: half h owns fragments
 // kq = h and kq = h + 2, i.e. k in [4h, 4h+4) U [8+4h, 12+4h).
-// A fragments are pre-packed on the host (wq); B columns are loaded with time on the lanes
-// (four 4-byte loads per 4k x 1col micro-tile, 256-byte segments per wave) and written as one
-// conflict-free ds_write_b128.
+// A fragments are pre-packed on the host (wq) and never touch LDS: a wave's 32 weight rows are
+// private to it, so every lane loads its two fragments per chunk straight from global memory.
+// Only the B operand, which all waves share, is staged (see RowPairLoader / ConvTrPair).
 // ------------------------------------------------------------------------------------------
 template <class T>
 struct QT {
     static constexpr int KQ = BK / 4;                         // fragments along k per chunk
-    static constexpr int NA = KQ * T::BM, NB = KQ * T::BN;    // f32x4 fragments per stage
+    static constexpr int NB = KQ * T::BN;                     // B fragments (f32x4) per LDS stage
     static constexpr int CG = T::BN / 4;                      // column groups of 4
     static constexpr int NBT = (BK / 2) * CG;                 // B micro-tiles: 2 k rows x 4 columns
-    static constexpr int A_PER = (NA + T::NTHREADS - 1) / T::NTHREADS;
     static constexpr int B_PER = (NBT + T::NTHREADS - 1) / T::NTHREADS;
-    static constexpr int STAGE = NA + NB;                     // f32x4 per stage (== BK*(BM+BN) floats)
     static_assert(T::NTHREADS % CG == 0, "a thread keeps its column group");
 };
 
@@ -374,17 +372,18 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
     static_assert(T::WN == 1 && T::MT == 1, "row-strip tile");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cg = tid % Q::CG;
-    f32x4 ra[Q::A_PER];
+    const int h = lane >> 5, i31 = lane & 31;
+    // A fragments: a wave's 32 weight rows are private to it, so they skip LDS altogether -- each
+    // lane loads the two fragments it multiplies with straight from the packed weights (L2-resident),
+    // one chunk ahead.  Only the B operand (shared by all waves) is staged.
+    const f32x4* wa = wq + m0 + 32 * wave + i31;
+    f32x4 an0, an1;
     float rb[Q::B_PER][LB::NRAW];
     lb.init(cg);
 
     auto fetch = [&](int c) {
-#pragma unroll
-        for (int r = 0; r < Q::A_PER; ++r) {
-            const int idx = tid + r * T::NTHREADS;
-            if (Q::NA % T::NTHREADS == 0 || idx < Q::NA)
-                ra[r] = wq[(size_t)(c * Q::KQ + idx / T::BM) * Mp + m0 + idx % T::BM];
-        }
+        an0 = wa[(size_t)(c * Q::KQ + h) * Mp];
+        an1 = wa[(size_t)(c * Q::KQ + h + 2) * Mp];
 #pragma unroll
         for (int r = 0; r < Q::B_PER; ++r) {
             const int idx = tid + r * T::NTHREADS;
@@ -392,12 +391,7 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
         }
     };
     auto commit = [&](int c, f32x4* buf) {
-#pragma unroll
-        for (int r = 0; r < Q::A_PER; ++r) {
-            const int idx = tid + r * T::NTHREADS;
-            if (Q::NA % T::NTHREADS == 0 || idx < Q::NA) buf[idx] = ra[r];
-        }
-        float* Bf = reinterpret_cast<float*>(buf + Q::NA);
+        float* Bf = reinterpret_cast<float*>(buf);
 #pragma unroll
         for (int r = 0; r < Q::B_PER; ++r) {
             const int idx = tid + r * T::NTHREADS;
@@ -414,20 +408,17 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
             }
         }
     };
-    const int h = lane >> 5, i31 = lane & 31;
     int bslot[T::NT];
 #pragma unroll
     for (int j = 0; j < T::NT; ++j) bslot[j] = q_slot(32 * j + i31);
     fetch(0);
     commit(0, smem);
+    f32x4 a0 = an0, a1 = an1;
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        const f32x4* As = smem + (c & 1) * Q::STAGE;
-        const f32x4* Bs = As + Q::NA;
+        const f32x4* Bs = smem + (c & 1) * Q::NB;
         if (!(dbg & 16) && c + 1 < nchunks) fetch(c + 1);
         if (!(dbg & 2)) {
-            const f32x4 a0 = As[h * T::BM + 32 * wave + i31];
-            const f32x4 a1 = As[(h + 2) * T::BM + 32 * wave + i31];
             f32x4 b0[T::NT], b1[T::NT];
 #pragma unroll
             for (int j = 0; j < T::NT; ++j) {
@@ -441,7 +432,8 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
             WV_QSTEP(a1.x, b1, x) WV_QSTEP(a1.y, b1, y) WV_QSTEP(a1.z, b1, z) WV_QSTEP(a1.w, b1, w)
 #undef WV_QSTEP
         }
-        if (!(dbg & 16) && c + 1 < nchunks) commit(c + 1, smem + ((c + 1) & 1) * Q::STAGE);
+        if (!(dbg & 16) && c + 1 < nchunks) commit(c + 1, smem + ((c + 1) & 1) * Q::NB);
+        a0 = an0; a1 = an1;
         __syncthreads();
     }
 }
@@ -672,8 +664,9 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
     // residual rows in flight per lane: 8 on the 128 x 128 tile; 4 on the others, where the 16
     // registers saved buy one more wave per SIMD (or remove the spill of the 96-row tile)
     PwDwEpi<T, KS, (RM < 0 && RES) ? ((T::BN == 64 || T::BM <= 96) ? 4 : 8) : 0> epi;
-    epi.begin(p, smem + 2 * T::STAGE, smem, m0, b, to0);
-    static_assert(PwDwEpi<T, KS>::STRIP_FLOATS <= 2 * T::STAGE, "strips alias the stages");
+    constexpr int STAGES_F = 2 * QT<T>::NB * 4;              // floats in the two B stages (A skips LDS)
+    epi.begin(p, smem + STAGES_F, smem, m0, b, to0);
+    static_assert(PwDwEpi<T, KS>::STRIP_FLOATS <= STAGES_F, "strips alias the stages");
     f32x16 acc[1][T::NT];
     zero_acc<T>(acc);
     if constexpr (RM < 0) {
@@ -1330,7 +1323,7 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     if (!pw_dw_geometry(a, T::BN)) return hipErrorInvalidValue;
     a.dbg = g_debug_flags & 31;
     const size_t eb = (size_t)PwDwEpi<T, KS>::FLOATS * sizeof(float);
-    const size_t smem = stage_bytes<T>() + eb;
+    const size_t smem = 2 * (size_t)QT<T>::NB * 16 + eb;       // two B stages + the epilogue's row table
     static bool attr_f32 = false;
     if (!attr_f32) {
         hipError_t e = set_smem(pw_dw_kernel<T, KS>, smem);
