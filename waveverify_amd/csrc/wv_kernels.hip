@@ -1072,23 +1072,36 @@ __global__ __launch_bounds__(NT_) void conv_pre_kernel(const float* __restrict__
                                                        const float* __restrict__ bias,
                                                        float* __restrict__ Y, int C, int T, int ks,
                                                        float in_scale) {
+    // a thread owns 4 consecutive samples: one 16-byte store per channel row (1 KB per wave)
     const int b = blockIdx.y;
-    const int t = blockIdx.x * NT_ + threadIdx.x;
+    const int t = (blockIdx.x * NT_ + threadIdx.x) * 4;
     if (t >= T) return;
     const float* xb = x + (size_t)b * T;
-    float xv[MAX_KS];
+    float xv[MAX_KS + 3];                                    // x[t-(ks-1) .. t+3], scaled, 0 outside [0,T)
 #pragma unroll
-    for (int i = 0; i < MAX_KS; ++i) {
+    for (int i = 0; i < MAX_KS + 3; ++i) {
         const int ti = t - (ks - 1) + i;
-        xv[i] = (i < ks && ti >= 0) ? xb[ti] * in_scale : 0.f;
+        xv[i] = (i < ks + 3 && ti >= 0 && ti < T) ? xb[ti] * in_scale : 0.f;
     }
     float* yb = Y + (size_t)b * C * T + t;
+    const bool vec = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0;
     for (int c = 0; c < C; ++c) {
-        float y = bias ? bias[c] : 0.f;
+        const float bc = bias ? bias[c] : 0.f;
+        float y[4] = {bc, bc, bc, bc};
 #pragma unroll
         for (int i = 0; i < MAX_KS; ++i)
-            if (i < ks) y = fmaf(w[c * ks + i], xv[i], y);
-        yb[(size_t)c * T] = y;
+            if (i < ks) {
+                const float wi = w[c * ks + i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = fmaf(wi, xv[i + e], y[e]);
+            }
+        float* yr = yb + (size_t)c * T;
+        if (vec) *reinterpret_cast<f32x4*>(yr) = f32x4{y[0], y[1], y[2], y[3]};
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (t + e < T) yr[e] = y[e];
+        }
     }
 }
 
@@ -1110,13 +1123,21 @@ __global__ __launch_bounds__(NT_) void tail_kernel(const float* __restrict__ H,
     const bool inb = t >= 0 && t < Tin;
     const float* hb = H + (size_t)b * C * Tin + (inb ? t : 0);
     float y = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float e = inb ? elu1(hb[(size_t)c * Tin] * pre_scale) : 0.f;
-        const float* wc = w + c * ks;
-        y = fmaf(wc[ks - 1], e, y);
-        for (int i = 1; i < ks; ++i) {
-            const float ei = __shfl_up(e, i);          // lanes < i get garbage; they are halo lanes
-            y = fmaf(wc[ks - 1 - i], ei, y);
+    for (int c0 = 0; c0 < C; c0 += 8) {                        // 8 channel rows in flight per lane
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = hb[(size_t)min(c0 + u, C - 1) * Tin];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            if (c >= C) break;
+            const float e = inb ? elu1(v[u] * pre_scale) : 0.f;
+            const float* wc = w + c * ks;
+            y = fmaf(wc[ks - 1], e, y);
+            for (int i = 1; i < ks; ++i) {
+                const float ei = __shfl_up(e, i);              // lanes < i get garbage; they are halo lanes
+                y = fmaf(wc[ks - 1 - i], ei, y);
+            }
         }
     }
     if (lane >= ks - 1 && t < T) {
@@ -1537,7 +1558,7 @@ hipError_t launch_stft_logmag(const StftArgs& a, hipStream_t s) {
 hipError_t launch_conv_pre(const float* x, const float* w, const float* bias, float* Y, int B,
                            int C, int T, int ks, float in_scale, hipStream_t s) {
     if (ks < 1 || ks > MAX_KS) return hipErrorInvalidValue;
-    dim3 grid((T + NT_ - 1) / NT_, B);
+    dim3 grid((T + 4 * NT_ - 1) / (4 * NT_), B);
     prof::Scope ps(s, "conv_pre", 2.0 * B * C * ks * (double)T, 4.0 * B * (double)T * (1.0 + C));
     hipLaunchKernelGGL(conv_pre_kernel, grid, dim3(NT_), 0, s, x, w, bias, Y, C, T, ks, in_scale);
     return hipGetLastError();
