@@ -150,3 +150,22 @@ def test_errors_are_loud(nets):
         nets["generator"].generator(torch.zeros(2, 2, 100).cuda(), torch.zeros(2, 16).cuda())
     with pytest.raises(RuntimeError):
         HipNet(cfg, random_state_dict(cfg, 0), device="cpu")
+
+
+def test_split_f16_precision_full_nets(golden_dir, nets):
+    """precision="f16x3" (split-f16 matrix core on the K >= 256 layers): same bar as f32 against the
+    reference golden -- watermarked samples within 1e-4 (measured 7e-8), identical bits."""
+    g = np.load(os.path.join(golden_dir, "full_T16000.npz"))
+    x, msg = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["msg"]).cuda()
+    G, D = nets["generator"], nets["detector"]
+    try:
+        G.set_precision("f16x3")
+        D.set_precision("f16x3")
+        wm = G.generator(x, msg, add_input=True)
+        assert dmax(wm, g["wm"]) <= 2e-5
+        mp = D.detector_mean_prob(wm)
+        assert dmax(mp, g["det_mean_prob"]) <= 1e-5
+        assert ((mp >= 0.5).int().cpu().numpy() == g["det_bits"]).all()
+    finally:
+        G.set_precision("f32")
+        D.set_precision("f32")
