@@ -102,8 +102,21 @@ def test_forward_captures_into_a_hip_graph(wv):
         step()
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, stream=side):         # captured on `side`, whose workspaces exist already
         wm1, p1 = step()
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(wm1, wm0) and torch.equal(p1, p0)
+    # A larger eager batch on the capture stream outgrows its workspaces.  The buffers the graph
+    # points at must stay alive (retired, not freed) and must not be handed to anything else.
+    xb = (torch.randn(16, 1, 6400) * 0.1).clamp(-1, 1).cuda()
+    with torch.cuda.stream(side):
+        big = gen.generator(xb, msg[:1], add_input=True)
+        junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]   # would reuse freed blocks
+    torch.cuda.synchronize()
+    assert len(gen._retired) >= 1
+    wm1.zero_(); p1.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(wm1, wm0) and torch.equal(p1, p0)
+    assert torch.isfinite(big).all() and len(junk) == 8

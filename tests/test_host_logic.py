@@ -174,6 +174,43 @@ def test_checkpoint_formats(tmp_path):
         checkpoint.apply_argbind_config("generator", cfgs["generator"], {"Generator.causal": False})
 
 
+def test_checkpoint_with_full_train_py_key_set(tmp_path):
+    """An atomic checkpoint carrying every key scripts/train.py:1632-1656 writes (optimizers with real
+    Adam state, scheduler dicts, tracker, message_threshold, an argbind-style config dict with entries of
+    other classes and None values) loads under weights_only=True; discovery follows core.py:343-356
+    (first file that loads AND has a 'models' dict), and a file the safe loader refuses is reported as
+    such instead of falling through to the legacy layout."""
+    cfgs = {k: default_config(k) for k in ("generator", "detector", "locator")}
+    models = {k: _torch_sd(c, 0) for k, c in cfgs.items()}
+    models["discriminator"] = {"convs.0.weight": torch.zeros(4, 1, 3)}
+    lin = torch.nn.Linear(3, 2)
+    opt = torch.optim.AdamW(lin.parameters(), lr=1e-4)
+    lin(torch.ones(1, 3)).sum().backward(); opt.step()
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.999)
+    full = {"step": 123, "models": models,
+            "optimizers": {"generator": opt.state_dict(), "discriminator": opt.state_dict()},
+            "schedulers": {"generator": sched.state_dict(), "discriminator": sched.state_dict()},
+            "tracker": {"step": 123, "history": {"loss": [1.0, 0.5]}}, "message_threshold": 0.5,
+            "config": {"Generator.res_scale_enc": 0.4, "Generator.sample_rate": 16000, "Generator.causal": True,
+                       "Discriminator.rates": [], "AdamW.lr": 1e-4, "train.seed": None, "Detector.nbits": 16}}
+    d = tmp_path / "run"; d.mkdir()
+    torch.save({"not_models": 1}, d / "best.pth")              # loads, but is not an atomic checkpoint
+    torch.save(full, d / "zz_step123.pth")
+    assert checkpoint.is_atomic_checkpoint(d)
+    assert checkpoint.find_atomic_checkpoint_file(d).name == "zz_step123.pth"
+    sds, got = checkpoint.load_checkpoint(d)
+    assert set(sds) == {"generator", "detector", "locator"}
+    assert got["generator"].res_scale_enc == pytest.approx(0.4) and got["detector"] == cfgs["detector"]
+    # a checkpoint the safe loader refuses: clear error, no legacy fallback
+    import argparse
+    bad = tmp_path / "bad"; bad.mkdir()
+    torch.save({"models": {}, "tracker": argparse.Namespace(step=1)}, bad / "latest.pth")   # an arbitrary pickled object
+    with pytest.raises(checkpoint.UnsafeCheckpointError, match="weights_only"):
+        checkpoint.load_checkpoint(bad)
+    with pytest.raises(NotImplementedError, match="res_scale_dec"):
+        checkpoint.apply_argbind_config("generator", cfgs["generator"], {"Generator.res_scale_dec": None})
+
+
 def test_infer_config_small_generator():
     cfg = default_config("generator", channels_enc=8, channels_dec=8, n_residual_dec=2, dimension=16,
                          strides=[2, 2], n_fft_base=16, zero_init=False)

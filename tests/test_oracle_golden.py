@@ -136,6 +136,41 @@ def test_ber_and_miou_edge_cases():
     assert abs(O.miou(m, n) - (0.5 + 2 / 3) / 2) < 1e-12
 
 
+def test_metrics_pinned_to_reference_classes(golden_dir):
+    """BER / MIOU against outputs of the reference's own classes (scripts/evaluate.py:419-516, 575-665),
+    generated by tests/golden/make_golden_metrics.py: the numpy oracle AND the shipped
+    waveverify_amd.metrics restatement, incl. the edge cases at :504-510 and :640-653 and the inputs
+    on which the reference raises RuntimeError (stored as NaN)."""
+    import pytest
+    import torch
+    from waveverify_amd import metrics
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    n_raise = 0
+    for i in range(int(g["n_ber"])):
+        logits, bits, thr, want = g[f"ber{i}_logits"], g[f"ber{i}_bits"], float(g[f"ber{i}_thr"]), float(g[f"ber{i}_out"])
+        mask = g[f"ber{i}_mask"] if f"ber{i}_mask" in g.files else None
+        call = lambda: metrics.BER(threshold=thr)(torch.from_numpy(logits), torch.from_numpy(bits),
+                                                  None if mask is None else torch.from_numpy(mask))
+        if np.isnan(want):
+            n_raise += 1
+            with pytest.raises(RuntimeError):
+                call()
+            continue
+        assert abs(float(call()) - want) < 1e-7, f"metrics.BER case {i}"
+        assert abs(O.ber(logits, bits, mask, threshold=thr) - want) < 1e-7, f"oracle.ber case {i}"
+    for i in range(int(g["n_miou"])):
+        p, q, want = g[f"miou{i}_p"], g[f"miou{i}_g"], float(g[f"miou{i}_out"])
+        args = (torch.from_numpy(p), torch.from_numpy(q)) if int(g[f"miou{i}_torch"]) else (p, q)
+        if np.isnan(want):
+            n_raise += 1
+            with pytest.raises(RuntimeError):
+                metrics.MIOU()(*args)
+            continue
+        assert abs(metrics.MIOU()(*args) - want) < 1e-12, f"metrics.MIOU case {i}"
+        assert abs(O.miou(p, q) - want) < 1e-12, f"oracle.miou case {i}"
+    assert n_raise == 4
+
+
 def test_torch_flavoured_oracle_matches_reference(golden_dir):
     """oracle/wv_oracle_torch.py (what bench.py times as the CPU baseline) is pinned like the numpy one."""
     import torch

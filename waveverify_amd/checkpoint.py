@@ -27,18 +27,51 @@ def _load(path: Path):
     return torch.load(str(path), map_location="cpu", weights_only=True)
 
 
+class UnsafeCheckpointError(RuntimeError):
+    """A .pth file that torch.load(weights_only=True) refuses (it holds pickled objects beyond tensors
+    and plain containers).  Never retried with weights_only=False."""
+
+
+def _candidates(path: Path):
+    files = sorted(path.glob("*.pth"))
+    pref = [f for name in ("best.pth", "latest.pth") for f in files if f.name == name]
+    return pref + [f for f in files if f not in pref]
+
+
+def _scan_atomic(path: Path):
+    """-> (file, checkpoint dict) of the first VALID atomic file in `path` (preference order best.pth,
+    latest.pth, then the rest: core.py:141-168 for the order, core.py:343-356 for 'first file that loads
+    and has a models dict'), or (None, None).  A file the safe loader refuses is remembered: if no
+    valid file exists the refusal is raised instead of silently falling back to the legacy layout."""
+    refused = None
+    for f in _candidates(path):
+        try:
+            ck = _load(f)
+        except Exception as e:                     # unreadable / refused by weights_only
+            if refused is None:
+                refused = (f, e)
+            continue
+        if isinstance(ck, dict) and "models" in ck:
+            return f, ck
+    if refused is not None:
+        f, e = refused
+        raise UnsafeCheckpointError(
+            f"{f} cannot be read with torch.load(weights_only=True) ({type(e).__name__}: {str(e)[:200]}); "
+            "waveverify_amd never unpickles arbitrary objects -- re-save the checkpoint with tensors and "
+            "plain containers only (e.g. drop 'tracker' / argbind objects)")
+    return None, None
+
+
 def find_atomic_checkpoint_file(path: Path) -> Path:
     path = Path(path)
     if path.is_file() and path.suffix == ".pth":
         return path
-    files = sorted(path.glob("*.pth"))
-    if not files:
+    if not list(path.glob("*.pth")):
         raise FileNotFoundError(f"No atomic checkpoint files found in {path}")
-    for preferred in ("best.pth", "latest.pth"):
-        for f in files:
-            if f.name == preferred:
-                return f
-    return files[0]
+    f, _ = _scan_atomic(path)
+    if f is None:
+        raise FileNotFoundError(f"No valid atomic checkpoint found in {path}")
+    return f
 
 
 def is_atomic_checkpoint(path: Path) -> bool:
@@ -46,13 +79,7 @@ def is_atomic_checkpoint(path: Path) -> bool:
     if path.is_file() and path.suffix == ".pth":
         return True
     if path.is_dir():
-        for f in sorted(path.glob("*.pth")):
-            try:
-                ck = _load(f)
-                if isinstance(ck, dict) and "models" in ck:
-                    return True
-            except Exception:
-                continue
+        return _scan_atomic(path)[0] is not None
     return False
 
 
@@ -132,6 +159,9 @@ def apply_argbind_config(kind: str, cfg: NetConfig, flat: Optional[Mapping[str, 
             continue
         name = k[len(prefix):]
         if name in ("res_scale_enc", "res_scale_dec", "dilation_base"):
+            if v is None:                          # Identity scale in the reference (seanet.py:1097-1108)
+                raise NotImplementedError(f"{k}=None (no residual scaling) has no HIP path: only a "
+                                          "numeric scale is supported")
             kw[name] = type(kw[name])(v)
         elif name in unsupported and v != unsupported[name]:
             raise NotImplementedError(

@@ -69,7 +69,8 @@ class HipNet:
         self._h = C.c_void_p()
         ccfg = _fill_config(cfg)
         _lib.check(self._lib.wv_model_create(C.byref(ccfg), C.byref(self._h)), "wv_model_create")
-        self._ws: Optional[torch.Tensor] = None
+        self._ws: Dict[int, torch.Tensor] = {}          # per-stream workspaces
+        self._retired: list = []                        # outgrown buffers, kept alive (see _workspace)
         self.unexpected_keys = []
         with torch.cuda.device(self.device):
             self._load(state_dict, strict)
@@ -124,12 +125,24 @@ class HipNet:
             raise RuntimeError(f"unexpected keys in state dict: {self.unexpected_keys[:5]} ...")
 
     # ------------------------------------------------------------------ plumbing
+    def reserve(self, B: int, T: int) -> None:
+        """Pre-allocate the current stream's workspace for batches up to (B, T) (e.g. before capturing
+        a forward into a HIP graph outside torch.cuda.graph, where a capture must not allocate)."""
+        self._workspace(B, T)
+
     def _workspace(self, B: int, T: int) -> torch.Tensor:
+        """One workspace per (net, stream): calls on different streams never share scratch memory.
+        A buffer that is outgrown is RETIRED, not freed -- a captured graph (or a launch still queued
+        on the stream) may hold its address -- and stays alive as long as the net does."""
         need = int(self._lib.wv_workspace_bytes(self._h, B, T))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = int(torch.cuda.current_stream(self.device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            if ws is not None:
+                self._retired.append(ws)
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
 
     def _prep(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() == 2:
