@@ -147,11 +147,15 @@ int wv_op_set_precision(int precision);   /* precision used by the wv_op_* calls
  *   pre_elu: 1 -> act = ELU, 0 -> identity.
  *   film [B,bands,2] (gamma,beta) or NULL: y = y*gamma+beta per band (seanet.py:928-966);
  *   resid [B,M,Tout] or NULL: y = y*out_scale + resid (seanet.py:272-277).
- * This is the ResnetBlock half (seanet.py:39-116) and the Downsample+FiLM unit (seanet.py:733-772). */
+ * This is the ResnetBlock half (seanet.py:39-116) and the Downsample+FiLM unit (seanet.py:733-772).
+ * Yact [B,M,Tout] or NULL: second output ELU(act_scale * y) -- the NEXT unit's prologue hoisted into
+ *   this epilogue, so that the consumer can stage its operand by LDS-DMA (a pure copy, pre_elu = 0).
+ *   Y may be NULL when only Yact is wanted. */
 int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const float* dw_bias,
                 const float* film, const float* resid, float* Y,
                 int B, int K, int M, int Tin, int ks, int stride, int dilation,
-                float pre_scale, int pre_elu, float out_scale, int bands, void* stream);
+                float pre_scale, int pre_elu, float out_scale, int bands,
+                float* Yact, float act_scale, void* stream);
 
 /* Y = W1x1 @ producer(X) + bias, then optional L2-normalise over channels * sqrt(M).
  *   mode 0: producer = act(pre_scale*X)                                  (plain 1x1)
@@ -160,11 +164,12 @@ int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const floa
  *           (upsample, seanet.py:1112-1138; SConvTranspose1d conv.py:838-881); Tout = Tin*r
  *   accumulate != 0: Y += out_scale * (W @ producer(X))  (SpecBlock add, seanet.py:500-505).
  * Routing mirrors the model's: mode 2 and the accumulate form with M >= 128 run on the pw_dw kernel
- * (ConvTranspose producer in its operand loader / identity stencil with Y as the residual operand). */
+ * (ConvTranspose producer in its operand loader / identity stencil with Y as the residual operand).
+ * Yact / act_scale: as for wv_op_pw_dw (mode 2 and the accumulate form with M >= 128 only, else NULL). */
 int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const float* bias, float* Y,
                 int B, int K, int M, int Tin, int mode, int ks_or_ratio,
                 float pre_scale, int pre_elu, int l2norm, int accumulate, float out_scale,
-                void* stream);
+                float* Yact, float act_scale, void* stream);
 
 /* P[b,f,t] = (log(max(|STFT|,1e-5)) - mean)/std, CausalSTFT magnitude with eps 1e-12
  * (modules/conv.py:1036-1080, seanet.py:479-494). wav [B,1,T]; basis [2F,n_fft] host or NULL
@@ -197,7 +202,6 @@ int wv_model_film(wv_model* m, const float* msg, int msg_rows, float* film, int 
  * aggregated by "<kernel>|<role>" together with its ALGORITHMIC flops and bytes (the per-unit
  * figures of DESIGN.md).  wv_profile_collect(-1, ...) synchronises, snapshots and returns the
  * number of entries; wv_profile_collect(i, ...) reads entry i of that snapshot. */
-int wv_debug_flags(int flags);   /* kernel ablation switches for tools/kbench.py; 0 in production */
 int wv_profile_enable(int on);
 int wv_profile_reset(void);
 int wv_profile_collect(int index, char* name_out, int name_cap, int64_t* launches,

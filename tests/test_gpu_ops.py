@@ -73,6 +73,77 @@ def test_pw_dw(ops, K, M, Tin, ks, stride, dil, epi):
     close(got, ref.astype(np.float32), what=f"pw_dw {epi}")
 
 
+# ---- the LDS-DMA core (csrc/wv_k1.hip): M >= 128, lengths that are multiples of 4 ----------------
+# (K, M, Tin, ks, stride, dil): both window widths (128 / 64 columns), every tile-edge length, M and K
+# that are not multiples of the tile / chunk sizes, every strided stencil of the net.
+DMA_CASES = [
+    (128, 128, 8, 5, 1, 1), (128, 128, 4, 5, 1, 1), (256, 256, 60, 5, 1, 1), (256, 256, 64, 5, 1, 1),
+    (128, 128, 124, 5, 1, 1), (128, 128, 128, 5, 1, 1), (128, 256, 132, 5, 1, 1), (384, 384, 2000, 5, 1, 1),
+    (100, 130, 252, 5, 1, 1), (33, 128, 400, 5, 1, 1), (513, 1024, 52, 5, 1, 1), (768, 768, 400, 5, 1, 1),
+    (160, 288, 1000, 5, 1, 2), (128, 128, 500, 3, 1, 1),
+    (64, 128, 1000, 4, 2, 1), (128, 256, 8000, 8, 4, 1), (256, 512, 2000, 10, 5, 1), (512, 1024, 400, 16, 8, 1),
+    (256, 512, 204, 10, 5, 1), (48, 136, 36, 16, 8, 1),
+]
+
+
+@pytest.mark.parametrize("K,M,Tin,ks,stride,dil", DMA_CASES)
+@pytest.mark.parametrize("mode", ["copy", "copy+resid+act", "elu", "elu+film+act"])
+def test_pw_dw_dma_core(ops, K, M, Tin, ks, stride, dil, mode):
+    """pre_elu = 0: operand staged by LDS-DMA (pure copy); pre_elu = 1: through registers.  With
+    act_scale the epilogue also writes ELU(act_scale * y) (the next unit's hoisted prologue)."""
+    if "resid" in mode and stride != 1:
+        pytest.skip("residual only on stride-1 units")
+    if "film" in mode and M % 4:
+        pytest.skip("FiLM needs channels divisible by the band count")
+    rng = np.random.default_rng(K * 11 + M + Tin + len(mode))
+    B = 2
+    X = rnd(rng, B, K, Tin)
+    w_pw = rnd(rng, M, K, 1, scale=K ** -0.5)
+    w_dw = rnd(rng, M, 1, ks, scale=ks ** -0.5)
+    b_dw = rnd(rng, M, scale=0.1)
+    elu = mode.startswith("elu")
+    pre = 0.8660254 if elu else 1.0
+    h = O.sconv1d(O.elu(X * np.float32(pre)) if elu else X, w_pw, None)
+    ref = O.sconv1d(h, w_dw, b_dw, stride=stride, dilation=dil, groups=M)
+    kw = {}
+    if "resid" in mode:
+        R = rnd(rng, *ref.shape)
+        ref = ref * np.float32(0.37) + R
+        kw.update(resid=cu(R), out_scale=0.37)
+    if "film" in mode:
+        film = rnd(rng, B, 4, 2)
+        bw = M // 4
+        ref = ref * np.repeat(film[:, :, 0], bw, 1)[:, :, None] + np.repeat(film[:, :, 1], bw, 1)[:, :, None]
+        kw.update(film=cu(film), bands=4)
+    ref = ref.astype(np.float32)
+    if "act" in mode:
+        got, gact = ops.pw_dw(cu(X), w_pw, w_dw, b_dw, stride=stride, dilation=dil, pre_scale=pre, pre_elu=elu,
+                              act_scale=0.7071, **kw)
+        close(gact, O.elu(ref * np.float32(0.7071)), what=f"pw_dw {mode} (activated copy)")
+    else:
+        got = ops.pw_dw(cu(X), w_pw, w_dw, b_dw, stride=stride, dilation=dil, pre_scale=pre, pre_elu=elu, **kw)
+    close(got, ref, what=f"pw_dw {mode}")
+
+
+@pytest.mark.parametrize("K,M,Tin,r", [(1536, 768, 52, 8), (384, 256, 332, 4), (192, 128, 1000, 2),
+                                       (768, 384, 400, 5), (66, 130, 64, 3), (96, 128, 4, 4)])
+@pytest.mark.parametrize("pre_elu", [True, False])
+def test_upsample_convtr_pw_dma_core(ops, K, M, Tin, r, pre_elu):
+    """The upsample unit on the LDS-DMA core (weights by DMA, ConvTranspose producer through registers),
+    also with a pre-activated input (pre_elu = 0) and the second, activated output."""
+    rng = np.random.default_rng(K + r + 100)
+    X = rnd(rng, 2, K, Tin)
+    w_ct = rnd(rng, K, 1, 2 * r, scale=(2 * r) ** -0.5)
+    w_pw = rnd(rng, M, K, 1, scale=K ** -0.5)
+    b = rnd(rng, M, scale=0.1)
+    up = O.sconvtr1d_depthwise(O.elu(X * np.float32(0.7071)) if pre_elu else X, w_ct, r)
+    ref = O.sconv1d(up, w_pw, b)
+    got, gact = ops.dw_pw(cu(X), w_pw, b, w_ct, mode=2, ks_or_ratio=r, pre_scale=0.7071 if pre_elu else 1.0,
+                          pre_elu=pre_elu, act_scale=0.9)
+    close(got, ref, what="upsample")
+    close(gact, O.elu(ref * np.float32(0.9)), what="upsample (activated copy)")
+
+
 def test_pw_dw_no_prologue_no_bias(ops):
     """decoder head: 1x1 (128->1536, no bias) -> DW k5 (seanet.py:1070-1091)."""
     rng = np.random.default_rng(5)

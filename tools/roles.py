@@ -20,11 +20,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--flags", type=int, default=0, help="wv_debug_flags value (A/B switches)")
     a = ap.parse_args()
     wv = WaveVerify.random_init(seed=0, device="cuda:0")
-    from waveverify_amd import _lib
-    _lib.load().wv_debug_flags(a.flags)
     gen, det = wv.model.generator, wv.model.detector
     gen.set_precision(a.precision)
     det.set_precision(a.precision)

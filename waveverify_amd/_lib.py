@@ -57,7 +57,6 @@ SIGNATURES = {
     "wv_encoder_forward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_int, _VP,
                                      C.c_size_t, _VP]),
     "wv_model_film": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP]),
-    "wv_debug_flags": (C.c_int, [C.c_int]),
     "wv_profile_enable": (C.c_int, [C.c_int]),
     "wv_profile_reset": (C.c_int, []),
     "wv_profile_collect": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
@@ -65,9 +64,9 @@ SIGNATURES = {
                                      C.POINTER(C.c_double)]),
     "wv_op_pw_dw": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
-                              C.c_int, _VP]),
+                              C.c_int, _VP, C.c_float, _VP]),
     "wv_op_dw_pw": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                              C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, _VP]),
+                              C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, _VP, C.c_float, _VP]),
     "wv_op_stft_logmag": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.c_float, _VP]),
     "wv_op_conv_pre": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int,

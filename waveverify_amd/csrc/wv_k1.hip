@@ -1,0 +1,442 @@
+// K1 on the LDS-DMA core (round 2): Y = epi( DWconv( W1x1 @ B ) + b ), B = activation rows.
+//
+// What changed against the round-1 core (wv_kernels.hip, kept for ragged shapes and M < 128), and why
+// (measured in tools/mfma_peak.hip, profiles/r02_mfma_ceiling_*.txt): the bare v_mfma_f32_32x32x2_f32
+// loop runs 155 TFLOP/s and a loop that re-reads both operands from LDS still 150, but staging the B
+// operand through registers with a scale -> ELU -> transposing ds_write commit cost 15 % of that at any
+// occupancy, and the accumulator -> LDS strip -> stencil epilogue another 5-25 % depending on K.
+//
+//  * Both operands arrive by LDS-DMA (global_load_lds_dwordx4): no staging registers, no VALU, no
+//    s_waitcnt in front of matrix work.  A = packed weights wq[k/4][m][4]; B = the activation rows as
+//    they lie in HBM, [k][t] with time innermost.  Out-of-range columns (causal left pad, right edge)
+//    are DMA'd from a 16-byte zero constant and rows past K are clamped (their weights are zero), so
+//    the loop has no branch.
+//  * B keeps its NATURAL layout in LDS.  One ds_read_b128 of row k gives a lane 4 CONSECUTIVE columns;
+//    the wave's NT = 4 column tiles are therefore interleaved (tile e holds columns 4j + e) instead of
+//    blocked.  Same instruction count as the round-1 k-inner layout (one read feeds 4 MFMAs), no
+//    transposition on the write side -- and after the GEMM a lane ALREADY holds 4 consecutive columns
+//    of each of its rows (acc[0..3][r]), which is exactly what the depth-wise stencil wants: its right
+//    neighbours come from the next lane by DPP (wave_shl:1).  No accumulator round trip through LDS.
+//  * The consumer-side prologue (scale -> ELU) is hoisted into the PRODUCER's epilogue, which writes
+//    ELU(s*y) as a second output (PwDwArgs::Yact): done once per element instead of once per m-tile
+//    workgroup, and the consumer's operand becomes a pure copy.  Units whose input is not available
+//    pre-activated (or whose B operand is computed: the upsample unit's ConvTranspose) stage B through
+//    registers (LDR >= 1) into the same natural layout with two ds_write_b128.
+//
+// Accumulation order over k is the round-1 order (lane half h owns k in [4h,4h+4) U [8+4h,12+4h) of
+// every 16), so results are bit-identical to the round-1 kernel.
+#include <atomic>
+#include <string>
+
+#include "wv_dev.h"
+
+namespace wv {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ float dpp_next(float v) {          // lane i <- lane i+1 (wave_shl:1), lane 63 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+template <int NT_, int BKC_>
+struct K1 {
+    static constexpr int NT = NT_, BN = 32 * NT_, BKC = BKC_, KQ = BKC_ / 4, BM = 128, NTHREADS = 256;
+    static constexpr int A4 = KQ * BM;                      // f32x4 per A stage: [kq][m]
+    static constexpr int B4 = BKC * BN / 4;                 // f32x4 per B stage: [k][t]
+    static constexpr int STAGE4 = A4 + B4;
+    static constexpr int A_DMA = A4 / 256, B_DMA = B4 / 256;   // DMA instructions per wave and chunk
+    static constexpr int CG = BN / 4;                       // 4-column groups per row
+    static constexpr int HLD = BN + 4;                      // generic epilogue: strip row
+    static_assert(A4 % 256 == 0 && B4 % 256 == 0 && (BKC / 2) * CG == 256, "staging maps");
+};
+
+template <int NT> struct NVec;
+template <> struct NVec<4> { typedef f32x4 type; };
+template <> struct NVec<2> { typedef f32x2 type; };
+
+// ---- loaders ----------------------------------------------------------------------------------
+template <class C>
+struct DmaRows {                        // LDR 0: B = X rows, pure copy
+    const float* src; size_t ld; int K; int rbase;
+    __device__ __forceinline__ void init(const float* Xb, int K_, int Tin, int ti0, int wave, int lane) {
+        const int idx = wave * C::B_DMA * 64 + lane;
+        const int col = ti0 + 4 * (idx % C::CG);
+        rbase = idx / C::CG;
+        const bool inr = col >= 0 && col + 3 < Tin;
+        src = inr ? Xb + col : g_zero16;
+        ld = inr ? (size_t)Tin : 0;
+        K = K_;
+    }
+    __device__ __forceinline__ void issue(int c, f32x4* Bst, int wave) const {
+#pragma unroll
+        for (int i = 0; i < C::B_DMA; ++i) {
+            const int k = min(c * C::BKC + rbase + i * (64 / C::CG), K - 1);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)k * ld), (lptr_t)(Bst + (wave * C::B_DMA + i) * 64), 16, 0, 0);
+        }
+    }
+};
+
+template <class C>
+__device__ __forceinline__ void dma_A(const f32x4* wq, int Mp, int m0, int c, f32x4* Ast, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < C::A_DMA; ++i) {
+        const int blk = wave * C::A_DMA + i;                  // 64 fragments = half a kq row
+        const f32x4* s = wq + (size_t)(c * C::KQ + (blk >> 1)) * Mp + m0 + (blk & 1) * 64 + lane;
+        __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(Ast + blk * 64), 16, 0, 0);
+    }
+}
+
+// ---- the GEMM main loop -------------------------------------------------------------------------
+// LB (register path only): init(cg); fetch2(k0, raw); finish2(k0, raw, o[8]) -- the round-1 loader structs.
+template <class C, bool REG, class LB>
+__device__ __forceinline__ void k1_mainloop(f32x16 (&acc)[C::NT], const f32x4* __restrict__ wq, int Mp, int m0,
+                                            const DmaRows<C>& db, LB& lb, int nchunks, f32x4* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, i31 = lane & 31;
+    const int cg = tid % C::CG, kp = tid / C::CG;              // register path: rows 2kp, 2kp+1; columns 4cg..
+    float raw[REG ? LB::NRAW : 1];
+    if (REG) lb.init(cg);
+
+    auto issue = [&](int c, int st) {
+        f32x4* S = smem + st * C::STAGE4;
+        dma_A<C>(wq, Mp, m0, c, S, wave, lane);
+        if (!REG) db.issue(c, S + C::A4, wave);
+    };
+    auto commit = [&](int c, int st) {
+        if constexpr (REG) {
+            float o[8];
+            lb.finish2(c * C::BKC + 2 * kp, raw, o);
+            f32x4* Bq = smem + st * C::STAGE4 + C::A4;
+            Bq[(2 * kp) * C::CG + cg] = f32x4{o[0], o[1], o[2], o[3]};
+            Bq[(2 * kp + 1) * C::CG + cg] = f32x4{o[4], o[5], o[6], o[7]};
+        }
+    };
+    issue(0, 0);
+    if constexpr (REG) { lb.fetch2(2 * kp, raw); commit(0, 0); }
+    __syncthreads();
+    typedef typename NVec<C::NT>::type bvec;
+    for (int c = 0; c < nchunks; ++c) {
+        const f32x4* S = smem + (c & 1) * C::STAGE4;
+        if (c + 1 < nchunks) {
+            issue(c + 1, (c + 1) & 1);
+            if constexpr (REG) lb.fetch2((c + 1) * C::BKC + 2 * kp, raw);
+        }
+        const float* Bf = reinterpret_cast<const float*>(S + C::A4) + C::NT * i31;
+#pragma unroll
+        for (int g = 0; g < C::BKC / 16; ++g) {
+            const f32x4 a0 = S[(4 * g + h) * C::BM + 32 * wave + i31];
+            const f32x4 a1 = S[(4 * g + h + 2) * C::BM + 32 * wave + i31];
+#define WV_K1_STEP(AV, ROW)                                                                        \
+    { const bvec bv = *reinterpret_cast<const bvec*>(Bf + (ROW) * C::BN);                          \
+      _Pragma("unroll") for (int e = 0; e < C::NT; ++e)                                            \
+          acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, bv[e], acc[e], 0, 0, 0); }
+            WV_K1_STEP(a0.x, 16 * g + 4 * h + 0) WV_K1_STEP(a0.y, 16 * g + 4 * h + 1)
+            WV_K1_STEP(a0.z, 16 * g + 4 * h + 2) WV_K1_STEP(a0.w, 16 * g + 4 * h + 3)
+            WV_K1_STEP(a1.x, 16 * g + 8 + 4 * h + 0) WV_K1_STEP(a1.y, 16 * g + 8 + 4 * h + 1)
+            WV_K1_STEP(a1.z, 16 * g + 8 + 4 * h + 2) WV_K1_STEP(a1.w, 16 * g + 8 + 4 * h + 3)
+#undef WV_K1_STEP
+        }
+        if (c + 1 < nchunks) commit(c + 1, (c + 1) & 1);
+        __syncthreads();
+    }
+}
+
+// ---- epilogue -----------------------------------------------------------------------------------
+// EPI 0: the ResnetBlock stencil (k5, stride 1, dilation 1, pad 4) straight from the accumulators.
+// EPI 1: any (ks <= 16, stride, dilation): rows go through a wave-private LDS strip (one 16/8-byte
+//        write per lane and row) and the taps are gathered from there.
+// begin() runs before the GEMM (row table, first residual rows), finish() after it.
+template <class C, int EPI, bool RES>
+struct K1Epi {
+    static constexpr int NT = C::NT, HLD = C::HLD;
+    static constexpr int WLD = EPI == 0 ? 8 : 20;                // row table: taps, bias, FiLM gamma, beta
+    static constexpr int TABLE_FLOATS = C::BM * WLD;
+    static constexpr int RP = RES ? 4 : 0;                       // residual rows in flight per lane
+    typedef typename NVec<NT>::type ovec;
+    int M, m0, b, to0, lane, wave, half, q, o, to;
+    bool act_lane, vec;
+    const float* Rb; float* Yb; float* Ab; float* Wl;
+    ovec res[RES ? 4 : 1];
+
+    __device__ __forceinline__ int row_of(int r) const { return 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half; }
+    __device__ __forceinline__ ovec load_res(const PwDwArgs& p, int r) const {
+        ovec v;
+#pragma unroll
+        for (int e = 0; e < NT; ++e) v[e] = 0.f;
+        const int gm = m0 + row_of(r);
+        if (act_lane && gm < M) {
+            const float* rp = Rb + (size_t)gm * p.Tout + to;
+            if (vec) v = *reinterpret_cast<const ovec*>(rp);
+            else {
+#pragma unroll
+                for (int e = 0; e < NT; ++e)
+                    if (o + e < p.tto && to + e < p.Tout) v[e] = rp[e];
+            }
+        }
+        return v;
+    }
+    __device__ __forceinline__ void store(const PwDwArgs& p, int gm, const float (&y)[NT]) const {
+        const size_t yo = (size_t)gm * p.Tout + to;
+        if (Yb) {
+            if (vec) { ovec v; _Pragma("unroll") for (int e = 0; e < NT; ++e) v[e] = y[e]; *reinterpret_cast<ovec*>(Yb + yo) = v; }
+            else {
+#pragma unroll
+                for (int e = 0; e < NT; ++e)
+                    if (o + e < p.tto && to + e < p.Tout) Yb[yo + e] = y[e];
+            }
+        }
+        if (Ab) {
+            float a[NT];
+#pragma unroll
+            for (int e = 0; e < NT; ++e) a[e] = elu1(y[e] * p.act_scale);
+            if (vec) { ovec v; _Pragma("unroll") for (int e = 0; e < NT; ++e) v[e] = a[e]; *reinterpret_cast<ovec*>(Ab + yo) = v; }
+            else {
+#pragma unroll
+                for (int e = 0; e < NT; ++e)
+                    if (o + e < p.tto && to + e < p.Tout) Ab[yo + e] = a[e];
+            }
+        }
+    }
+    __device__ __forceinline__ void begin(const PwDwArgs& p, float* table, int m0_, int b_, int to0_) {
+        M = p.pw.M; m0 = m0_; b = b_; to0 = to0_;
+        const int tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        half = lane >> 5; q = lane & 31;
+        Wl = table;
+        const size_t bo = (size_t)b * M * p.Tout;
+        Yb = p.Y ? p.Y + bo : nullptr;
+        Ab = p.Yact ? p.Yact + bo : nullptr;
+        Rb = (RES && p.resid) ? p.resid + bo : nullptr;
+        o = NT * q; to = to0 + o;
+        act_lane = o < p.tto && to < p.Tout;
+        vec = act_lane && to + NT - 1 < p.Tout && o + NT - 1 < p.tto && (p.Tout % NT) == 0;
+        const int bw = p.film ? (M / p.bands) : 1;
+        const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
+        for (int m = tid; m < C::BM; m += C::NTHREADS) {
+            const int gm = m0 + m;
+            float* row = Wl + m * WLD;
+            constexpr int NTAP = EPI == 0 ? 5 : 16;
+#pragma unroll
+            for (int i = 0; i < NTAP; ++i) row[i] = (gm < M && i < p.ks) ? p.dw_w[(size_t)gm * p.ks + i] : 0.f;
+            float gam = 1.f, bet = 0.f;
+            if (filmb && gm < M) { const int band = gm / bw; gam = filmb[2 * band]; bet = filmb[2 * band + 1]; }
+            row[NTAP] = (gm < M && p.dw_b) ? p.dw_b[gm] : 0.f;
+            row[NTAP + 1] = gam; row[NTAP + 2] = bet;
+            if (EPI != 0) row[19] = 0.f;
+        }
+        if constexpr (RES) {
+            if (EPI == 0 && Rb) {
+#pragma unroll
+                for (int r = 0; r < RP; ++r) res[r] = load_res(p, r);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void finish(f32x16 (&acc)[NT], const PwDwArgs& p, float* strips) {
+        if constexpr (EPI == 0) {
+            constexpr int NSH = 4 / NT;                          // lane shifts that bring 4 more columns
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // columns NT*q .. NT*q + NT + 3 of this row: own registers + the next lane(s) by DPP.
+                // (All 64 lanes execute the DPP moves: no divergence up to here.)
+                float hh[NT + 4];
+                float cur[NT];
+#pragma unroll
+                for (int e = 0; e < NT; ++e) { cur[e] = acc[e][r]; hh[e] = cur[e]; }
+#pragma unroll
+                for (int s = 1; s <= NSH; ++s) {
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) { cur[e] = dpp_next(cur[e]); hh[s * NT + e] = cur[e]; }
+                }
+                const int row = row_of(r), gm = m0 + row;
+                ovec rr;
+#pragma unroll
+                for (int e = 0; e < NT; ++e) rr[e] = 0.f;
+                if constexpr (RES) {
+                    if (Rb) {
+                        rr = res[r % RP];
+                        if (r + RP < 16) res[r % RP] = load_res(p, r + RP);
+                    }
+                }
+                if (act_lane && gm < M) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wl + row * 8);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wl + row * 8 + 4);
+                    float y[NT];
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) {
+                        float v = w1.y;                                          // bias
+                        v = fmaf(w0.x, hh[e], v); v = fmaf(w0.y, hh[e + 1], v); v = fmaf(w0.z, hh[e + 2], v);
+                        v = fmaf(w0.w, hh[e + 3], v); v = fmaf(w1.x, hh[e + 4], v);
+                        v = fmaf(v, w1.z, w1.w);                                 // FiLM (1, 0 when off)
+                        if (RES && Rb) v = fmaf(v, p.out_scale, rr[e]);
+                        y[e] = v;
+                    }
+                    store(p, gm, y);
+                }
+            }
+        } else {
+            float* Hw = strips + wave * (4 * HLD);
+            const int ks = p.ks;
+            const int no = (p.tto + 31) / 32;                     // consecutive outputs per lane
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* strip = Hw + (r & 1) * 2 * HLD;
+                ovec hv;
+#pragma unroll
+                for (int e = 0; e < NT; ++e) hv[e] = acc[e][r];
+                *reinterpret_cast<ovec*>(strip + half * HLD + NT * q) = hv;
+                const int row = row_of(r), gm = m0 + row;
+                if (gm >= M) continue;
+                const float* wt = Wl + row * WLD;
+                const float bias = wt[16], gam = wt[17], bet = wt[18];
+                const float* hrow = strip + half * HLD + p.off;
+                const size_t ro = (size_t)gm * p.Tout + to0;
+                for (int e = 0; e < no; ++e) {
+                    const int oo = q * no + e;
+                    if (oo >= p.tto || to0 + oo >= p.Tout) break;
+                    const float* hp = hrow + oo * p.stride;
+                    float y = bias;
+                    for (int i = 0; i < ks; ++i) y = fmaf(wt[i], hp[i * p.dil], y);
+                    y = fmaf(y, gam, bet);
+                    if (RES && Rb) y = fmaf(y, p.out_scale, Rb[ro + oo]);
+                    if (Yb) Yb[ro + oo] = y;
+                    if (Ab) Ab[ro + oo] = elu1(y * p.act_scale);
+                }
+            }
+        }
+    }
+};
+
+// LDR: 0 DMA copy | 1 registers, scale -> ELU | 2,3,4,5 registers, DW ConvTranspose producer (RM 4,2,1,0)
+template <int LDR> struct LdrSel { typedef RowPairLoader type; };
+template <> struct LdrSel<2> { typedef ConvTrPair<4> type; };
+template <> struct LdrSel<3> { typedef ConvTrPair<2> type; };
+template <> struct LdrSel<4> { typedef ConvTrPair<1> type; };
+template <> struct LdrSel<5> { typedef ConvTrPair<0> type; };
+
+template <class C, int EPI, int LDR, bool RES>
+__global__ __launch_bounds__(256, (LDR == 0 && C::NT == 4) ? 4 : 3) void k1_kernel(PwDwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const TileId tile = decode_tile(p);
+    if (!tile.valid) return;
+    const int m0 = tile.m_tile * C::BM;
+    const int b = tile.b;
+    const int K = p.pw.K;
+    const int to0 = tile.t_tile * p.tto;
+    const int ti0 = to0 * p.stride - p.pad - p.off;
+    constexpr int STAGE_FLOATS = 2 * C::STAGE4 * 4;
+    K1Epi<C, EPI, RES> epi;
+    epi.begin(p, smem + STAGE_FLOATS, m0, b, to0);
+    f32x16 acc[C::NT];
+#pragma unroll
+    for (int e = 0; e < C::NT; ++e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+    const float* Xb = p.X + (size_t)b * K * p.Tin;
+    const int nchunks = (K + C::BKC - 1) / C::BKC;
+    const f32x4* wq = reinterpret_cast<const f32x4*>(p.pw.wq);
+    DmaRows<C> db{};
+    if constexpr (LDR == 0) {
+        db.init(Xb, K, p.Tin, ti0, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
+        RowPairLoader none{};
+        k1_mainloop<C, false>(acc, wq, p.pw.Mp, m0, db, none, nchunks, reinterpret_cast<f32x4*>(smem));
+    } else if constexpr (LDR == 1) {
+        RowPairLoader lb{Xb, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
+        k1_mainloop<C, true>(acc, wq, p.pw.Mp, m0, db, lb, nchunks, reinterpret_cast<f32x4*>(smem));
+    } else {
+        typename LdrSel<LDR>::type lb{Xb, p.ct_w, p.ct_wt, K, p.pw.Kp, p.Tin, p.Tout, ti0, p.ratio, p.pre_scale, p.pre_elu, 0, 0, {}, {}};
+        k1_mainloop<C, true>(acc, wq, p.pw.Mp, m0, db, lb, nchunks, reinterpret_cast<f32x4*>(smem));
+    }
+    epi.finish(acc, p, smem);              // strips (EPI 1) alias the stages: the main loop ended with a barrier
+}
+
+// ---- launcher -----------------------------------------------------------------------------------
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Shapes this core covers; everything else stays on the round-1 kernel (launch_pw_dw falls through, also
+// when launch_k1 answers hipErrorNotSupported).
+bool k1_supported(const PwDwArgs& a) {
+    if (!a.pw.wq || a.pw.Mp % 128 || a.prec != PREC_F32) return false;
+    if (a.pw.M < 128 || a.pw.M == 192) return false;         // narrow layers: 32/64/96-row tiles of the round-1 core
+    if ((a.Tin & 3) || !aligned16(a.X) || a.pw.K < 1) return false;
+    if (a.Y && !aligned16(a.Y)) return false;
+    if (a.Yact && !aligned16(a.Yact)) return false;
+    if (a.resid && !aligned16(a.resid)) return false;
+    if (a.ks < 1 || a.ks > 16 || (a.ks - 1) * a.dil + 1 + 3 > 64) return false;
+    if (a.ct_w && a.ratio == 1) return false;                // degenerate ratio: rare, round-1 path
+    return true;
+}
+
+template <class C, int EPI, int LDR, bool RES>
+static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
+    const size_t smem = 2 * (size_t)C::STAGE4 * 16 + (size_t)K1Epi<C, EPI, RES>::TABLE_FLOATS * sizeof(float);
+    static_assert(4 * 4 * C::HLD <= 2 * C::STAGE4 * 4, "strips alias the stages");
+    a.num_m = (a.pw.M + C::BM - 1) / C::BM;
+    a.num_t = (a.Tout + a.tto - 1) / a.tto;
+    a.stagger = 0; a.first_gen = 0;
+    const long long n_act = (long long)a.num_t * a.B;
+    const long long nblk = ((n_act + 7) / 8) * 8 * a.num_m;
+    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    std::string name;
+    if (prof::enabled())
+        name = std::string(base) + "<128," + std::to_string(C::BN) + (LDR == 0 ? ",dma>" : ",reg>");
+    const double M = a.pw.M, K = a.pw.K, Bd = a.B;
+    const double outs = (a.Y ? 1.0 : 0.0) + (a.Yact ? 1.0 : 0.0) + (a.resid ? 1.0 : 0.0);
+    const double flops = a.ct_w ? 2.0 * Bd * a.Tout * K * (M + 2.0) : 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout);
+    prof::Scope ps(s, name.c_str(), flops, 4.0 * Bd * (K * a.Tin + M * a.Tout * outs));
+    hipLaunchKernelGGL((k1_kernel<C, EPI, LDR, RES>), dim3((unsigned)nblk), dim3(256), smem, s, a);
+    return hipGetLastError();
+}
+
+bool pw_dw_geometry(PwDwArgs& a, int BN);                     // wv_kernels.hip
+
+template <class C, int EPI, bool RES>
+static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
+    if (a.ct_w) {
+        if constexpr (EPI == 0 && !RES) {
+            if (a.ratio % 4 == 0) return k1_run<C, 0, 2, false>(a, s, "convtr_pw");
+            if (a.ratio == 2) return k1_run<C, 0, 3, false>(a, s, "convtr_pw");
+            return k1_run<C, 0, 5, false>(a, s, "convtr_pw");
+        }
+        return hipErrorInvalidValue;
+    }
+    const char* base = a.spec_add ? "spec_add" : (EPI == 0 ? (RES ? "pw_dw_k5" : "pw_dw_k5_nr") : "pw_dw");
+    if (a.pre_elu || a.pre_scale != 1.f) return k1_run<C, EPI, 1, RES>(a, s, base);
+    return k1_run<C, EPI, 0, RES>(a, s, base);
+}
+
+hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
+    PwDwArgs a = a0;
+    const bool k5 = a.ks == 5 && a.stride == 1 && a.dil == 1 && a.pad == 4;
+    // window width: 64 columns when that computes fewer columns (tile quantisation) or the layer is short
+    const int need = (a.ks - 1) * a.dil + 1;
+    bool narrow = a.Tin + a.pad + 3 <= 64;
+    if (!narrow) {
+        PwDwArgs g128 = a, g64 = a;
+        if (pw_dw_geometry(g128, 128) && pw_dw_geometry(g64, 64)) {
+            const long long c128 = (long long)((a.Tout + g128.tto - 1) / g128.tto) * 128;
+            const long long c64 = (long long)((a.Tout + g64.tto - 1) / g64.tto) * 64;
+            if (c64 * 100 < c128 * 95) narrow = true;
+        }
+    }
+    (void)need;
+    if (!pw_dw_geometry(a, narrow ? 64 : 128)) return hipErrorNotSupported;
+    // every tile's window must start on a multiple of 4 samples (16-byte DMA source addresses)
+    if ((a.tto * a.stride) % 4 != 0 || (a.pad + a.off) % 4 != 0) return hipErrorNotSupported;
+    const bool res = a.resid != nullptr;
+    if (narrow) {
+        using C = K1<2, 32>;
+        if (k5) return res ? k1_pick_ldr<C, 0, true>(a, s) : k1_pick_ldr<C, 0, false>(a, s);
+        return res ? k1_pick_ldr<C, 1, true>(a, s) : k1_pick_ldr<C, 1, false>(a, s);
+    }
+    using C = K1<4, 16>;
+    if (k5) return res ? k1_pick_ldr<C, 0, true>(a, s) : k1_pick_ldr<C, 0, false>(a, s);
+    return res ? k1_pick_ldr<C, 1, true>(a, s) : k1_pick_ldr<C, 1, false>(a, s);
+}
+
+}  // namespace wv

@@ -23,7 +23,8 @@ struct PwWeight {
     // fragment (kb, m) = W[m][8kb .. 8kb+7]; Kh = roundup(K, 32), zero padded.  May be null.
     const void* wh = nullptr;
     int Kh = 0;
-    // k-inner f32 layout for the row-strip core: wq[Kp/4][Mp][4] (W[m][4kq .. 4kq+3]); may be null
+    // k-inner f32 layout for the row-strip cores: wq[roundup(K,32)/4][Mp][4] (W[m][4kq .. 4kq+3], zero padded;
+    // the LDS-DMA core reads whole 32-deep chunks); may be null
     const float* wq = nullptr;
 };
 constexpr int BKH = 32;         // K-chunk of the split-f16 core
@@ -61,11 +62,10 @@ struct PwDwArgs {
     int pre_elu;
     float out_scale;
     int bands, film_stride;
-    float post_scale;     // optional activation of the OUTPUT (consumer's prologue hoisted):
-    int post_elu;         //   y = post_elu ? ELU(post_scale*y) : y
+    float* Yact;          // optional SECOND output [B, M, Tout] = ELU(act_scale * y): the consumer's prologue
+    float act_scale;      //   hoisted into the producer, so that the consumer stages its operand by LDS-DMA
+                          //   (a pure copy).  Y may be null when only the activated copy is consumed.
     int prec;             // Precision of the GEMM core
-    int dbg;              // ablation flags (tools/kbench.py): 1 skip stencil epilogue, 2 skip MFMA,
-                          // 4 skip X loads, 8 skip H spill
     int num_m, num_t;         // tile counts (filled by launch_pw_dw; XCD-aware 1-D grid)
     int stagger, first_gen;   // de-phasing of the first workgroup generation (see kernel)
     int tto, off;         // filled by launch_pw_dw: outputs per time tile; stencil offset inside
@@ -76,6 +76,10 @@ struct PwDwArgs {
     const float* ct_wt;   // the same taps transposed and zero padded, [2*ratio][pw.Kp] (pack_ct_wt)
 };
 hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s);
+// the LDS-DMA core (wv_k1.hip); launch_pw_dw routes to it when k1_supported()
+bool k1_supported(const PwDwArgs& a);
+hipError_t launch_k1(const PwDwArgs& a, hipStream_t s);   // hipErrorNotSupported: use the round-1 kernel
+bool pw_dw_geometry(PwDwArgs& a, int BN);                 // time-tile geometry shared by both cores
 // host: ConvTranspose taps [K][2r] -> [2r][Kp], zero padded
 inline std::vector<float> pack_ct_wt(const float* w, int K, int Kp, int ratio) {
     std::vector<float> t((size_t)2 * ratio * Kp, 0.f);
@@ -170,7 +174,6 @@ hipError_t launch_film(const FilmArgs& a, hipStream_t s);
 // ---- optional per-launch profiling with HIP events on the launch stream ---------------------
 // When enabled every launcher brackets its kernel with an event pair; entries aggregate by
 // "<kernel symbol>|<role>".  Roles are set by the model plan (e.g. "enc.down_film").
-void set_debug_flags(int flags);
 namespace prof {
 void enable(bool on);
 bool enabled();
@@ -178,6 +181,15 @@ void reset();
 void set_role(const char* role);
 struct Entry { const char* name; long long launches; double ms, flops, bytes; };
 int collect(Entry* out, int cap);   // synchronises the recorded events; returns entry count
+// RAII bracket used by every launcher: records an event pair around the launch when profiling is on
+// (thread-safe; skipped on a capturing stream).
+struct Scope {
+    hipStream_t s; void* ev_a = nullptr; void* ev_b = nullptr; int key_ = -1; bool armed = false;
+    Scope(hipStream_t st, const char* kernel, double flops, double bytes);
+    ~Scope();
+    Scope(const Scope&) = delete;
+    Scope& operator=(const Scope&) = delete;
+};
 }  // namespace prof
 
 }  // namespace wv

@@ -11,20 +11,10 @@
 // [Kp][Mp] (k-major, so an MFMA A-fragment is 32 consecutive floats), B = activations
 // [K][time] (k-major too), D[m][t].  64-lane wavefronts, 4 waves per workgroup.
 #include "wv_kernels.h"
+#include "wv_dev.h"
 
 namespace wv {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int NT_ = 256;   // threads per workgroup
-
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
-__device__ __forceinline__ float act(float x, float scale, int elu) {
-    x *= scale;
-    return elu ? elu1(x) : x;
-}
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // ------------------------------------------------------------------------------------------
 // GEMM core.  Tile BM x BN per workgroup, WM x WN waves, each wave MT x NT MFMA tiles of 32x32.
@@ -69,19 +59,13 @@ struct NoSide { __device__ __forceinline__ void operator()(int, const float*) co
 // chunk's barrier); used by the STFT for its two vector-side rows.
 template <class T, class LA, class LB, class SD = NoSide>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::MT][T::NT], const LA& la, LB& lb,
-                                              int nchunks, float* smem, int dbg = 0, SD&& side = SD()) {
+                                              int nchunks, float* smem, SD&& side = SD()) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN;
     const int bcol = (tid % T::B_TPR) * 4, bk0 = tid / T::B_TPR;
     float4 ra[T::A_PER];
     float rb[T::B_PER][4 * LB::NRAW];
-    if (dbg & 4) {
-#pragma unroll
-        for (int r = 0; r < T::B_PER; ++r)
-#pragma unroll
-            for (int i = 0; i < 4 * LB::NRAW; ++i) rb[r][i] = 0.25f;
-    }
     lb.init(bcol);
 
     auto fetch = [&](int c) {
@@ -91,12 +75,10 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::MT][T::NT], const
             if (T::A_VEC % T::NTHREADS == 0 || e4 < T::A_VEC)
                 ra[r] = la.load4(c * BK + e4 / (T::BM / 4), (e4 % (T::BM / 4)) * 4);
         }
-        if (!(dbg & 4)) {
 #pragma unroll
-            for (int r = 0; r < T::B_PER; ++r)
-                if (BK % T::BKSTEP == 0 || bk0 + r * T::BKSTEP < BK)
-                    lb.fetch(c * BK + bk0 + r * T::BKSTEP, rb[r]);
-        }
+        for (int r = 0; r < T::B_PER; ++r)
+            if (BK % T::BKSTEP == 0 || bk0 + r * T::BKSTEP < BK)
+                lb.fetch(c * BK + bk0 + r * T::BKSTEP, rb[r]);
     };
     auto commit = [&](int c, float* buf) {
         float* As = buf;
@@ -124,29 +106,21 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::MT][T::NT], const
     for (int c = 0; c < nchunks; ++c) {
         const float* As = smem + (c & 1) * T::STAGE;
         const float* Bs = As + BK * T::BM;
-        if (!(dbg & 16) && c + 1 < nchunks) fetch(c + 1);
-        if (!(dbg & 2))
+        if (c + 1 < nchunks) fetch(c + 1);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[T::MT], b[T::NT];
-            if (dbg & 8) {                       // ablation: operands from registers, no LDS reads
-#pragma unroll
-                for (int i = 0; i < T::MT; ++i) a[i] = 0.5f + kk;
-#pragma unroll
-                for (int j = 0; j < T::NT; ++j) b[j] = 0.25f + j;
-            } else {
 #pragma unroll
             for (int i = 0; i < T::MT; ++i) a[i] = As[(kk + arow) * T::BM + acol + i * 32];
 #pragma unroll
             for (int j = 0; j < T::NT; ++j) b[j] = Bs[(kk + arow) * T::BN + bcol_f + j * 32];
-            }
 #pragma unroll
             for (int i = 0; i < T::MT; ++i)
 #pragma unroll
                 for (int j = 0; j < T::NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (!(dbg & 16) && c + 1 < nchunks) commit(c + 1, smem + ((c + 1) & 1) * T::STAGE);
+        if (c + 1 < nchunks) commit(c + 1, smem + ((c + 1) & 1) * T::STAGE);
         side(c, Bs);
         __syncthreads();
     }
@@ -239,135 +213,9 @@ struct QT {
     static_assert(T::NTHREADS % CG == 0, "a thread keeps its column group");
 };
 
-// B operand for the k-inner core: a thread owns a 2(k) x 4(time) micro-tile -- two 16-byte row
-// loads, exactly the coalescing of a plain row copy -- and scatters it as four 8-byte halves of
-// the [kq][col] fragments.  Column slots are XOR-swizzled inside each group of 4 so the 16 lanes
-// of a ds_write_b64 group land on 8 distinct bank pairs (2-way, free) instead of 2 (8-way).
-__device__ __forceinline__ int q_slot(int n) { return (n & ~3) | ((n & 3) ^ ((n >> 3) & 3)); }
-
-struct RowPairLoader {
-    const float* base; int K, ld, ncols, c0; float scale; int elu;
-    const float* p; int c; bool full, vec;
-    __device__ __forceinline__ void init(int cg) {
-        c = c0 + 4 * cg;
-        full = c >= 0 && c + 3 < ncols;
-        vec = full && ((ld & 3) == 0) && ((c & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
-        p = base + c;
-    }
-    __device__ __forceinline__ void fetch2(int k0, float (&raw)[8]) const {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k = k0 + i;
-            if (k < K && vec) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)k * ld);
-                raw[4 * i] = v.x; raw[4 * i + 1] = v.y; raw[4 * i + 2] = v.z; raw[4 * i + 3] = v.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    raw[4 * i + j] = (k < K && c + j >= 0 && c + j < ncols) ? p[(size_t)k * ld + j] : 0.f;
-            }
-        }
-    }
-    __device__ __forceinline__ float xform(float v) const { return act(v, scale, elu); }
-    static constexpr int NRAW = 8;
-    // raw 2(k) x 4(t) micro-tile -> staged values o[4*i + j] = B[k0+i][t+j]
-    __device__ __forceinline__ void finish2(int, const float (&raw)[8], float (&o)[8]) const {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = xform(raw[i]);
-    }
-};
-
-// B operand of the upsample unit for the k-inner core: act(s*x) -> depth-wise ConvTranspose1d(2r, r),
-// right-trimmed (modules/conv.py SConvTranspose1d causal trim), produced on the fly:
-//   B[k][t] = a(x[k][l]) * w[k][ph] + a(x[k][l-1]) * w[k][ph + r],   l = t / r, ph = t % r.
-// A thread owns 2 channels x 4 consecutive output times t (t0 a multiple of 4).  RM picks the
-// addressing: RM = 4 (r % 4 == 0): the four times share l and their taps are one aligned float4
-// pair -> 2 scalar + 2 vector loads and 2 activations per channel;  RM = 2 (r == 2): three inputs
-// and one float4 of taps;  RM = 0: any ratio, per-time scalar gathers.  Loads go to clamped
-// (always valid) addresses and the zero-selects happen in finish2, at commit time, so that no
-// s_waitcnt sits between issuing the loads and the matrix work.
-template <int RM>
-struct ConvTrPair {
-    static constexpr int NRAW = RM == 4 ? 20 : (RM == 2 ? 14 : (RM == 1 ? 14 : 22));
-    const float* Xb; const float* ct_w; const float* ct_wt; int K, Kt, Tin, Tout, c0, ratio; float scale; int elu;
-    int t, l0, ph[4], dl[4];
-    __device__ __forceinline__ void init(int cg) {
-        t = c0 + 4 * cg;                                          // first output time of the micro-tile
-        l0 = min(max(t, 0) / ratio, Tin - 1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int te = max(t + e, 0), le = te / ratio;
-            ph[e] = te - le * ratio;
-            dl[e] = min(le, Tin - 1) - l0;                         // 0 or 1 for ratio >= 2
-        }
-    }
-    __device__ __forceinline__ void fetch2(int k0, float (&raw)[NRAW]) const {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k = min(k0 + i, K - 1);
-            const float* xr = Xb + (size_t)k * Tin;
-            const float* w = ct_w + (size_t)k * 2 * ratio;
-            float* r = raw + i * (NRAW / 2);
-            if (RM == 4) {                                         // one input pair, aligned tap vectors
-                r[0] = xr[l0]; r[1] = xr[max(l0 - 1, 0)];
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + ph[0]);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + ph[0] + ratio);
-                r[2] = w0.x; r[3] = w0.y; r[4] = w0.z; r[5] = w0.w;
-                r[6] = w1.x; r[7] = w1.y; r[8] = w1.z; r[9] = w1.w;
-            } else if (RM == 2) {                                  // inputs l0-1, l0, l0+1; w = (w0[0], w0[1], w1[0], w1[1])
-                r[0] = xr[max(l0 - 1, 0)]; r[1] = xr[l0]; r[2] = xr[min(l0 + 1, Tin - 1)];
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(w);
-                r[3] = wv.x; r[4] = wv.y; r[5] = wv.z; r[6] = wv.w;
-            } else if (RM == 1) {                                  // ratio 1: five inputs, two taps
-#pragma unroll
-                for (int e = 0; e < 5; ++e) r[e] = xr[min(max(l0 - 1 + e, 0), Tin - 1)];
-                r[5] = w[0]; r[6] = w[1];
-            } else {                                               // any ratio >= 2: three inputs, per-time taps
-                r[0] = xr[max(l0 - 1, 0)]; r[1] = xr[l0]; r[2] = xr[min(l0 + 1, Tin - 1)];
-            }
-        }
-        if (RM == 0) {
-            // taps from the transposed copy ct_wt[2r][Kt] (channels contiguous): the two channel rows
-            // of a (tap, time) pair are one 8-byte load (k0 is even, Kt is even)
-            const int k = min(k0, Kt - 2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x2 a = *reinterpret_cast<const f32x2*>(ct_wt + (size_t)ph[e] * Kt + k);
-                const f32x2 b = *reinterpret_cast<const f32x2*>(ct_wt + (size_t)(ph[e] + ratio) * Kt + k);
-                raw[3 + e] = a.x; raw[NRAW / 2 + 3 + e] = a.y;
-                raw[7 + e] = b.x; raw[NRAW / 2 + 7 + e] = b.y;
-            }
-        }
-    }
-    __device__ __forceinline__ void finish2(int k0, const float (&raw)[NRAW], float (&o)[8]) const {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool kv = k0 + i < K;
-            const float* r = raw + i * (NRAW / 2);
-            float a[5];                                            // activated inputs (each computed once)
-            constexpr int NX = RM == 4 ? 2 : (RM == 1 ? 5 : 3);
-#pragma unroll
-            for (int e = 0; e < NX; ++e) a[e] = act(r[e], scale, elu);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int te = t + e;
-                const bool ok = kv && te >= 0 && te < Tout;
-                float xa, xb, w0, w1;
-                if (RM == 4) { xa = a[0]; xb = a[1]; w0 = r[2 + e]; w1 = r[6 + e]; }
-                else if (RM == 2) { xa = a[1 + (e >> 1)]; xb = a[e >> 1]; w0 = r[3 + (e & 1)]; w1 = r[5 + (e & 1)]; }
-                else if (RM == 1) { xa = a[1 + e]; xb = a[e]; w0 = r[5]; w1 = r[6]; }
-                else { xa = dl[e] ? a[2] : a[1]; xb = dl[e] ? a[1] : a[0]; w0 = r[3 + e]; w1 = r[7 + e]; }
-                const float v = fmaf(te >= ratio ? xb : 0.f, w1, xa * w0);
-                o[4 * i + e] = ok ? v : 0.f;
-            }
-        }
-    }
-};
-
 template <class T, class LB>
 __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f32x4* __restrict__ wq,
-                                                int Mp, int m0, LB& lb, int nchunks, f32x4* smem,
-                                                int dbg = 0) {
+                                                int Mp, int m0, LB& lb, int nchunks, f32x4* smem) {
     using Q = QT<T>;
     static_assert(T::WN == 1 && T::MT == 1, "row-strip tile");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -417,8 +265,8 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const f32x4* Bs = smem + (c & 1) * Q::NB;
-        if (!(dbg & 16) && c + 1 < nchunks) fetch(c + 1);
-        if (!(dbg & 2)) {
+        if (c + 1 < nchunks) fetch(c + 1);
+        {
             f32x4 b0[T::NT], b1[T::NT];
 #pragma unroll
             for (int j = 0; j < T::NT; ++j) {
@@ -432,25 +280,10 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
             WV_QSTEP(a1.x, b1, x) WV_QSTEP(a1.y, b1, y) WV_QSTEP(a1.z, b1, z) WV_QSTEP(a1.w, b1, w)
 #undef WV_QSTEP
         }
-        if (!(dbg & 16) && c + 1 < nchunks) commit(c + 1, smem + ((c + 1) & 1) * Q::NB);
+        if (c + 1 < nchunks) commit(c + 1, smem + ((c + 1) & 1) * Q::NB);
         a0 = an0; a1 = an1;
         __syncthreads();
     }
-}
-
-// XCD-aware tile mapping for K1.  Workgroup ids are dealt round-robin over the 8 XCDs (private
-// L2 each), so ids L, L+8, L+16, ... share an L2.  We enumerate, per XCD, the m-tiles of ONE
-// activation tile back to back: the X window is fetched into that L2 once and reused by all
-// M/BM m-tiles instead of crossing the fabric M/BM times.  (Speed only: any placement is correct.)
-struct TileId { int m_tile, t_tile, b; bool valid; };
-__device__ __forceinline__ TileId decode_tile(const PwDwArgs& p) {
-    const unsigned L = blockIdx.x;
-    const unsigned xcd = L & 7, j = L >> 3;
-    const unsigned m_tile = j % p.num_m, n_idx = (j / p.num_m) * 8 + xcd;
-    TileId t;
-    t.valid = n_idx < (unsigned)p.num_t * p.B;
-    t.m_tile = m_tile; t.t_tile = n_idx % p.num_t; t.b = n_idx / p.num_t;
-    return t;
 }
 
 // K1 epilogue (shared by the f32 and the split-f16 GEMM cores).  begin() runs BEFORE the GEMM:
@@ -566,15 +399,28 @@ struct PwDwEpi {
                         v = fmaf(w0.w, h[e + 3], v); v = fmaf(w1.x, h[e + 4], v);
                         v = fmaf(v, w1.z, w1.w);                                 // FiLM (1, 0 when off)
                         if (RP > 0 && Rb) v = fmaf(v, p.out_scale, rv[e]);
-                        if (p.post_elu) v = elu1(v * p.post_scale);
                         y[e] = v;
                     }
-                    float* yp = Yb + (size_t)gm * p.Tout + to;
-                    if (vec) *reinterpret_cast<float4*>(yp) = make_float4(y[0], y[1], y[2], y[3]);
-                    else {
+                    const size_t yo = (size_t)gm * p.Tout + to;
+                    if (p.Y) {
+                        float* yp = Yb + yo;
+                        if (vec) *reinterpret_cast<float4*>(yp) = make_float4(y[0], y[1], y[2], y[3]);
+                        else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (o + e < p.tto && to + e < p.Tout) yp[e] = y[e];
+                            for (int e = 0; e < 4; ++e)
+                                if (o + e < p.tto && to + e < p.Tout) yp[e] = y[e];
+                        }
+                    }
+                    if (p.Yact) {                                   // second output: the consumer's ELU(s*y)
+                        float* ya = p.Yact + (size_t)b * M * p.Tout + yo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = elu1(y[e] * p.act_scale);
+                        if (vec) *reinterpret_cast<float4*>(ya) = make_float4(y[0], y[1], y[2], y[3]);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (o + e < p.tto && to + e < p.Tout) ya[e] = y[e];
+                        }
                     }
                 }
             }
@@ -594,6 +440,7 @@ struct PwDwEpi {
                 const float bias = wt[16], gam = wt[17], bet = wt[18];
                 const float* hrow = strip + half * HLD + p.off;
                 float* yrow = Yb + (size_t)gm * p.Tout + to0;
+                float* arow = p.Yact ? p.Yact + ((size_t)b * M + gm) * p.Tout + to0 : nullptr;
                 const float* rrow = Rb ? Rb + (size_t)gm * p.Tout + to0 : nullptr;
                 if (pair2) {
                     const int o0 = 2 * q;
@@ -605,8 +452,8 @@ struct PwDwEpi {
                         float y1 = fmaf(wt[3], hc.y, fmaf(wt[2], hc.x, fmaf(wt[1], hb.y, fmaf(wt[0], hb.x, bias))));
                         y0 = fmaf(y0, gam, bet); y1 = fmaf(y1, gam, bet);
                         if (rrow) { y0 = fmaf(y0, p.out_scale, rrow[o0]); y1 = fmaf(y1, p.out_scale, rrow[o0 + 1]); }
-                        if (p.post_elu) { y0 = elu1(y0 * p.post_scale); y1 = elu1(y1 * p.post_scale); }
-                        *reinterpret_cast<f32x2*>(yrow + o0) = f32x2{y0, y1};
+                        if (p.Y) *reinterpret_cast<f32x2*>(yrow + o0) = f32x2{y0, y1};
+                        if (arow) *reinterpret_cast<f32x2*>(arow + o0) = f32x2{elu1(y0 * p.act_scale), elu1(y1 * p.act_scale)};
                         continue;
                     }
                 }
@@ -618,8 +465,8 @@ struct PwDwEpi {
                     for (int i = 0; i < ks; ++i) y = fmaf(wt[i], h[i * p.dil], y);
                     y = fmaf(y, gam, bet);
                     if (rrow) y = fmaf(y, p.out_scale, rrow[oo]);
-                    if (p.post_elu) y = elu1(y * p.post_scale);
-                    yrow[oo] = y;
+                    if (p.Y) yrow[oo] = y;
+                    if (arow) arow[oo] = elu1(y * p.act_scale);
                 }
             }
         }
@@ -672,13 +519,12 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
     if constexpr (RM < 0) {
         RowPairLoader lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
         gemm_mainloop_q<T>(acc, reinterpret_cast<const f32x4*>(p.pw.wq), p.pw.Mp, m0, lb, p.pw.Kp / BK,
-                           reinterpret_cast<f32x4*>(smem), p.dbg);
+                           reinterpret_cast<f32x4*>(smem));
     } else {
         ConvTrPair<RM> lb{p.X + (size_t)b * K * p.Tin, p.ct_w, p.ct_wt, K, p.pw.Kp, p.Tin, p.Tout, ti0, p.ratio, p.pre_scale, p.pre_elu, 0, 0, {}, {}};
         gemm_mainloop_q<T>(acc, reinterpret_cast<const f32x4*>(p.pw.wq), p.pw.Mp, m0, lb, p.pw.Kp / BK,
-                           reinterpret_cast<f32x4*>(smem), p.dbg);
+                           reinterpret_cast<f32x4*>(smem));
     }
-    if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.Y[0] = 0.f; return; }
     epi.finish(acc, p);
 }
 
@@ -1029,7 +875,7 @@ __global__ __launch_bounds__(NT_) void stft_logmag_kernel(StftArgs p) {
     FrameLoader lb{p.wav + (size_t)b * p.T, p.T, p.Tf, p.n_fft, p.hop, t0, {}, {}};
     StftSide<T::BN> side{p.side, p.side + p.n_fft, p.n_fft, blockIdx.x == 0 && (int)threadIdx.x < T::BN,
                          (int)threadIdx.x % T::BN, 0.f, 0.f};
-    gemm_mainloop<T>(acc, la, lb, (p.n_fft + BK - 1) / BK, smem, 0, side);
+    gemm_mainloop<T>(acc, la, lb, (p.n_fft + BK - 1) / BK, smem, side);
     float* sd = smem;                                        // [2][BN] (stages are free after the last barrier)
     if (side.on) { sd[side.col] = side.d0; sd[T::BN + side.col] = side.d1; }
     if (blockIdx.x == 0) __syncthreads();
@@ -1240,17 +1086,22 @@ __global__ __launch_bounds__(NT_) void film_kernel(FilmArgs p) {
 // Per-launch profiler (HIP events on the launch stream)
 // ------------------------------------------------------------------------------------------
 }  // namespace wv
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 namespace wv {
-static int g_debug_flags = 0;
-void set_debug_flags(int flags) { g_debug_flags = flags; }
 namespace prof {
 namespace {
+// All state below is guarded by g_mu (launchers may be called from several host threads).  Events are
+// never recorded on a capturing stream (a captured event cannot be synchronised on later), and the
+// record list is drained when it grows past MAX_RECS so a long profiled run keeps bounded memory.
 struct Rec { hipEvent_t a, b; int key; };
 struct Agg { std::string name; long long launches = 0; double ms = 0, flops = 0, bytes = 0; };
-bool g_on = false;
+constexpr size_t MAX_RECS = 8192;
+std::mutex g_mu;
+std::atomic<bool> g_on{false};
 thread_local const char* g_role = "";
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -1260,22 +1111,24 @@ hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
-void drain() {
+void drain_locked() {
     for (Rec& r : g_recs) {
         float ms = 0.f;
-        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess)
+        if (r.b && hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess)
             g_agg[r.key].ms += ms;
-        g_pool.push_back(r.a); g_pool.push_back(r.b);
+        g_pool.push_back(r.a);
+        if (r.b) g_pool.push_back(r.b);
     }
     g_recs.clear();
 }
 }  // namespace
-void enable(bool on) { g_on = on; }
-bool enabled() { return g_on; }
-void reset() { drain(); g_agg.clear(); g_index.clear(); }
+void enable(bool on) { g_on.store(on); }
+bool enabled() { return g_on.load(); }
+void reset() { std::lock_guard<std::mutex> lk(g_mu); drain_locked(); g_agg.clear(); g_index.clear(); }
 void set_role(const char* role) { g_role = role ? role : ""; }
 int collect(Entry* out, int cap) {
-    drain();
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain_locked();
     int n = 0;
     for (const Agg& a : g_agg) {
         if (n < cap) out[n] = Entry{a.name.c_str(), a.launches, a.ms, a.flops, a.bytes};
@@ -1283,23 +1136,28 @@ int collect(Entry* out, int cap) {
     }
     return n;
 }
-struct Scope {
-    hipStream_t s; int rec = -1;
-    Scope(hipStream_t st, const char* kernel, double flops, double bytes) : s(st) {
-        if (!g_on) return;
-        std::string key = std::string(kernel) + "|" + g_role;
-        auto it = g_index.find(key);
-        int k;
-        if (it == g_index.end()) { k = (int)g_agg.size(); g_index[key] = k; Agg a; a.name = key; g_agg.push_back(a); }
-        else k = it->second;
-        g_agg[k].launches += 1; g_agg[k].flops += flops; g_agg[k].bytes += bytes;
-        Rec r{get_event(), get_event(), k};
-        (void)hipEventRecord(r.a, s);
-        g_recs.push_back(r);
-        rec = (int)g_recs.size() - 1;
-    }
-    ~Scope() { if (rec >= 0) (void)hipEventRecord(g_recs[rec].b, s); }
-};
+Scope::Scope(hipStream_t st, const char* kernel, double flops, double bytes) : s(st) {
+    if (!g_on.load(std::memory_order_relaxed)) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_recs.size() >= MAX_RECS) drain_locked();
+    std::string key = std::string(kernel) + "|" + g_role;
+    auto it = g_index.find(key);
+    int k;
+    if (it == g_index.end()) { k = (int)g_agg.size(); g_index[key] = k; Agg a; a.name = key; g_agg.push_back(a); }
+    else k = it->second;
+    g_agg[k].launches += 1; g_agg[k].flops += flops; g_agg[k].bytes += bytes;
+    ev_a = get_event(); ev_b = get_event(); key_ = k;
+    (void)hipEventRecord((hipEvent_t)ev_a, s);
+    armed = true;
+}
+Scope::~Scope() {
+    if (!armed) return;
+    (void)hipEventRecord((hipEvent_t)ev_b, s);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_recs.push_back(Rec{(hipEvent_t)ev_a, (hipEvent_t)ev_b, key_});
+}
 }  // namespace prof
 
 template <class T>
@@ -1314,18 +1172,25 @@ static std::string tile_name(const char* base) {
 template <class T>
 static constexpr size_t stage_bytes() { return 2 * (size_t)T::STAGE * sizeof(float); }
 
+// Per-kernel launch attributes are per DEVICE (one process may drive several GPUs): `done` is a bit
+// mask of the devices on which the attribute has been set (idempotent, so a lost race only repeats it).
+static int cur_dev() { int d = 0; (void)hipGetDevice(&d); return d & 31; }
 template <class K>
-static hipError_t set_smem(K kernel, size_t bytes) {
+static hipError_t set_smem(K kernel, size_t bytes, std::atomic<unsigned>& done) {
     if (bytes <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    const unsigned bit = 1u << cur_dev();
+    if (done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+    return e;
 }
 
 static int gcd_(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 // Time-tile geometry of K1: the H window of a tile starts at ti0 = to0*s - pad - off with `off`
 // chosen so that ti0 is a multiple of 4 for every tile (16-byte X loads); tto outputs per tile.
-static bool pw_dw_geometry(PwDwArgs& a, int BN) {
+bool pw_dw_geometry(PwDwArgs& a, int BN) {
     const int span = (a.ks - 1) * a.dil + 1;
     a.off = (4 - (a.pad % 4)) % 4;
     int tto = (BN - a.off - span) / a.stride + 1;
@@ -1342,25 +1207,24 @@ static bool pw_dw_geometry(PwDwArgs& a, int BN) {
 template <class T, int KS>
 static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     if (!pw_dw_geometry(a, T::BN)) return hipErrorInvalidValue;
-    a.dbg = g_debug_flags & 31;
     const size_t eb = (size_t)PwDwEpi<T, KS>::FLOATS * sizeof(float);
     const size_t smem = 2 * (size_t)QT<T>::NB * 16 + eb;       // two B stages + the epilogue's row table
-    static bool attr_f32 = false;
-    if (!attr_f32) {
-        hipError_t e = set_smem(pw_dw_kernel<T, KS>, smem);
+    static std::atomic<unsigned> attr_f32{0};
+    {
+        hipError_t e = set_smem(pw_dw_kernel<T, KS>, smem, attr_f32);
         if (e != hipSuccess) return e;
-        attr_f32 = true;
     }
-    static int per_cu = -1;                               // resident workgroups per CU
-    if (per_cu < 0) {
+    static std::atomic<int> per_cu_dev[32];               // resident workgroups per CU, per device (0 = unknown)
+    int per_cu = per_cu_dev[cur_dev()].load(std::memory_order_relaxed);
+    if (per_cu < 1) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pw_dw_kernel<T, KS>, T::NTHREADS, smem) != hipSuccess || n < 1)
             n = 1;
         per_cu = n;
+        per_cu_dev[cur_dev()].store(n, std::memory_order_relaxed);
     }
     // de-phase the first generation of workgroups (see kernel); off for tiny grids
-    const int st_flag = (g_debug_flags >> 8) & 255;
-    a.stagger = st_flag == 255 ? 0 : (st_flag ? st_flag : 2);       // default 2 x s_sleep(127) per slot
+    a.stagger = 2;                                         // 2 x s_sleep(127) per resident slot
     a.first_gen = 256 * per_cu;
     a.num_m = (a.pw.M + T::BM - 1) / T::BM;
     a.num_t = (a.Tout + a.tto - 1) / a.tto;
@@ -1375,11 +1239,10 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     // HBM-bound anyway) stay on the f32 core
     if constexpr (T::NTHREADS == 256 && T::BN == 64) if (a.prec == PREC_F16X3 && a.pw.wh && a.pw.K >= 256 && !a.ct_w) {
         const size_t hs = 2 * (size_t)HT<T>::STAGE * 16 + eb;
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = set_smem(pw_dw_h_kernel<T, KS>, hs);
+        static std::atomic<unsigned> attr_done{0};
+        {
+            hipError_t e = set_smem(pw_dw_h_kernel<T, KS>, hs, attr_done);
             if (e != hipSuccess) return e;
-            attr_done = true;
         }
         a.stagger = 0;
         static const std::string hname = tile_name<T>(KS ? "pw_dw_k5_h" : "pw_dw_h");
@@ -1392,14 +1255,13 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
         // upsample unit: ConvTranspose producer in the B loader, identity stencil (see pw_dw_kernel)
         static const std::string cname = tile_name<T>("convtr_pw");
         prof::Scope pc(s, cname.c_str(), 2.0 * Bd * a.Tout * K * (M + 2.0), 4.0 * Bd * (K * a.Tin + M * a.Tout));
-        static bool attr_ct = false;
-        if (!attr_ct) {
-            hipError_t e = set_smem(pw_dw_kernel<T, 5, 4>, smem);
-            if (e == hipSuccess) e = set_smem(pw_dw_kernel<T, 5, 2>, smem);
-            if (e == hipSuccess) e = set_smem(pw_dw_kernel<T, 5, 1>, smem);
-            if (e == hipSuccess) e = set_smem(pw_dw_kernel<T, 5, 0>, smem);
+        static std::atomic<unsigned> attr_ct4{0}, attr_ct2{0}, attr_ct1{0}, attr_ct0{0};
+        {
+            hipError_t e = set_smem(pw_dw_kernel<T, 5, 4>, smem, attr_ct4);
+            if (e == hipSuccess) e = set_smem(pw_dw_kernel<T, 5, 2>, smem, attr_ct2);
+            if (e == hipSuccess) e = set_smem(pw_dw_kernel<T, 5, 1>, smem, attr_ct1);
+            if (e == hipSuccess) e = set_smem(pw_dw_kernel<T, 5, 0>, smem, attr_ct0);
             if (e != hipSuccess) return e;
-            attr_ct = true;
         }
         if (a.ratio % 4 == 0) hipLaunchKernelGGL((pw_dw_kernel<T, 5, 4>), grid, dim3(T::NTHREADS), smem, s, a);
         else if (a.ratio == 2) hipLaunchKernelGGL((pw_dw_kernel<T, 5, 2>), grid, dim3(T::NTHREADS), smem, s, a);
@@ -1412,11 +1274,10 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
         // this HBM-bound launch apart from the matrix-bound ResnetBlock halves
         static const std::string sname = tile_name<T>("spec_add");
         prof::Scope pa(s, sname.c_str(), 2.0 * Bd * M * K * a.Tin, 4.0 * Bd * (K * a.Tin + 2.0 * M * a.Tout));
-        static bool attr_sa = false;
-        if (!attr_sa) {
-            hipError_t e = set_smem(pw_dw_kernel<T, 5, -2>, smem);
+        static std::atomic<unsigned> attr_sa{0};
+        {
+            hipError_t e = set_smem(pw_dw_kernel<T, 5, -2>, smem, attr_sa);
             if (e != hipSuccess) return e;
-            attr_sa = true;
         }
         hipLaunchKernelGGL((pw_dw_kernel<T, 5, -2>), grid, dim3(T::NTHREADS), smem, s, a);
         return hipGetLastError();
@@ -1426,11 +1287,10 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     prof::Scope ps(s, nores ? name_nr.c_str() : name.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
                    4.0 * Bd * (K * a.Tin + M * a.Tout * (a.resid ? 2.0 : 1.0)));
     if constexpr (KS == 5) if (nores) {
-        static bool attr_nr = false;
-        if (!attr_nr) {
-            hipError_t e = set_smem(pw_dw_kernel<T, 5, -1, false>, smem);
+        static std::atomic<unsigned> attr_nr{0};
+        {
+            hipError_t e = set_smem(pw_dw_kernel<T, 5, -1, false>, smem, attr_nr);
             if (e != hipSuccess) return e;
-            attr_nr = true;
         }
         hipLaunchKernelGGL((pw_dw_kernel<T, 5, -1, false>), grid, dim3(T::NTHREADS), smem, s, a);
         return hipGetLastError();
@@ -1456,6 +1316,10 @@ static int pick_bm(int M) {
 }
 
 hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
+    if (k1_supported(a)) {                                   // the LDS-DMA core (wv_k1.hip)
+        const hipError_t e = launch_k1(a, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (a.ct_w && (!a.ct_wt || (reinterpret_cast<uintptr_t>(a.ct_wt) & 7) || a.ratio < 1 || a.Tout != a.Tin * a.ratio || a.ks != 5 || a.stride != 1 || a.dil != 1 || a.pad != 4 ||
                    (reinterpret_cast<uintptr_t>(a.ct_w) & 15)))
         return hipErrorInvalidValue;
@@ -1497,11 +1361,10 @@ static hipError_t run_dw_pw_mode(const DwPwArgs& a, hipStream_t s) {
     size_t smem = stage_bytes<T>();
     const size_t hb = ((size_t)T::BM * (T::BN + 4) + T::BN) * sizeof(float);
     if (hb > smem) smem = hb;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = set_smem(dw_pw_kernel<T, MODE>, smem);
+    static std::atomic<unsigned> attr_done{0};
+    {
+        hipError_t e = set_smem(dw_pw_kernel<T, MODE>, smem, attr_done);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     if (a.l2norm && a.pw.M > T::BM) return hipErrorInvalidValue;
     dim3 grid((a.pw.M + T::BM - 1) / T::BM, (a.Tout + T::BN - 1) / T::BN, a.B);

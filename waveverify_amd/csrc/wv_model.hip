@@ -230,7 +230,7 @@ struct Uploader {
         std::vector<float> as_f(hf.size() / 2);
         std::memcpy(as_f.data(), hf.data(), hf.size() * 2);
         p.wh = up(as_f);
-        std::vector<float> q((size_t)p.Kp * p.Mp, 0.f);            // wq[Kp/4][Mp][4]
+        std::vector<float> q((size_t)wv::round_up(K, 32) * p.Mp, 0.f);   // wq[roundup(K,32)/4][Mp][4]
         for (int mm = 0; mm < M; ++mm)
             for (int k = 0; k < K; ++k) q[((size_t)(k / 4) * p.Mp + mm) * 4 + (k & 3)] = w[(size_t)mm * K + k];
         p.wq = up(q);
@@ -426,7 +426,7 @@ struct WsLayout {
     size_t act = 0;        // floats per activation buffer
     size_t spec = 0;       // floats of the STFT scratch
     size_t film = 0, latent = 0;
-    size_t off_a = 0, off_b = 0, off_c = 0, off_p = 0, off_film = 0, off_lat = 0, total = 0;
+    size_t off_r0 = 0, off_r1 = 0, off_a0 = 0, off_a1 = 0, off_u = 0, off_p = 0, off_film = 0, off_lat = 0, total = 0;
 };
 
 WsLayout layout(const wv_model* m, int B, int T) {
@@ -455,9 +455,11 @@ WsLayout layout(const wv_model* m, int B, int T) {
     L.film = (size_t)B * c.n_strides * c.freq_bands * 2;
     L.latent = (size_t)B * c.dimension * Fr;
     size_t o = 0;
-    L.off_a = o; o += align_up(L.act * 4);
-    L.off_b = o; o += align_up(L.act * 4);
-    L.off_c = o; o += align_up(L.act * 4);
+    L.off_r0 = o; o += align_up(L.act * 4);      // residual stream, raw (ping-pong)
+    L.off_r1 = o; o += align_up(L.act * 4);
+    L.off_a0 = o; o += align_up(L.act * 4);      // the same stream pre-activated for its consumer (ping-pong)
+    L.off_a1 = o; o += align_up(L.act * 4);
+    L.off_u = o; o += align_up(L.act * 4);       // ResnetBlock intermediate (activated)
     L.off_p = o; o += align_up(L.spec * 4);
     L.off_film = o; o += align_up(L.film * 4);
     L.off_lat = o; o += align_up(L.latent * 4);
@@ -473,21 +475,37 @@ WsLayout layout(const wv_model* m, int B, int T) {
             return fail(WV_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
-struct Bufs { float *a, *b, *c; };   // a = current activation, b / c = scratch
+// The residual stream of a net: `raw` = x, `act` = ELU(s * x) for the NEXT consumer's scale s (written
+// by the producer's epilogue, PwDwArgs::Yact, so that the consumer stages it by LDS-DMA), either may be
+// null.  r[2] / a[2] are the ping-pong buffers behind them, u the ResnetBlock intermediate.
+struct Stream {
+    float* r[2]; float* a[2]; float* u;
+    float* raw = nullptr; float* act = nullptr;
+    float* other_raw() const { return raw == r[0] ? r[1] : r[0]; }
+    float* other_act() const { return act == a[0] ? a[1] : a[0]; }
+};
 
-int run_resblock(const ResBlock& r, Bufs& bf, int B, int T, hipStream_t st, const char* role, int prec) {
+// SEANetResnetBlock (seanet.py:245-281) as two K1 launches.  next_scale > 0: also write ELU(next_scale*y);
+// want_raw: write y itself (needed when y is a later residual / raw operand).
+int run_resblock(const ResBlock& r, Stream& st, bool want_raw, float next_scale, int B, int T, hipStream_t s,
+                 const char* role, int prec) {
     wv::prof::set_role(role);
     wv::PwDwArgs a{};
-    a.X = bf.a; a.pw = r.pw1; a.dw_w = r.dw1_w; a.dw_b = r.dw1_b; a.Y = bf.b;
+    if (st.act) { a.X = st.act; a.pre_scale = 1.f; a.pre_elu = 0; }
+    else { a.X = st.raw; a.pre_scale = r.pre_scale; a.pre_elu = 1; }
+    a.pw = r.pw1; a.dw_w = r.dw1_w; a.dw_b = r.dw1_b; a.Y = nullptr; a.Yact = st.u; a.act_scale = 1.f;
     a.B = B; a.Tin = T; a.Tout = T; a.ks = r.ks; a.stride = 1; a.dil = r.dil1; a.pad = (r.ks - 1) * r.dil1;
-    a.pre_scale = r.pre_scale; a.pre_elu = 1; a.out_scale = 1.f; a.bands = 1; a.prec = prec;
-    LAUNCH(wv::launch_pw_dw(a, st));
+    a.out_scale = 1.f; a.bands = 1; a.prec = prec;
+    LAUNCH(wv::launch_pw_dw(a, s));
     wv::PwDwArgs b{};
-    b.X = bf.b; b.pw = r.pw2; b.dw_w = r.dw2_w; b.dw_b = r.dw2_b; b.resid = bf.a; b.Y = bf.c;
+    float* yr = want_raw ? st.other_raw() : nullptr;
+    float* ya = next_scale > 0.f ? st.other_act() : nullptr;
+    b.X = st.u; b.pw = r.pw2; b.dw_w = r.dw2_w; b.dw_b = r.dw2_b; b.resid = st.raw; b.Y = yr; b.Yact = ya;
+    b.act_scale = next_scale;
     b.B = B; b.Tin = T; b.Tout = T; b.ks = r.ks; b.stride = 1; b.dil = r.dil2; b.pad = (r.ks - 1) * r.dil2;
-    b.pre_scale = 1.f; b.pre_elu = 1; b.out_scale = r.out_scale; b.bands = 1; b.prec = prec;
-    LAUNCH(wv::launch_pw_dw(b, st));
-    float* t = bf.a; bf.a = bf.c; bf.c = t;
+    b.pre_scale = 1.f; b.pre_elu = 0; b.out_scale = r.out_scale; b.bands = 1; b.prec = prec;
+    LAUNCH(wv::launch_pw_dw(b, s));
+    st.raw = yr; st.act = ya;
     return WV_OK;
 }
 
@@ -505,11 +523,19 @@ int run_film(wv_model* m, const float* msg, int msg_rows, float* film, int B, hi
     return WV_OK;
 }
 
+Stream make_stream(char* ws, const WsLayout& L) {
+    Stream st{};
+    st.r[0] = (float*)(ws + L.off_r0); st.r[1] = (float*)(ws + L.off_r1);
+    st.a[0] = (float*)(ws + L.off_a0); st.a[1] = (float*)(ws + L.off_a1);
+    st.u = (float*)(ws + L.off_u);
+    return st;
+}
+
 // SEANetEncoder.forward (modules/seanet.py:883-976). Result in `latent` [B, dimension, Fr].
 int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, float* latent, int B,
                 int T, char* ws, const WsLayout& L, hipStream_t st, int* Fr_out) {
     const wv_config& c = m->cfg;
-    Bufs bf{(float*)(ws + L.off_a), (float*)(ws + L.off_b), (float*)(ws + L.off_c)};
+    Stream sm = make_stream(ws, L);
     float* P = (float*)(ws + L.off_p);
     float* film = nullptr;
     if (msg) {
@@ -518,17 +544,23 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         if (rc) return rc;
     }
     wv::prof::set_role("enc.conv_pre");
-    LAUNCH(wv::launch_conv_pre(x, m->pre_w, m->pre_b, bf.a, B, c.channels_enc, T, c.kernel_size,
+    sm.raw = sm.r[0]; sm.act = nullptr;
+    LAUNCH(wv::launch_conv_pre(x, m->pre_w, m->pre_b, sm.raw, B, c.channels_enc, T, c.kernel_size,
                                1.f / c.wav_std, st));
     int Tl = T, C = c.channels_enc;
     const int film_stride = c.n_strides * c.freq_bands * 2;
     for (int s = 0; s <= c.n_strides; ++s) {
         const bool post = s == c.n_strides;
-        if (!post)
-            for (const ResBlock& r : m->enc_blocks[s]) {
-                int rc = run_resblock(r, bf, B, Tl, st, "enc.resblock", m->prec);
+        if (!post) {
+            const std::vector<ResBlock>& blocks = m->enc_blocks[s];
+            for (size_t j = 0; j < blocks.size(); ++j) {
+                // the last block feeds the SpecBlock add, which takes y raw (as its residual operand)
+                const bool last = j + 1 == blocks.size();
+                int rc = run_resblock(blocks[j], sm, true, last ? 0.f : blocks[j + 1].pre_scale, B, Tl, st,
+                                      "enc.resblock", m->prec);
                 if (rc) return rc;
             }
+        }
         wv::prof::set_role("enc.spec");
         const SpecLayer& sp = m->specs[s];
         wv::StftArgs sa{};
@@ -537,42 +569,53 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         sa.mean = sp.mean; sa.inv_std = sp.inv_std;
         if (sa.Tf != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");
         LAUNCH(wv::launch_stft_logmag(sa, st));
-        // x += scale * (W @ P)  (seanet.py:500-502).  Runs on K1's k-inner core with an identity
-        // stencil (taps 0,0,0,0,1 are exact: fmaf(0,h,0) = 0, fmaf(1,h,0) = h) and x as the
-        // residual operand, written in place: every element is read and then written by the
-        // same lane, and the halo columns of a tile are only ever read from P.
+        // x += scale * (W @ P)  (seanet.py:500-502).  Runs on K1 with an identity stencil (taps 0,0,0,0,1
+        // are exact: fmaf(0,h,0) = 0, fmaf(1,h,0) = h) and x as the residual operand.  Before a
+        // downsample only ELU(s * x') is consumed, so only that is written; spec_post keeps x' raw
+        // (in place: every element is read and then written by the same lane).
+        const float down_scale = post ? 0.f : m->downs[s].pre_scale;
         if (sp.pw.M < 128) {                  // small layers: the plain 1x1 kernel streams better
             wv::DwPwArgs k2{};
-            k2.X = P; k2.pw = sp.pw; k2.Y = bf.a; k2.B = B; k2.Tin = Tl; k2.Tout = Tl; k2.mode = 0;
+            k2.X = P; k2.pw = sp.pw; k2.Y = sm.raw; k2.B = B; k2.Tin = Tl; k2.Tout = Tl; k2.mode = 0;
             k2.pre_scale = 1.f; k2.pre_elu = 0; k2.accumulate = 1; k2.out_scale = sp.scale;
             LAUNCH(wv::launch_dw_pw(k2, st));
+            sm.act = nullptr;
         } else {
-        wv::PwDwArgs acc{};
-        acc.X = P; acc.pw = sp.pw; acc.dw_w = sp.id_taps; acc.dw_b = nullptr; acc.resid = bf.a; acc.Y = bf.a;
-        acc.B = B; acc.Tin = Tl; acc.Tout = Tl; acc.ks = 5; acc.stride = 1; acc.dil = 1; acc.pad = 4;
-        acc.pre_scale = 1.f; acc.pre_elu = 0; acc.out_scale = sp.scale; acc.bands = 1; acc.prec = wv::PREC_F32;
-        acc.spec_add = 1;
-        LAUNCH(wv::launch_pw_dw(acc, st));
+            wv::PwDwArgs acc{};
+            acc.X = P; acc.pw = sp.pw; acc.dw_w = sp.id_taps; acc.dw_b = nullptr; acc.resid = sm.raw;
+            acc.Y = post ? sm.raw : nullptr;
+            acc.Yact = post ? nullptr : sm.other_act(); acc.act_scale = down_scale;
+            acc.B = B; acc.Tin = Tl; acc.Tout = Tl; acc.ks = 5; acc.stride = 1; acc.dil = 1; acc.pad = 4;
+            acc.pre_scale = 1.f; acc.pre_elu = 0; acc.out_scale = sp.scale; acc.bands = 1; acc.prec = wv::PREC_F32;
+            acc.spec_add = 1;
+            LAUNCH(wv::launch_pw_dw(acc, st));
+            if (!post) { sm.act = acc.Yact; sm.raw = nullptr; }
         }
         if (post) break;
         const DownLayer& d = m->downs[s];
         wv::prof::set_role(film ? "enc.down_film" : "enc.down");
         wv::PwDwArgs a{};
-        a.X = bf.a; a.pw = d.pw; a.dw_w = d.dw_w; a.dw_b = d.dw_b; a.Y = bf.b;
+        if (sm.act) { a.X = sm.act; a.pre_scale = 1.f; a.pre_elu = 0; }
+        else { a.X = sm.raw; a.pre_scale = d.pre_scale; a.pre_elu = 1; }
+        const bool next_has_blocks = s + 1 < c.n_strides && !m->enc_blocks[s + 1].empty();
+        float* yr = sm.raw ? sm.other_raw() : sm.r[0];
+        float* ya = next_has_blocks ? (sm.act ? sm.other_act() : sm.a[0]) : nullptr;
+        a.pw = d.pw; a.dw_w = d.dw_w; a.dw_b = d.dw_b; a.Y = yr; a.Yact = ya;
+        a.act_scale = next_has_blocks ? m->enc_blocks[s + 1][0].pre_scale : 0.f;
         a.B = B; a.Tin = Tl; a.Tout = (Tl + d.ratio - 1) / d.ratio;
         a.ks = 2 * d.ratio; a.stride = d.ratio; a.dil = 1; a.pad = d.ratio;  // (k-1) - (s-1) = r
-        a.pre_scale = d.pre_scale; a.pre_elu = 1; a.out_scale = 1.f;
+        a.out_scale = 1.f;
         a.bands = c.freq_bands; a.film_stride = film_stride;
         a.film = film ? film + (size_t)s * c.freq_bands * 2 : nullptr;
         a.prec = m->prec;
         if (film && (2 * C) % c.freq_bands) return fail(WV_EINVAL, "channels not divisible by freq_bands");
         LAUNCH(wv::launch_pw_dw(a, st));
-        float* t = bf.a; bf.a = bf.b; bf.b = t;
+        sm.raw = yr; sm.act = ya;
         Tl = a.Tout; C *= 2;
     }
     wv::prof::set_role("enc.conv_post");
     wv::DwPwArgs cp{};                       // conv_post: ELU -> DW k -> 1x1 + bias -> L2Norm
-    cp.X = bf.a; cp.dw_w = m->post_dw_w; cp.pw = m->post_pw; cp.bias = m->post_b; cp.Y = latent;
+    cp.X = sm.raw; cp.dw_w = m->post_dw_w; cp.pw = m->post_pw; cp.bias = m->post_b; cp.Y = latent;
     cp.B = B; cp.Tin = Tl; cp.Tout = Tl; cp.mode = 1; cp.ks = c.last_kernel_size;
     cp.pre_scale = 1.f; cp.pre_elu = 1; cp.l2norm = 1;
     if (c.dimension > 128) return fail(WV_EINVAL, "dimension > 128 not supported by the fused L2-norm epilogue");
@@ -755,33 +798,48 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
     int Fr = 0;
     rc = run_encoder(m, x, msg, msg_rows, latent, B, T, w, L, st, &Fr);
     if (rc) return rc;
-    // SEANetDecoder.forward (modules/seanet.py:1212-1226)
-    Bufs bf{(float*)(w + L.off_a), (float*)(w + L.off_b), (float*)(w + L.off_c)};
+    // SEANetDecoder.forward (modules/seanet.py:1212-1226).  Every unit's output is consumed through an
+    // ELU, so producers write the activated copy the next unit wants; the raw stream exists only where
+    // it is a residual operand (inside a stage) or the tail's input.
+    Stream sm = make_stream(w, L);
     wv::prof::set_role("dec.head");
     wv::PwDwArgs h{};
-    h.X = latent; h.pw = m->dec_pw0; h.dw_w = m->dec_dw0_w; h.dw_b = m->dec_dw0_b; h.Y = bf.a;
+    h.X = latent; h.pw = m->dec_pw0; h.dw_w = m->dec_dw0_w; h.dw_b = m->dec_dw0_b;
+    h.Y = nullptr; h.Yact = sm.a[0]; h.act_scale = m->ups.empty() ? 1.f : m->ups[0].pre_scale;
     h.B = B; h.Tin = Fr; h.Tout = Fr; h.ks = c.kernel_size; h.stride = 1; h.dil = 1; h.pad = c.kernel_size - 1;
     h.pre_scale = 1.f; h.pre_elu = 0; h.out_scale = 1.f; h.bands = 1; h.prec = m->prec;
     LAUNCH(wv::launch_pw_dw(h, st));
+    sm.raw = nullptr; sm.act = sm.a[0];
     int Tl = Fr;
-    for (const UpLayer& u : m->ups) {
+    for (size_t i = 0; i < m->ups.size(); ++i) {
+        const UpLayer& u = m->ups[i];
+        const bool last_up = i + 1 == m->ups.size();
+        // what the stage's final output is consumed as: the next upsample's ELU(dec_post * y), or y by the tail
+        const float stage_next = last_up ? 0.f : m->ups[i + 1].pre_scale;
         wv::prof::set_role("dec.upsample");
-        // [Scale] -> ELU -> DW ConvTranspose(2r, r), trimmed -> 1x1 + bias (seanet.py:1147-1170): the
-        // K1 kernel with the ConvTranspose built in its B-operand loader and an identity stencil.
+        // [Scale] -> ELU -> DW ConvTranspose(2r, r), trimmed -> 1x1 + bias (seanet.py:1147-1170): the K1
+        // kernel with the ConvTranspose built in its B-operand loader (on the pre-activated input) and an
+        // identity stencil.
         wv::PwDwArgs a{};
-        a.X = bf.a; a.ct_w = u.ct_w; a.ct_wt = u.ct_wt; a.ratio = u.ratio; a.pw = u.pw; a.dw_w = u.id_taps; a.dw_b = u.pw_b; a.Y = bf.b;
+        a.X = sm.act; a.ct_w = u.ct_w; a.ct_wt = u.ct_wt; a.ratio = u.ratio; a.pw = u.pw; a.dw_w = u.id_taps; a.dw_b = u.pw_b;
+        const bool has_blocks = !u.res.empty();
+        a.Y = (has_blocks || last_up) ? sm.r[0] : nullptr;
+        a.Yact = has_blocks ? sm.other_act() : (last_up ? nullptr : sm.other_act());
+        a.act_scale = has_blocks ? u.res[0].pre_scale : stage_next;
         a.B = B; a.Tin = Tl; a.Tout = Tl * u.ratio; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
-        a.pre_scale = u.pre_scale; a.pre_elu = 1; a.out_scale = 1.f; a.bands = 1; a.prec = wv::PREC_F32;
+        a.pre_scale = 1.f; a.pre_elu = 0; a.out_scale = 1.f; a.bands = 1; a.prec = wv::PREC_F32;
         LAUNCH(wv::launch_pw_dw(a, st));
-        float* t = bf.a; bf.a = bf.b; bf.b = t;
+        sm.raw = a.Y; sm.act = a.Yact;
         Tl = a.Tout;
-        for (const ResBlock& r : u.res) {
-            rc = run_resblock(r, bf, B, Tl, st, "dec.resblock", m->prec);
+        for (size_t j = 0; j < u.res.size(); ++j) {
+            const bool last = j + 1 == u.res.size();
+            const float next = last ? stage_next : u.res[j + 1].pre_scale;
+            rc = run_resblock(u.res[j], sm, !last || last_up, next, B, Tl, st, "dec.resblock", m->prec);
             if (rc) return rc;
         }
     }
     wv::prof::set_role("dec.tail");
-    LAUNCH(wv::launch_tail(bf.a, m->last_w, m->last_b, add_input ? x : nullptr, out, B, c.channels_dec,
+    LAUNCH(wv::launch_tail(sm.raw, m->last_w, m->last_b, add_input ? x : nullptr, out, B, c.channels_dec,
                            Tl, T, c.last_kernel_size, m->dec_post, c.wav_std, st));
     return WV_OK;
 }
@@ -823,7 +881,6 @@ int wv_model_set_precision(wv_model* m, int prec) {
     m->prec = prec;
     return WV_OK;
 }
-int wv_debug_flags(int flags) { wv::set_debug_flags(flags); return WV_OK; }
 int wv_profile_enable(int on) { wv::prof::enable(on != 0); return WV_OK; }
 int wv_profile_reset(void) { wv::prof::reset(); return WV_OK; }
 int wv_profile_collect(int index, char* name_out, int name_cap, int64_t* launches, double* total_ms,

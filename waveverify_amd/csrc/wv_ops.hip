@@ -39,7 +39,7 @@ struct Tmp {                       // scoped device uploads
         std::vector<float> as_f(hf.size() / 2);
         std::memcpy(as_f.data(), hf.data(), hf.size() * 2);
         p.wh = upv(as_f);
-        std::vector<float> q((size_t)p.Kp * p.Mp, 0.f);            // wq[Kp/4][Mp][4]
+        std::vector<float> q((size_t)wv::round_up(K, 32) * p.Mp, 0.f);   // wq[roundup(K,32)/4][Mp][4]
         for (int mm = 0; mm < M; ++mm)
             for (int k = 0; k < K; ++k) q[((size_t)(k / 4) * p.Mp + mm) * 4 + (k & 3)] = w[(size_t)mm * K + k];
         p.wq = upv(q);
@@ -69,12 +69,12 @@ int wv_op_set_precision(int prec) {
 int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const float* dw_bias,
                 const float* film, const float* resid, float* Y, int B, int K, int M, int Tin,
                 int ks, int stride, int dilation, float pre_scale, int pre_elu, float out_scale,
-                int bands, void* stream) {
-    if (!X || !w_pw || !w_dw || !Y || B < 1 || K < 1 || M < 1 || Tin < 1) return WV_EINVAL;
+                int bands, float* Yact, float act_scale, void* stream) {
+    if (!X || !w_pw || !w_dw || (!Y && !Yact) || B < 1 || K < 1 || M < 1 || Tin < 1) return WV_EINVAL;
     Tmp t;
     wv::PwDwArgs a{};
     a.X = X; a.pw = t.pw(w_pw, M, K); a.dw_w = t.up(w_dw, (size_t)M * ks);
-    a.dw_b = t.up(dw_bias, M); a.film = film; a.resid = resid; a.Y = Y;
+    a.dw_b = t.up(dw_bias, M); a.film = film; a.resid = resid; a.Y = Y; a.Yact = Yact; a.act_scale = act_scale;
     a.B = B; a.Tin = Tin; a.Tout = (Tin + stride - 1) / stride; a.ks = ks; a.stride = stride;
     a.dil = dilation; a.pad = (ks - 1) * dilation - (stride - 1);
     a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = out_scale;
@@ -86,7 +86,7 @@ int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const floa
 
 int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const float* bias, float* Y,
                 int B, int K, int M, int Tin, int mode, int ks_or_ratio, float pre_scale, int pre_elu,
-                int l2norm, int accumulate, float out_scale, void* stream) {
+                int l2norm, int accumulate, float out_scale, float* Yact, float act_scale, void* stream) {
     if (!X || !w_pw || !Y || B < 1 || K < 1 || M < 1 || Tin < 1) return WV_EINVAL;
     if (mode == 2 && !l2norm && !accumulate) {
         // upsample unit = K1 kernel with the ConvTranspose producer in its loader (as the model runs it)
@@ -97,7 +97,7 @@ int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const floa
         wv::PwDwArgs a{};
         a.X = X; a.pw = t.pw(w_pw, M, K); a.ct_w = t.up(w_dw, (size_t)K * 2 * ks_or_ratio); a.ratio = ks_or_ratio;
         a.ct_wt = t.upv(wv::pack_ct_wt(w_dw, K, a.pw.Kp, ks_or_ratio));
-        a.dw_w = t.upv(taps); a.dw_b = t.up(bias, M); a.Y = Y;
+        a.dw_w = t.upv(taps); a.dw_b = t.up(bias, M); a.Y = Y; a.Yact = Yact; a.act_scale = act_scale;
         a.B = B; a.Tin = Tin; a.Tout = Tin * ks_or_ratio; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
         a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1;
         a.film_stride = 2; a.prec = wv::PREC_F32;
@@ -108,13 +108,15 @@ int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const floa
     a.X = X; a.pw = t.pw(w_pw, M, K); a.bias = t.up(bias, M); a.Y = Y;
     a.B = B; a.Tin = Tin; a.mode = mode; a.Tout = Tin;
     if (mode == 2) return WV_EINVAL;                  // the upsample unit has neither L2-norm nor accumulate
+    const bool k1_form = mode == 0 && accumulate && !l2norm && !bias && M >= 128;
+    if (Yact && !k1_form) return WV_EINVAL;           // the second output exists on the pw_dw kernel only
     if (mode == 0 && accumulate && !l2norm && !bias && M >= 128) {
         // SpecBlock add as the model runs it for M >= 128: K1 kernel, identity stencil, Y as residual
         Tmp t;
         std::vector<float> taps((size_t)M * 5, 0.f);
         for (int m = 0; m < M; ++m) taps[(size_t)m * 5 + 4] = 1.f;
         wv::PwDwArgs a{};
-        a.X = X; a.pw = t.pw(w_pw, M, K); a.dw_w = t.upv(taps); a.resid = Y; a.Y = Y;
+        a.X = X; a.pw = t.pw(w_pw, M, K); a.dw_w = t.upv(taps); a.resid = Y; a.Y = Y; a.Yact = Yact; a.act_scale = act_scale;
         a.B = B; a.Tin = Tin; a.Tout = Tin; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
         a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = out_scale; a.bands = 1; a.film_stride = 2;
         a.prec = wv::PREC_F32; a.spec_add = 1;

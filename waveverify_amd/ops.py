@@ -44,7 +44,8 @@ def set_precision(precision: str) -> None:
 
 
 def pw_dw(X, w_pw, w_dw, dw_bias=None, film=None, resid=None, stride=1, dilation=1,
-          pre_scale=1.0, pre_elu=True, out_scale=1.0, bands=1) -> torch.Tensor:
+          pre_scale=1.0, pre_elu=True, out_scale=1.0, bands=1, act_scale: Optional[float] = None):
+    """act_scale given: also returns the second output ELU(act_scale * y) -> (Y, Yact)."""
     lib = _lib.load()
     X = _dev(X)
     B, K, Tin = X.shape
@@ -55,14 +56,17 @@ def pw_dw(X, w_pw, w_dw, dw_bias=None, film=None, resid=None, stride=1, dilation
     Y = torch.empty((B, M, Tout), dtype=torch.float32, device=X.device)
     film = None if film is None else _dev(film)
     resid = None if resid is None else _dev(resid)
+    Yact = torch.empty_like(Y) if act_scale is not None else None
     _lib.check(lib.wv_op_pw_dw(X.data_ptr(), _hp(w_pw), _hp(w_dw), _hp(dw_bias), _dp(film), _dp(resid),
                                Y.data_ptr(), B, K, M, Tin, ks, stride, dilation, pre_scale,
-                               int(pre_elu), out_scale, bands, _stream()), "wv_op_pw_dw")
-    return Y
+                               int(pre_elu), out_scale, bands, _dp(Yact), float(act_scale or 0.0),
+                               _stream()), "wv_op_pw_dw")
+    return Y if act_scale is None else (Y, Yact)
 
 
 def dw_pw(X, w_pw, bias=None, w_dw=None, mode=0, ks_or_ratio=0, pre_scale=1.0, pre_elu=False,
-          l2norm=False, accumulate_into: Optional[torch.Tensor] = None, out_scale=1.0) -> torch.Tensor:
+          l2norm=False, accumulate_into: Optional[torch.Tensor] = None, out_scale=1.0,
+          act_scale: Optional[float] = None):
     lib = _lib.load()
     X = _dev(X)
     B, K, Tin = X.shape
@@ -75,10 +79,12 @@ def dw_pw(X, w_pw, bias=None, w_dw=None, mode=0, ks_or_ratio=0, pre_scale=1.0, p
         assert Y.is_cuda and Y.is_contiguous() and tuple(Y.shape) == (B, M, Tout)
     else:
         Y = torch.empty((B, M, Tout), dtype=torch.float32, device=X.device)
+    Yact = torch.empty_like(Y) if act_scale is not None else None
     _lib.check(lib.wv_op_dw_pw(X.data_ptr(), _hp(w_dw), _hp(w_pw), _hp(bias), Y.data_ptr(), B, K, M,
                                Tin, mode, ks_or_ratio, pre_scale, int(pre_elu), int(l2norm),
-                               int(accumulate_into is not None), out_scale, _stream()), "wv_op_dw_pw")
-    return Y
+                               int(accumulate_into is not None), out_scale, _dp(Yact),
+                               float(act_scale or 0.0), _stream()), "wv_op_dw_pw")
+    return Y if act_scale is None else (Y, Yact)
 
 
 def stft_logmag(wav, n_fft, hop, mean=0.0, std=1.0, basis=None) -> torch.Tensor:
