@@ -144,6 +144,26 @@ def test_upsample_convtr_pw_dma_core(ops, K, M, Tin, r, pre_elu):
     close(gact, O.elu(ref * np.float32(0.9)), what="upsample (activated copy)")
 
 
+@pytest.mark.parametrize("C,T", [(64, 16000), (64, 120), (64, 4), (96, 1000), (96, 128), (128, 8000), (128, 124),
+                                 (192, 8000), (192, 56), (192, 60), (64, 112), (128, 240)])
+def test_fused_resblock(ops, C, T):
+    """Whole ResnetBlock in one launch (u stays in LDS) vs the oracle's two-unit composition; lengths around
+    every tile edge (120 / 56 outputs per tile, 8-column halo)."""
+    rng = np.random.default_rng(C + T)
+    B = 2
+    X = rnd(rng, B, C, T)
+    w1, w2 = rnd(rng, C, C, 1, scale=C ** -0.5), rnd(rng, C, C, 1, scale=C ** -0.5)
+    d1, d2 = rnd(rng, C, 1, 5, scale=0.45), rnd(rng, C, 1, 5, scale=0.45)
+    b1, b2 = rnd(rng, C, scale=0.1), rnd(rng, C, scale=0.1)
+    pre, s_out, s_act = np.float32(0.8660254), np.float32(0.41), np.float32(0.7071)
+    xa = O.elu(X * pre)
+    u = O.sconv1d(O.sconv1d(xa, w1, None), d1, b1, groups=C)
+    y = X + s_out * O.sconv1d(O.sconv1d(O.elu(u), w2, None), d2, b2, groups=C)
+    got, gact = ops.resblock(cu(xa), cu(X), w1, d1, b1, w2, d2, b2, out_scale=float(s_out), act_scale=float(s_act))
+    close(got, y.astype(np.float32), what="fused resblock")
+    close(gact, O.elu(y.astype(np.float32) * s_act), what="fused resblock (activated copy)")
+
+
 def test_pw_dw_no_prologue_no_bias(ops):
     """decoder head: 1x1 (128->1536, no bias) -> DW k5 (seanet.py:1070-1091)."""
     rng = np.random.default_rng(5)

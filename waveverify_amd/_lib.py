@@ -65,6 +65,7 @@ SIGNATURES = {
     "wv_op_pw_dw": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
                               C.c_int, _VP, C.c_float, _VP]),
+    "wv_op_resblock": (C.c_int, [_VP] * 10 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _VP]),
     "wv_op_dw_pw": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, _VP, C.c_float, _VP]),
     "wv_op_stft_logmag": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

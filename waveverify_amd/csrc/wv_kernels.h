@@ -80,6 +80,30 @@ hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s);
 bool k1_supported(const PwDwArgs& a);
 hipError_t launch_k1(const PwDwArgs& a, hipStream_t s);   // hipErrorNotSupported: use the round-1 kernel
 bool pw_dw_geometry(PwDwArgs& a, int BN);                 // time-tile geometry shared by both cores
+// ---- whole ResnetBlock in one launch (C <= 192; wv_k1.hip) -----------------------------------
+struct RbArgs {
+    const float* Xa;      // [B, C, T] ELU(pre_scale * x): the block's input, pre-activated by its producer
+    const float* Xr;      // [B, C, T] x (residual operand)
+    PwWeight pw1, pw2;    // the two 1x1 convs (no bias)
+    const float* tab1;    // [C][8] per channel: 5 depth-wise taps, bias, 1, 0 (pack_rb_table)
+    const float* tab2;
+    float* Y;             // [B, C, T] y = x + out_scale * block(x), or null
+    float* Yact;          // [B, C, T] ELU(act_scale * y), or null
+    float out_scale, act_scale;
+    int B, C, T;
+    int num_t;            // filled by the launcher
+};
+bool rb_supported(const RbArgs& a);
+hipError_t launch_resblock(const RbArgs& a, hipStream_t s);   // hipErrorNotSupported: run it as two K1 launches
+inline std::vector<float> pack_rb_table(const float* dw_w, const float* dw_b, int C) {   // dw_w [C][5]
+    std::vector<float> t((size_t)C * 8, 0.f);
+    for (int m = 0; m < C; ++m) {
+        for (int i = 0; i < 5; ++i) t[(size_t)m * 8 + i] = dw_w[(size_t)m * 5 + i];
+        t[(size_t)m * 8 + 5] = dw_b ? dw_b[m] : 0.f;
+        t[(size_t)m * 8 + 6] = 1.f;
+    }
+    return t;
+}
 // host: ConvTranspose taps [K][2r] -> [2r][Kp], zero padded
 inline std::vector<float> pack_ct_wt(const float* w, int K, int Kp, int ratio) {
     std::vector<float> t((size_t)2 * ratio * Kp, 0.f);
@@ -139,8 +163,9 @@ inline void pack_stft_basis(const float* basis, int n_fft, std::vector<float>& b
 hipError_t launch_stft_logmag(const StftArgs& a, hipStream_t s);
 
 // ---- K4: conv_pre ---------------------------------------------------------------------------
-hipError_t launch_conv_pre(const float* x, const float* w, const float* bias, float* Y, int B,
-                           int C, int T, int ks, float in_scale, hipStream_t s);
+// Yact (optional): second output ELU(act_scale * y), the first ResnetBlock's hoisted prologue
+hipError_t launch_conv_pre(const float* x, const float* w, const float* bias, float* Y, float* Yact, float act_scale,
+                           int B, int C, int T, int ks, float in_scale, hipStream_t s);
 
 // ---- K5: decoder tail -----------------------------------------------------------------------
 hipError_t launch_tail(const float* H, const float* w, const float* bias, const float* x,

@@ -916,8 +916,8 @@ constexpr int MAX_KS = 16;
 __global__ __launch_bounds__(NT_) void conv_pre_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias,
-                                                       float* __restrict__ Y, int C, int T, int ks,
-                                                       float in_scale) {
+                                                       float* __restrict__ Y, float* __restrict__ Yact,
+                                                       float act_scale, int C, int T, int ks, float in_scale) {
     // a thread owns 4 consecutive samples: one 16-byte store per channel row (1 KB per wave)
     const int b = blockIdx.y;
     const int t = (blockIdx.x * NT_ + threadIdx.x) * 4;
@@ -930,7 +930,8 @@ __global__ __launch_bounds__(NT_) void conv_pre_kernel(const float* __restrict__
         xv[i] = (i < ks + 3 && ti >= 0 && ti < T) ? xb[ti] * in_scale : 0.f;
     }
     float* yb = Y + (size_t)b * C * T + t;
-    const bool vec = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0;
+    float* ab = Yact ? Yact + (size_t)b * C * T + t : nullptr;      // second output: ELU(act_scale * y)
+    const bool vec = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && (reinterpret_cast<uintptr_t>(Yact) & 15) == 0;
     for (int c = 0; c < C; ++c) {
         const float bc = bias ? bias[c] : 0.f;
         float y[4] = {bc, bc, bc, bc};
@@ -947,6 +948,17 @@ __global__ __launch_bounds__(NT_) void conv_pre_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (t + e < T) yr[e] = y[e];
+        }
+        if (ab) {
+            float* ar = ab + (size_t)c * T;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = elu1(y[e] * act_scale);
+            if (vec) *reinterpret_cast<f32x4*>(ar) = f32x4{y[0], y[1], y[2], y[3]};
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (t + e < T) ar[e] = y[e];
+            }
         }
     }
 }
@@ -1419,12 +1431,12 @@ hipError_t launch_stft_logmag(const StftArgs& a, hipStream_t s) {
     return run_stft<Tile<128, 128, 1, 4>>(a, s);
 }
 
-hipError_t launch_conv_pre(const float* x, const float* w, const float* bias, float* Y, int B,
-                           int C, int T, int ks, float in_scale, hipStream_t s) {
+hipError_t launch_conv_pre(const float* x, const float* w, const float* bias, float* Y, float* Yact, float act_scale,
+                           int B, int C, int T, int ks, float in_scale, hipStream_t s) {
     if (ks < 1 || ks > MAX_KS) return hipErrorInvalidValue;
     dim3 grid((T + 4 * NT_ - 1) / (4 * NT_), B);
-    prof::Scope ps(s, "conv_pre", 2.0 * B * C * ks * (double)T, 4.0 * B * (double)T * (1.0 + C));
-    hipLaunchKernelGGL(conv_pre_kernel, grid, dim3(NT_), 0, s, x, w, bias, Y, C, T, ks, in_scale);
+    prof::Scope ps(s, "conv_pre", 2.0 * B * C * ks * (double)T, 4.0 * B * (double)T * (1.0 + C * (Yact ? 2.0 : 1.0)));
+    hipLaunchKernelGGL(conv_pre_kernel, grid, dim3(NT_), 0, s, x, w, bias, Y, Yact, act_scale, C, T, ks, in_scale);
     return hipGetLastError();
 }
 

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -39,6 +40,7 @@ using wv::PwWeight;
 struct ResBlock {
     PwWeight pw1, pw2;
     const float *dw1_w, *dw1_b, *dw2_w, *dw2_b;
+    const float *tab1 = nullptr, *tab2 = nullptr;   // [C][8] taps + bias rows of the fused-block kernel (ks == 5 only)
     float pre_scale, out_scale;
     int ks, dil1, dil2;
 };
@@ -282,6 +284,11 @@ ResBlock pack_resblock(Uploader& U, const std::string& pre, int idx, float rs, i
     r.pre_scale = (float)std::pow(1.0 + idx * (double)rs * rs, -0.5);      // seanet.py:183
     r.out_scale = rs * U.scalar_or(pre + ".res_scale_param", 1.f);         // seanet.py:272-274
     r.ks = ks; r.dil1 = dil1; r.dil2 = 1;                                   // dilations=[base**j, 1]
+    if (ks == 5 && U.err == WV_OK) {
+        const int C = r.pw1.M;
+        r.tab1 = U.up(wv::pack_rb_table(U.host(pre + ".block.2.conv.conv.weight").data(), U.host(pre + ".block.2.conv.conv.bias").data(), C));
+        r.tab2 = U.up(wv::pack_rb_table(U.host(pre + ".block.5.conv.conv.weight").data(), U.host(pre + ".block.5.conv.conv.bias").data(), C));
+    }
     return r;
 }
 
@@ -490,6 +497,20 @@ struct Stream {
 int run_resblock(const ResBlock& r, Stream& st, bool want_raw, float next_scale, int B, int T, hipStream_t s,
                  const char* role, int prec) {
     wv::prof::set_role(role);
+    // Fused form: measured slower than two K1 launches until it is made persistent;
+    // opt-in with WV_FUSED_RB=1 for tools/rbbench.py and the parity tests of the in-model path.
+    static const bool fused_on = getenv("WV_FUSED_RB") && atoi(getenv("WV_FUSED_RB")) != 0;
+    if (fused_on && st.act && st.raw && r.tab1 && r.dil1 == 1 && r.dil2 == 1 && prec == wv::PREC_F32) {
+        // narrow layers: the whole block in one launch, the intermediate stays in LDS (wv_k1.hip)
+        wv::RbArgs f{};
+        f.Xa = st.act; f.Xr = st.raw; f.pw1 = r.pw1; f.pw2 = r.pw2; f.tab1 = r.tab1; f.tab2 = r.tab2;
+        f.Y = want_raw ? st.other_raw() : nullptr;
+        f.Yact = next_scale > 0.f ? st.other_act() : nullptr;
+        f.out_scale = r.out_scale; f.act_scale = next_scale; f.B = B; f.C = r.pw1.M; f.T = T;
+        const hipError_t e = wv::launch_resblock(f, s);
+        if (e == hipSuccess) { st.raw = f.Y; st.act = f.Yact; return WV_OK; }
+        if (e != hipErrorNotSupported) return fail(WV_EHIP, std::string("launch_resblock: ") + hipGetErrorString(e));
+    }
     wv::PwDwArgs a{};
     if (st.act) { a.X = st.act; a.pre_scale = 1.f; a.pre_elu = 0; }
     else { a.X = st.raw; a.pre_scale = r.pre_scale; a.pre_elu = 1; }
@@ -544,9 +565,10 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         if (rc) return rc;
     }
     wv::prof::set_role("enc.conv_pre");
-    sm.raw = sm.r[0]; sm.act = nullptr;
-    LAUNCH(wv::launch_conv_pre(x, m->pre_w, m->pre_b, sm.raw, B, c.channels_enc, T, c.kernel_size,
-                               1.f / c.wav_std, st));
+    sm.raw = sm.r[0];
+    sm.act = m->enc_blocks[0].empty() ? nullptr : sm.a[0];     // also ELU(c1 * y) for the first ResnetBlock
+    LAUNCH(wv::launch_conv_pre(x, m->pre_w, m->pre_b, sm.raw, sm.act, sm.act ? m->enc_blocks[0][0].pre_scale : 0.f,
+                               B, c.channels_enc, T, c.kernel_size, 1.f / c.wav_std, st));
     int Tl = T, C = c.channels_enc;
     const int film_stride = c.n_strides * c.freq_bands * 2;
     for (int s = 0; s <= c.n_strides; ++s) {
