@@ -25,6 +25,7 @@
 //
 // Accumulation order over k is the round-1 order (lane half h owns k in [4h,4h+4) U [8+4h,12+4h) of
 // every 16), so results are bit-identical to the round-1 kernel.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <string>
@@ -90,62 +91,6 @@ __device__ __forceinline__ void dma_A(const f32x4* wq, int Mp, int m0, int c, f3
     }
 }
 
-// ---- the GEMM main loop -------------------------------------------------------------------------
-// LB (register path only): init(cg); fetch2(k0, raw); finish2(k0, raw, o[8]) -- the round-1 loader structs.
-template <class C, bool REG, class LB>
-__device__ __forceinline__ void k1_mainloop(f32x16 (&acc)[C::NT], const f32x4* __restrict__ wq, int Mp, int m0,
-                                            const DmaRows<C>& db, LB& lb, int nchunks, f32x4* smem) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, i31 = lane & 31;
-    const int cg = tid % C::CG, kp = tid / C::CG;              // register path: rows 2kp, 2kp+1; columns 4cg..
-    float raw[REG ? LB::NRAW : 1];
-    if (REG) lb.init(cg);
-
-    auto issue = [&](int c, int st) {
-        f32x4* S = smem + st * C::STAGE4;
-        dma_A<C>(wq, Mp, m0, c, S, wave, lane);
-        if (!REG) db.issue(c, S + C::A4, wave);
-    };
-    auto commit = [&](int c, int st) {
-        if constexpr (REG) {
-            float o[8];
-            lb.finish2(c * C::BKC + 2 * kp, raw, o);
-            f32x4* Bq = smem + st * C::STAGE4 + C::A4;
-            Bq[(2 * kp) * C::CG + cg] = f32x4{o[0], o[1], o[2], o[3]};
-            Bq[(2 * kp + 1) * C::CG + cg] = f32x4{o[4], o[5], o[6], o[7]};
-        }
-    };
-    issue(0, 0);
-    if constexpr (REG) { lb.fetch2(2 * kp, raw); commit(0, 0); }
-    __syncthreads();
-    typedef typename NVec<C::NT>::type bvec;
-    for (int c = 0; c < nchunks; ++c) {
-        const f32x4* S = smem + (c & 1) * C::STAGE4;
-        if (c + 1 < nchunks) {
-            issue(c + 1, (c + 1) & 1);
-            if constexpr (REG) lb.fetch2((c + 1) * C::BKC + 2 * kp, raw);
-        }
-        const float* Bf = reinterpret_cast<const float*>(S + C::A4) + C::NT * i31;
-#pragma unroll
-        for (int g = 0; g < C::BKC / 16; ++g) {
-            const f32x4 a0 = S[(4 * g + h) * C::BM + 32 * wave + i31];
-            const f32x4 a1 = S[(4 * g + h + 2) * C::BM + 32 * wave + i31];
-#define WV_K1_STEP(AV, ROW)                                                                        \
-    { const bvec bv = *reinterpret_cast<const bvec*>(Bf + (ROW) * C::BN);                          \
-      _Pragma("unroll") for (int e = 0; e < C::NT; ++e)                                            \
-          acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, bv[e], acc[e], 0, 0, 0); }
-            WV_K1_STEP(a0.x, 16 * g + 4 * h + 0) WV_K1_STEP(a0.y, 16 * g + 4 * h + 1)
-            WV_K1_STEP(a0.z, 16 * g + 4 * h + 2) WV_K1_STEP(a0.w, 16 * g + 4 * h + 3)
-            WV_K1_STEP(a1.x, 16 * g + 8 + 4 * h + 0) WV_K1_STEP(a1.y, 16 * g + 8 + 4 * h + 1)
-            WV_K1_STEP(a1.z, 16 * g + 8 + 4 * h + 2) WV_K1_STEP(a1.w, 16 * g + 8 + 4 * h + 3)
-#undef WV_K1_STEP
-        }
-        if (c + 1 < nchunks) commit(c + 1, (c + 1) & 1);
-        __syncthreads();
-    }
-}
-
 // ---- epilogue -----------------------------------------------------------------------------------
 // EPI 0: the ResnetBlock stencil (k5, stride 1, dilation 1, pad 4) straight from the accumulators.
 // EPI 1: any (ks <= 16, stride, dilation): rows go through a wave-private LDS strip (one 16/8-byte
@@ -161,7 +106,6 @@ struct K1Epi {
     int M, m0, b, to0, lane, wave, half, q, o, to;
     bool act_lane, vec;
     const float* Rb; float* Yb; float* Ab; float* Wl;
-    ovec res[RES ? 4 : 1];
 
     __device__ __forceinline__ int row_of(int r) const { return 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half; }
     __device__ __forceinline__ ovec load_res(const PwDwArgs& p, int r) const {
@@ -230,55 +174,83 @@ struct K1Epi {
             row[NTAP + 1] = gam; row[NTAP + 2] = bet;
             if (EPI != 0) row[19] = 0.f;
         }
-        if constexpr (RES) {
-            if (EPI == 0 && Rb) {
-#pragma unroll
-                for (int r = 0; r < RP; ++r) res[r] = load_res(p, r);
-            }
-        }
+    }
+
+    // EPI 0 addressing: buffer descriptors over ONE clip's [M][Tout] block and a per-lane byte offset that is
+    // out of range for lanes without outputs.  Rows past M land beyond num_records as well, so loads return 0
+    // and stores are dropped by the hardware range check: the loop below has no mask, no branch per element
+    // and no 64-bit address arithmetic (every VALU cycle here is taken from the matrix pipe, which shares
+    // the SIMD's lanes with f32 VALU work -- profiles/r02_f32mfma_valu_coissue.txt).
+    typedef unsigned uvec __attribute__((ext_vector_type(NT)));
+    __device__ __forceinline__ ovec buf_load(__amdgpu_buffer_rsrc_t r, int off) const {
+        if constexpr (NT == 4) return __builtin_bit_cast(ovec, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        else return __builtin_bit_cast(ovec, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    }
+    __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, int off, ovec v) const {
+        if constexpr (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, v), r, off, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, v), r, off, 0, 0);
     }
 
     __device__ __forceinline__ void finish(f32x16 (&acc)[NT], const PwDwArgs& p, float* strips) {
         if constexpr (EPI == 0) {
             constexpr int NSH = 4 / NT;                          // lane shifts that bring 4 more columns
+            const int clip_bytes = M * p.Tout * 4;
+            const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(Yb ? Yb : p.Yact, 0, Yb ? clip_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(Ab ? Ab : p.Yact, 0, Ab ? clip_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Rb ? Rb : p.X), 0, Rb ? clip_bytes : 0, 0x00020000);
+            const int row_bytes = p.Tout * 4;
+            const int voff = act_lane ? ((m0 + 32 * wave + 4 * half) * p.Tout + to) * 4 : 0x7f000000;
+            const float* Wrow = Wl + (32 * wave + 4 * half) * 8;
+            ovec res4[RES ? 4 : 1];                              // RES instantiations always have a residual operand
+            if constexpr (RES) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) res4[r] = buf_load(rR, voff + ((r & 3) + 8 * (r >> 2)) * row_bytes);
+            }
+            // The row table of step r+1 is requested during step r; a scheduling barrier per step keeps the
+            // compiler from hoisting all 16 steps' loads to the top (128 live registers, spills).
+            f32x4 w0n = *reinterpret_cast<const f32x4*>(Wrow), w1n = *reinterpret_cast<const f32x4*>(Wrow + 4);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // columns NT*q .. NT*q + NT + 3 of this row: own registers + the next lane(s) by DPP.
-                // (All 64 lanes execute the DPP moves: no divergence up to here.)
-                float hh[NT + 4];
-                float cur[NT];
+                const int cr = (r & 3) + 8 * (r >> 2);           // row of this step inside the lane half's 32-row strip
+                const f32x4 w0 = w0n, w1 = w1n;
+                if (r + 1 < 16) {
+                    const int cn = ((r + 1) & 3) + 8 * ((r + 1) >> 2);
+                    w0n = *reinterpret_cast<const f32x4*>(Wrow + cn * 8);
+                    w1n = *reinterpret_cast<const f32x4*>(Wrow + cn * 8 + 4);
+                }
+                // columns NT*q .. NT*q + NT + 3 of this row: own registers + the next lane(s) by DPP
+                // (all 64 lanes execute the DPP moves: there is no divergence anywhere in this loop)
+                float hh[NT + 4], cur[NT];
 #pragma unroll
                 for (int e = 0; e < NT; ++e) { cur[e] = acc[e][r]; hh[e] = cur[e]; }
 #pragma unroll
-                for (int s = 1; s <= NSH; ++s) {
+                for (int s2 = 1; s2 <= NSH; ++s2) {
 #pragma unroll
-                    for (int e = 0; e < NT; ++e) { cur[e] = dpp_next(cur[e]); hh[s * NT + e] = cur[e]; }
+                    for (int e = 0; e < NT; ++e) { cur[e] = dpp_next(cur[e]); hh[s2 * NT + e] = cur[e]; }
                 }
-                const int row = row_of(r), gm = m0 + row;
-                ovec rr;
+                const int off = voff + cr * row_bytes;
+                ovec y;
 #pragma unroll
-                for (int e = 0; e < NT; ++e) rr[e] = 0.f;
+                for (int e = 0; e < NT; ++e) {
+                    float v = fmaf(w0.x, hh[e], w1.y);                           // bias + 5 taps
+                    v = fmaf(w0.y, hh[e + 1], v); v = fmaf(w0.z, hh[e + 2], v);
+                    v = fmaf(w0.w, hh[e + 3], v); v = fmaf(w1.x, hh[e + 4], v);
+                    y[e] = v;
+                }
                 if constexpr (RES) {
-                    if (Rb) {
-                        rr = res[r % RP];
-                        if (r + RP < 16) res[r % RP] = load_res(p, r + RP);
-                    }
-                }
-                if (act_lane && gm < M) {
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wl + row * 8);
-                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wl + row * 8 + 4);
-                    float y[NT];
+                    const ovec rr = res4[r & 3];
+                    if (r + 4 < 16) res4[r & 3] = buf_load(rR, voff + (((r + 4) & 3) + 8 * ((r + 4) >> 2)) * row_bytes);
 #pragma unroll
-                    for (int e = 0; e < NT; ++e) {
-                        float v = w1.y;                                          // bias
-                        v = fmaf(w0.x, hh[e], v); v = fmaf(w0.y, hh[e + 1], v); v = fmaf(w0.z, hh[e + 2], v);
-                        v = fmaf(w0.w, hh[e + 3], v); v = fmaf(w1.x, hh[e + 4], v);
-                        v = fmaf(v, w1.z, w1.w);                                 // FiLM (1, 0 when off)
-                        if (RES && Rb) v = fmaf(v, p.out_scale, rr[e]);
-                        y[e] = v;
-                    }
-                    store(p, gm, y);
+                    for (int e = 0; e < NT; ++e) y[e] = fmaf(y[e], p.out_scale, rr[e]);
                 }
+                if (Yb) buf_store(rY, off, y);
+                if (Ab) {
+                    ovec a;
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) a[e] = elu1(y[e] * p.act_scale);
+                    buf_store(rA, off, a);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             float* Hw = strips + wave * (4 * HLD);
@@ -320,38 +292,91 @@ template <> struct LdrSel<3> { typedef ConvTrPair<2> type; };
 template <> struct LdrSel<4> { typedef ConvTrPair<1> type; };
 template <> struct LdrSel<5> { typedef ConvTrPair<0> type; };
 
+// One workgroup per (m-tile, time-tile, clip); the 1-D grid is mapped XCD-aware (decode_tile, wv_dev.h): the
+// m-tiles of one activation window are adjacent on one XCD, whose L2 then fetches the window once.
+// (A persistent form with the next tile's head issued before the epilogue was measured and dropped: the
+// workgroup relaunch is not what limits this kernel -- at K = 384 the matrix pipe is busy 80 % of all SIMD
+// cycles at the 2.05 GHz the chip holds under this load, profiles/r02_k1_sq_counters.txt -- and the second
+// set of per-tile state cost the fourth resident wave per SIMD, which short-K layers need to hide the DMA
+// latency.)
 template <class C, int EPI, int LDR, bool RES>
-__global__ __launch_bounds__(256, (LDR == 0 && C::NT == 4) ? 4 : 3) void k1_kernel(PwDwArgs p) {
+__global__ __launch_bounds__(256, 4) void k1_kernel(PwDwArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool REG = LDR != 0;
+    typedef K1Epi<C, EPI, RES> Epi;
+    typedef typename LdrSel<LDR>::type LB;
+    typedef typename NVec<C::NT>::type bvec;
     const TileId tile = decode_tile(p);
     if (!tile.valid) return;
-    const int m0 = tile.m_tile * C::BM;
-    const int b = tile.b;
-    const int K = p.pw.K;
+    f32x4* S4 = reinterpret_cast<f32x4*>(smem);
+    float* table = smem + 2 * C::STAGE4 * 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, i31 = lane & 31;
+    const int cg = tid % C::CG, kp = tid / C::CG;              // register path: rows 2kp, 2kp+1; columns 4cg..
+    const int K = p.pw.K, Mp = p.pw.Mp;
+    const int nchunks = (K + C::BKC - 1) / C::BKC;
+    const f32x4* wq = reinterpret_cast<const f32x4*>(p.pw.wq);
+    const int m0 = tile.m_tile * C::BM, b = tile.b;
     const int to0 = tile.t_tile * p.tto;
     const int ti0 = to0 * p.stride - p.pad - p.off;
-    constexpr int STAGE_FLOATS = 2 * C::STAGE4 * 4;
-    K1Epi<C, EPI, RES> epi;
-    epi.begin(p, smem + STAGE_FLOATS, m0, b, to0);
+    const float* Xb = p.X + (size_t)b * K * p.Tin;
+
+    Epi epi;
+    epi.begin(p, table, m0, b, to0);
+    DmaRows<C> db{};
+    LB lb{};
+    float raw[REG ? LB::NRAW : 1];
+    if constexpr (LDR == 0) db.init(Xb, K, p.Tin, ti0, wave, lane);
+    else if constexpr (LDR == 1) lb = LB{Xb, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
+    else lb = LB{Xb, p.ct_w, p.ct_wt, K, p.pw.Kp, p.Tin, p.Tout, ti0, p.ratio, p.pre_scale, p.pre_elu, 0, 0, {}, {}};
+
+    auto issue = [&](int c, int st) {
+        f32x4* S = S4 + st * C::STAGE4;
+        dma_A<C>(wq, Mp, m0, c, S, wave, lane);
+        if constexpr (!REG) db.issue(c, S + C::A4, wave);
+    };
+    auto commit = [&](int c, int st) {
+        if constexpr (REG) {
+            float o[8];
+            lb.finish2(c * C::BKC + 2 * kp, raw, o);
+            f32x4* Bq = S4 + st * C::STAGE4 + C::A4;
+            Bq[(2 * kp) * C::CG + cg] = f32x4{o[0], o[1], o[2], o[3]};
+            Bq[(2 * kp + 1) * C::CG + cg] = f32x4{o[4], o[5], o[6], o[7]};
+        }
+    };
+    issue(0, 0);
+    if constexpr (REG) { lb.init(cg); lb.fetch2(2 * kp, raw); commit(0, 0); }
     f32x16 acc[C::NT];
 #pragma unroll
     for (int e = 0; e < C::NT; ++e)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-    const float* Xb = p.X + (size_t)b * K * p.Tin;
-    const int nchunks = (K + C::BKC - 1) / C::BKC;
-    const f32x4* wq = reinterpret_cast<const f32x4*>(p.pw.wq);
-    DmaRows<C> db{};
-    if constexpr (LDR == 0) {
-        db.init(Xb, K, p.Tin, ti0, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
-        RowPairLoader none{};
-        k1_mainloop<C, false>(acc, wq, p.pw.Mp, m0, db, none, nchunks, reinterpret_cast<f32x4*>(smem));
-    } else if constexpr (LDR == 1) {
-        RowPairLoader lb{Xb, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
-        k1_mainloop<C, true>(acc, wq, p.pw.Mp, m0, db, lb, nchunks, reinterpret_cast<f32x4*>(smem));
-    } else {
-        typename LdrSel<LDR>::type lb{Xb, p.ct_w, p.ct_wt, K, p.pw.Kp, p.Tin, p.Tout, ti0, p.ratio, p.pre_scale, p.pre_elu, 0, 0, {}, {}};
-        k1_mainloop<C, true>(acc, wq, p.pw.Mp, m0, db, lb, nchunks, reinterpret_cast<f32x4*>(smem));
+    __syncthreads();                                           // first chunk landed, table visible
+    for (int c = 0; c < nchunks; ++c) {
+        const int st = c & 1;
+        const f32x4* S = S4 + st * C::STAGE4;
+        if (c + 1 < nchunks) {
+            issue(c + 1, st ^ 1);
+            if constexpr (REG) lb.fetch2((c + 1) * C::BKC + 2 * kp, raw);
+        }
+        const float* Bf = reinterpret_cast<const float*>(S + C::A4) + C::NT * i31;
+#pragma unroll
+        for (int g = 0; g < C::BKC / 16; ++g) {
+            const f32x4 a0 = S[(4 * g + h) * C::BM + 32 * wave + i31];
+            const f32x4 a1 = S[(4 * g + h + 2) * C::BM + 32 * wave + i31];
+#define WV_K1_STEP(AV, ROW)                                                                        \
+    { const bvec bv = *reinterpret_cast<const bvec*>(Bf + (ROW) * C::BN);                          \
+      _Pragma("unroll") for (int e = 0; e < C::NT; ++e)                                            \
+          acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, bv[e], acc[e], 0, 0, 0); }
+            WV_K1_STEP(a0.x, 16 * g + 4 * h + 0) WV_K1_STEP(a0.y, 16 * g + 4 * h + 1)
+            WV_K1_STEP(a0.z, 16 * g + 4 * h + 2) WV_K1_STEP(a0.w, 16 * g + 4 * h + 3)
+            WV_K1_STEP(a1.x, 16 * g + 8 + 4 * h + 0) WV_K1_STEP(a1.y, 16 * g + 8 + 4 * h + 1)
+            WV_K1_STEP(a1.z, 16 * g + 8 + 4 * h + 2) WV_K1_STEP(a1.w, 16 * g + 8 + 4 * h + 3)
+#undef WV_K1_STEP
+        }
+        if (c + 1 < nchunks) commit(c + 1, st ^ 1);
+        __syncthreads();
     }
     epi.finish(acc, p, smem);              // strips (EPI 1) alias the stages: the main loop ended with a barrier
 }
@@ -413,7 +438,7 @@ static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
 
 hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
     PwDwArgs a = a0;
-    const bool k5 = a.ks == 5 && a.stride == 1 && a.dil == 1 && a.pad == 4;
+    const bool k5 = a.ks == 5 && a.stride == 1 && a.dil == 1 && a.pad == 4 && !a.film;   // FiLM: generic epilogue
     // window width: 64 columns when that computes fewer columns (tile quantisation) or the layer is short
     const int need = (a.ks - 1) * a.dil + 1;
     bool narrow = a.Tin + a.pad + 3 <= 64;
