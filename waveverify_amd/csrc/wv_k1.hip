@@ -43,16 +43,20 @@ __device__ __forceinline__ float dpp_next(float v) {          // lane i <- lane 
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
-template <int NT_, int BKC_>
+// Tile: BM = 32 * WM output channels (one 32-row strip per wave; WM = 2, 3, 4 waves) x BN = 32 * NT columns.
+template <int NT_, int BKC_, int BM_ = 128>
 struct K1 {
-    static constexpr int NT = NT_, BN = 32 * NT_, BKC = BKC_, KQ = BKC_ / 4, BM = 128, NTHREADS = 256;
+    static constexpr int NT = NT_, BN = 32 * NT_, BKC = BKC_, KQ = BKC_ / 4, BM = BM_, WM = BM_ / 32, NTHREADS = 64 * WM;
     static constexpr int A4 = KQ * BM;                      // f32x4 per A stage: [kq][m]
     static constexpr int B4 = BKC * BN / 4;                 // f32x4 per B stage: [k][t]
     static constexpr int STAGE4 = A4 + B4;
-    static constexpr int A_DMA = A4 / 256, B_DMA = B4 / 256;   // DMA instructions per wave and chunk
+    static constexpr int A_PIECES = A4 / 64, B_PIECES = B4 / 64;   // 64-lane DMA pieces per chunk, dealt round-robin to the waves
+    static constexpr int A_PER = (A_PIECES + WM - 1) / WM, B_PER_DMA = (B_PIECES + WM - 1) / WM;
     static constexpr int CG = BN / 4;                       // 4-column groups per row
     static constexpr int HLD = BN + 4;                      // generic epilogue: strip row
-    static_assert(A4 % 256 == 0 && B4 % 256 == 0 && (BKC / 2) * CG == 256, "staging maps");
+    static constexpr int NBT = (BKC / 2) * CG;              // register path: 2(k) x 4(t) micro-tiles per chunk
+    static constexpr int B_PER = (NBT + NTHREADS - 1) / NTHREADS;
+    static_assert(A4 % 64 == 0 && B4 % 64 == 0 && NTHREADS % CG == 0 && 64 % CG == 0, "staging maps");
 };
 
 template <int NT> struct NVec;
@@ -64,19 +68,22 @@ template <class C>
 struct DmaRows {                        // LDR 0: B = X rows, pure copy
     const float* src; size_t ld; int K; int rbase;
     __device__ __forceinline__ void init(const float* Xb, int K_, int Tin, int ti0, int wave, int lane) {
-        const int idx = wave * C::B_DMA * 64 + lane;
-        const int col = ti0 + 4 * (idx % C::CG);
-        rbase = idx / C::CG;
+        const int col = ti0 + 4 * (lane % C::CG);              // a lane keeps its column group in every piece
+        rbase = lane / C::CG;
         const bool inr = col >= 0 && col + 3 < Tin;
         src = inr ? Xb + col : g_zero16;
         ld = inr ? (size_t)Tin : 0;
         K = K_;
+        (void)wave;
     }
     __device__ __forceinline__ void issue(int c, f32x4* Bst, int wave) const {
 #pragma unroll
-        for (int i = 0; i < C::B_DMA; ++i) {
-            const int k = min(c * C::BKC + rbase + i * (64 / C::CG), K - 1);
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)k * ld), (lptr_t)(Bst + (wave * C::B_DMA + i) * 64), 16, 0, 0);
+        for (int i = 0; i < C::B_PER_DMA; ++i) {
+            const int pi = wave + i * C::WM;                   // piece = 64 / CG consecutive rows
+            if (C::B_PIECES % C::WM == 0 || pi < C::B_PIECES) {
+                const int k = min(c * C::BKC + pi * (64 / C::CG) + rbase, K - 1);
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)k * ld), (lptr_t)(Bst + pi * 64), 16, 0, 0);
+            }
         }
     }
 };
@@ -84,10 +91,13 @@ struct DmaRows {                        // LDR 0: B = X rows, pure copy
 template <class C>
 __device__ __forceinline__ void dma_A(const f32x4* wq, int Mp, int m0, int c, f32x4* Ast, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < C::A_DMA; ++i) {
-        const int blk = wave * C::A_DMA + i;                  // 64 fragments = half a kq row
-        const f32x4* s = wq + (size_t)(c * C::KQ + (blk >> 1)) * Mp + m0 + (blk & 1) * 64 + lane;
-        __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(Ast + blk * 64), 16, 0, 0);
+    for (int i = 0; i < C::A_PER; ++i) {
+        const int pi = wave + i * C::WM;                      // piece = 64 consecutive fragments of the [kq][m] stage
+        if (C::A_PIECES % C::WM == 0 || pi < C::A_PIECES) {
+            const int idx = pi * 64 + lane;
+            const f32x4* s = wq + (size_t)(c * C::KQ + idx / C::BM) * Mp + m0 + idx % C::BM;
+            __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(Ast + pi * 64), 16, 0, 0);
+        }
     }
 }
 
@@ -300,7 +310,7 @@ template <> struct LdrSel<5> { typedef ConvTrPair<0> type; };
 // set of per-tile state cost the fourth resident wave per SIMD, which short-K layers need to hide the DMA
 // latency.)
 template <class C, int EPI, int LDR, bool RES>
-__global__ __launch_bounds__(256, 4) void k1_kernel(PwDwArgs p) {
+__global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4) void k1_kernel(PwDwArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool REG = LDR != 0;
     typedef K1Epi<C, EPI, RES> Epi;
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(256, 4) void k1_kernel(PwDwArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, i31 = lane & 31;
-    const int cg = tid % C::CG, kp = tid / C::CG;              // register path: rows 2kp, 2kp+1; columns 4cg..
+    const int cg = tid % C::CG;                                // register path: columns 4cg..; rows 2kp, 2kp+1 per micro-tile
     const int K = p.pw.K, Mp = p.pw.Mp;
     const int nchunks = (K + C::BKC - 1) / C::BKC;
     const f32x4* wq = reinterpret_cast<const f32x4*>(p.pw.wq);
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(256, 4) void k1_kernel(PwDwArgs p) {
     epi.begin(p, table, m0, b, to0);
     DmaRows<C> db{};
     LB lb{};
-    float raw[REG ? LB::NRAW : 1];
+    float raw[REG ? C::B_PER : 1][REG ? LB::NRAW : 1];
     if constexpr (LDR == 0) db.init(Xb, K, p.Tin, ti0, wave, lane);
     else if constexpr (LDR == 1) lb = LB{Xb, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
     else lb = LB{Xb, p.ct_w, p.ct_wt, K, p.pw.Kp, p.Tin, p.Tout, ti0, p.ratio, p.pre_scale, p.pre_elu, 0, 0, {}, {}};
@@ -336,17 +346,32 @@ __global__ __launch_bounds__(256, 4) void k1_kernel(PwDwArgs p) {
         dma_A<C>(wq, Mp, m0, c, S, wave, lane);
         if constexpr (!REG) db.issue(c, S + C::A4, wave);
     };
+    auto fetch = [&](int c) {
+        if constexpr (REG) {
+#pragma unroll
+            for (int r = 0; r < C::B_PER; ++r) {
+                const int idx = tid + r * C::NTHREADS;
+                if (C::NBT % C::NTHREADS == 0 || idx < C::NBT) lb.fetch2(c * C::BKC + 2 * (idx / C::CG), raw[r]);
+            }
+        }
+    };
     auto commit = [&](int c, int st) {
         if constexpr (REG) {
-            float o[8];
-            lb.finish2(c * C::BKC + 2 * kp, raw, o);
             f32x4* Bq = S4 + st * C::STAGE4 + C::A4;
-            Bq[(2 * kp) * C::CG + cg] = f32x4{o[0], o[1], o[2], o[3]};
-            Bq[(2 * kp + 1) * C::CG + cg] = f32x4{o[4], o[5], o[6], o[7]};
+#pragma unroll
+            for (int r = 0; r < C::B_PER; ++r) {
+                const int idx = tid + r * C::NTHREADS;
+                if (!(C::NBT % C::NTHREADS == 0 || idx < C::NBT)) continue;
+                const int kp = idx / C::CG;
+                float o[8];
+                lb.finish2(c * C::BKC + 2 * kp, raw[r], o);
+                Bq[(2 * kp) * C::CG + cg] = f32x4{o[0], o[1], o[2], o[3]};
+                Bq[(2 * kp + 1) * C::CG + cg] = f32x4{o[4], o[5], o[6], o[7]};
+            }
         }
     };
     issue(0, 0);
-    if constexpr (REG) { lb.init(cg); lb.fetch2(2 * kp, raw); commit(0, 0); }
+    if constexpr (REG) { lb.init(cg); fetch(0); commit(0, 0); }
     f32x16 acc[C::NT];
 #pragma unroll
     for (int e = 0; e < C::NT; ++e)
@@ -358,7 +383,7 @@ __global__ __launch_bounds__(256, 4) void k1_kernel(PwDwArgs p) {
         const f32x4* S = S4 + st * C::STAGE4;
         if (c + 1 < nchunks) {
             issue(c + 1, st ^ 1);
-            if constexpr (REG) lb.fetch2((c + 1) * C::BKC + 2 * kp, raw);
+            fetch(c + 1);
         }
         const float* Bf = reinterpret_cast<const float*>(S + C::A4) + C::NT * i31;
 #pragma unroll
@@ -388,7 +413,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // when launch_k1 answers hipErrorNotSupported).
 bool k1_supported(const PwDwArgs& a) {
     if (!a.pw.wq || a.pw.Mp % 128 || a.prec != PREC_F32) return false;
-    if (a.pw.M < 128 || a.pw.M == 192) return false;         // narrow layers: 32/64/96-row tiles of the round-1 core
+    if (a.pw.M < 33) return false;                           // tiny layers: the round-1 core's 32-row tile
     if ((a.Tin & 3) || !aligned16(a.X) || a.pw.K < 1) return false;
     if (a.Y && !aligned16(a.Y)) return false;
     if (a.Yact && !aligned16(a.Yact)) return false;
@@ -401,7 +426,7 @@ bool k1_supported(const PwDwArgs& a) {
 template <class C, int EPI, int LDR, bool RES>
 static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
     const size_t smem = 2 * (size_t)C::STAGE4 * 16 + (size_t)K1Epi<C, EPI, RES>::TABLE_FLOATS * sizeof(float);
-    static_assert(4 * 4 * C::HLD <= 2 * C::STAGE4 * 4, "strips alias the stages");
+    static_assert(C::WM * 4 * C::HLD <= 2 * C::STAGE4 * 4, "strips alias the stages");
     a.num_m = (a.pw.M + C::BM - 1) / C::BM;
     a.num_t = (a.Tout + a.tto - 1) / a.tto;
     a.stagger = 0; a.first_gen = 0;
@@ -410,12 +435,12 @@ static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     std::string name;
     if (prof::enabled())
-        name = std::string(base) + "<128," + std::to_string(C::BN) + (LDR == 0 ? ",dma>" : ",reg>");
+        name = std::string(base) + "<" + std::to_string(C::BM) + "," + std::to_string(C::BN) + (LDR == 0 ? ",dma>" : ",reg>");
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
     const double outs = (a.Y ? 1.0 : 0.0) + (a.Yact ? 1.0 : 0.0) + (a.resid ? 1.0 : 0.0);
     const double flops = a.ct_w ? 2.0 * Bd * a.Tout * K * (M + 2.0) : 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout);
     prof::Scope ps(s, name.c_str(), flops, 4.0 * Bd * (K * a.Tin + M * a.Tout * outs));
-    hipLaunchKernelGGL((k1_kernel<C, EPI, LDR, RES>), dim3((unsigned)nblk), dim3(256), smem, s, a);
+    hipLaunchKernelGGL((k1_kernel<C, EPI, LDR, RES>), dim3((unsigned)nblk), dim3(C::NTHREADS), smem, s, a);
     return hipGetLastError();
 }
 
@@ -436,6 +461,13 @@ static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
     return k1_run<C, EPI, 0, RES>(a, s, base);
 }
 
+template <class C>
+static hipError_t k1_pick_epi(const PwDwArgs& a, hipStream_t s, bool k5) {
+    const bool res = a.resid != nullptr;
+    if (k5) return res ? k1_pick_ldr<C, 0, true>(a, s) : k1_pick_ldr<C, 0, false>(a, s);
+    return res ? k1_pick_ldr<C, 1, true>(a, s) : k1_pick_ldr<C, 1, false>(a, s);
+}
+
 hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
     PwDwArgs a = a0;
     const bool k5 = a.ks == 5 && a.stride == 1 && a.dil == 1 && a.pad == 4 && !a.film;   // FiLM: generic epilogue
@@ -454,15 +486,20 @@ hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
     if (!pw_dw_geometry(a, narrow ? 64 : 128)) return hipErrorNotSupported;
     // every tile's window must start on a multiple of 4 samples (16-byte DMA source addresses)
     if ((a.tto * a.stride) % 4 != 0 || (a.pad + a.off) % 4 != 0) return hipErrorNotSupported;
-    const bool res = a.resid != nullptr;
-    if (narrow) {
-        using C = K1<2, 32>;
-        if (k5) return res ? k1_pick_ldr<C, 0, true>(a, s) : k1_pick_ldr<C, 0, false>(a, s);
-        return res ? k1_pick_ldr<C, 1, true>(a, s) : k1_pick_ldr<C, 1, false>(a, s);
+    // tile height: the one that pads the channel count least (128 on a tie): 192 -> 2 x 96, 64 -> 64, 130 -> 2 x 96
+    int bm = 128, best = (a.pw.M + 127) / 128 * 128;
+    for (int cand : {96, 64}) {
+        const int padded = (a.pw.M + cand - 1) / cand * cand;
+        if (padded < best) { best = padded; bm = cand; }
     }
-    using C = K1<4, 16>;
-    if (k5) return res ? k1_pick_ldr<C, 0, true>(a, s) : k1_pick_ldr<C, 0, false>(a, s);
-    return res ? k1_pick_ldr<C, 1, true>(a, s) : k1_pick_ldr<C, 1, false>(a, s);
+    if (narrow) {
+        if (bm == 128) return k1_pick_epi<K1<2, 32, 128>>(a, s, k5);
+        if (bm == 96) return k1_pick_epi<K1<2, 32, 96>>(a, s, k5);
+        return k1_pick_epi<K1<2, 32, 64>>(a, s, k5);
+    }
+    if (bm == 128) return k1_pick_epi<K1<4, 16, 128>>(a, s, k5);
+    if (bm == 96) return k1_pick_epi<K1<4, 16, 96>>(a, s, k5);
+    return k1_pick_epi<K1<4, 16, 64>>(a, s, k5);
 }
 
 
