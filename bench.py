@@ -10,6 +10,15 @@ batch: wm = G(x, msg) + x, then the detector's time-averaged bit probabilities o
 
 Clips are independent units, so N GPUs = N data-parallel shards with NO data-path collective
 (SURVEY.md section 8e); weak scaling (256 clips per GPU).  Rank 0 prints ONE JSON line.
+
+Two passes: `value` / `ms_per_step` come from a CLEAN pass (W warm-up + exactly K steps, no event
+recording, barrier + synchronize on both sides, MAX over ranks); the per-kernel table and the roofline
+blocks come from a second, PROFILED pass of the same K steps (a hipEvent pair around every launch on
+the launch stream, ~190 pairs per step), whose own wall time is reported as `profiled_ms_per_step`.
+
+Other workloads (--workload): longform (configs[3]), detector_stress (configs[4]) and grad_allreduce
+(configs[2]: the training step's only exchange, a bucketed RCCL all-reduce of 56.1 + 170.1 MB of fp32
+gradients; reports ms per all-reduce and bus GB/s).
 """
 from __future__ import annotations
 
@@ -27,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def parse():
@@ -38,31 +48,86 @@ def parse():
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--cpu-clips", type=int, default=16, help="clips of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="embed_detect", choices=["embed_detect", "longform", "detector_stress"],
+    ap.add_argument("--workload", default="embed_detect",
+                    choices=["embed_detect", "longform", "detector_stress", "grad_allreduce"],
                     help="embed_detect = BASELINE configs[1] (the headline); longform = configs[3] "
-                         "(32 x 30 s, embed+locate+detect); detector_stress = configs[4] (1024 clips, detector only)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
-                    help="GEMM core: exact f32 MFMA, or split-f16 (hi+lo, 3 f16 MFMAs, f32 accumulate)")
+                         "(32 x 30 s, embed+locate+detect); detector_stress = configs[4] (1024 clips, detector "
+                         "only); grad_allreduce = configs[2]'s gradient exchange (no model compute)")
+    ap.add_argument("--bucket-mb", type=float, default=25.0, help="grad_allreduce: bucket size")
     return ap.parse_args()
 
 
 def cpu_baseline(cfgG, cfgD, sdG, sdD, x, msg, n):
     """The reference's CPU path, restated on torch.nn.functional (oracle/wv_oracle_torch.py, pinned to
-    the reference's outputs), timed on this box's host cores on a bounded sample of the same workload.
-    Reported beside the GPU number, never as it."""
+    the reference's outputs), timed on this box's host cores on a bounded sample of the same workload:
+    1 warm-up + 3 timed repetitions, generator / detector split.  Reported
+    beside the GPU number, never as it."""
     from oracle import wv_oracle_torch as OT
     threads = min(os.cpu_count() or 1, 16)            # a 1-GPU box's CPU share
     torch.set_num_threads(threads)
     G, D = OT.Net(cfgG, sdG), OT.Net(cfgD, sdD)
     xs, ms = x[:n], msg[:n]
-    OT.embed(G, xs[:1], ms[:1])                       # warm-up (oneDNN primitive creation)
-    t0 = time.perf_counter()
-    wm = OT.embed(G, xs, ms)
-    mp = OT.mean_probabilities(OT.detector_logits(D, wm))
-    dt = time.perf_counter() - t0
+    wm = OT.embed(G, xs, ms)                          # warm-up (oneDNN primitive creation), full sample
+    OT.mean_probabilities(OT.detector_logits(D, wm))
+    tg, td = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        wm = OT.embed(G, xs, ms)
+        t1 = time.perf_counter()
+        mp = OT.mean_probabilities(OT.detector_logits(D, wm))
+        t2 = time.perf_counter()
+        tg.append(t1 - t0); td.append(t2 - t1)
+    dt = float(np.median([a + b for a, b in zip(tg, td)]))
     return dict(value=n / dt, unit="clips/s", cores=threads, kind="port",
-                sample=f"{n} clips x 1 s @ 16 kHz, one embed+detect pass of the torch-CPU port of the "
-                       f"reference path (fp32, {threads} threads), {dt:.1f} s"), wm.numpy(), mp.numpy()
+                generator_s=round(float(np.median(tg)), 3), detector_s=round(float(np.median(td)), 3),
+                sample=f"{n} clips x 1 s @ 16 kHz, embed+detect by the torch-CPU port of the reference path "
+                       f"(fp32, {threads} threads), 1 warm-up + 3 repetitions, median {dt:.2f} s per pass "
+                       f"(generator {np.median(tg):.2f} s, detector {np.median(td):.2f} s)"), wm.numpy(), mp.numpy()
+
+
+def grad_allreduce(a, dev, dist, world, rank):
+    """configs[2]: the per-step gradient all-reduce of the reference's data-parallel training
+    (scripts/train.py:875-876,1277,1347), on synthetic fp32 gradients of the real sizes."""
+    from waveverify_amd import parallel
+    bucket = int(a.bucket_mb * 1024 * 1024)
+    payloads = parallel.GRAD_PAYLOAD_BYTES
+    # parameter granularity does not matter to the wire: model each payload as 1 MB tensors
+    grads = [torch.randn(250_000, device=dev) for nbytes in payloads.values() for _ in range(nbytes // 1_000_000)]
+    total = sum(g.numel() * 4 for g in grads)
+    buckets = parallel.plan_buckets([g.numel() for g in grads], bucket_bytes=bucket)
+
+    def step():
+        parallel.allreduce_mean_(grads, buckets)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        bus = 2.0 * (world - 1) / world * total / (ms * 1e-3) / 1e9 if world > 1 else 0.0
+        print(json.dumps(dict(
+            metric="grad all-reduce ms per training step (56.1 + 170.1 MB fp32, bucketed)", value=round(ms, 3), unit="ms",
+            n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=False,
+            scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload="grad_allreduce: BASELINE.json configs[2] gradient exchange only (no model compute)",
+                        payload_bytes=total, payloads=payloads, bucket_bytes=bucket, buckets=len(buckets),
+                        backend="nccl (RCCL)" if dist else "none (single rank: flatten/unflatten only)",
+                        world_size=dist.get_world_size() if dist else 1),
+            bus_gb_per_s=round(bus, 2),
+            note="bus GB/s = 2(N-1)/N * bytes / time (ring); xGMI gives one ~153 GB/s link per peer")), flush=True)
 
 
 def main():
@@ -77,7 +142,13 @@ def main():
     dist = None
     if world > 1 or os.environ.get("WV_BENCH_FORCE_DIST") == "1":   # the latter: 1-rank rehearsal of the N>1 path
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)          # RCCL; used for barrier + MAX only
+        dist.init_process_group("nccl", device_id=dev)          # RCCL; used for barrier + MAX only (embed/detect)
+        world = dist.get_world_size()                            # n_gpus is what RCCL reports
+    if a.workload == "grad_allreduce":
+        grad_allreduce(a, dev, dist, world, rank)
+        if dist:
+            dist.destroy_process_group()
+        return
 
     from waveverify_amd import profile
     from waveverify_amd.config import default_config
@@ -92,11 +163,11 @@ def main():
     B = a.batch
     cfgG, cfgD = default_config("generator"), default_config("detector")
     sdG, sdD = random_state_dict(cfgG, 0), random_state_dict(cfgD, 0)
-    G, D = HipNet(cfgG, sdG, dev, precision=a.precision), HipNet(cfgD, sdD, dev, precision=a.precision)
+    G, D = HipNet(cfgG, sdG, dev), HipNet(cfgD, sdD, dev)
     Lnet = None
     if a.workload == "longform":
         cfgL = default_config("locator")
-        Lnet = HipNet(cfgL, random_state_dict(cfgL, 0), dev, precision=a.precision)
+        Lnet = HipNet(cfgL, random_state_dict(cfgL, 0), dev)
     x_np, msg_np = synthetic_clips(B, T, seed=1234 + rank)         # each rank owns its shard
     x, msg = torch.from_numpy(x_np).to(dev), torch.from_numpy(msg_np).to(dev)
 
@@ -110,26 +181,32 @@ def main():
         mp = D.detector_mean_prob(wm)
         return wm, mp, mp >= 0.5
 
+    def timed(profiled: bool):
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        if profiled:
+            profile.reset()
+            profile.enable(True)                  # HIP event pair around every launch, on the launch stream
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        profile.enable(False)
+        if dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
     for _ in range(a.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    profile.reset()
-    profile.enable(True)                      # HIP event pair around every launch, on the launch stream
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        wm, mp, bits = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    profile.enable(False)
-    if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, (wm, mp, bits) = timed(False)        # the number: clean pass, events off
+    elapsed_prof, _ = timed(True)                 # the anatomy: same K steps with per-launch events
     prof = profile.collect()
 
     if rank != 0:
@@ -137,7 +214,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- per-kernel figures from the live event timings of the timed region -------------------
+    # ---- per-kernel figures from the live event timings of the profiled pass --------------------
     by_kernel = {}
     for e in prof:
         k = by_kernel.setdefault(e["kernel"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
@@ -147,16 +224,22 @@ def main():
     dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
     dom_avg_s = dom["ms"] / dom["launches"] * 1e-3
     ach = dom["flops"] / dom["launches"] / dom_avg_s / 1e12
-    traffic, traffic_src, pmc = None, None, None
-    try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same workload
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if a.workload == "embed_detect" and B == 256 and dom_name in pmc["kernels"]:
-            traffic = round(pmc["kernels"][dom_name]["traffic_bytes_per_launch"] / 1e9, 3)
-            traffic_src = "profiles/r01_pmc_traffic.json: GB per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes"
+    pmc = None
+    try:        # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command (profiles/)
+        pmc = json.load(open(PMC_FILE))
     except Exception:
         pass
+    headline = a.workload == "embed_detect" and B == 256 and T == 16000
+
+    def traffic_of(kernel):
+        if pmc and headline and kernel in pmc.get("kernels", {}):
+            return round(pmc["kernels"][kernel]["traffic_bytes_per_launch"] / 1e9, 3)
+        return None
+
     roofline = dict(bound="mfma", kernel=dom_name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                    unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
+                    unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic_of(dom_name),
+                    traffic_source=("profiles/r02_pmc_traffic.json: GB per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, "
+                                    "separate rocprofv3 --pmc passes over this command") if traffic_of(dom_name) else None,
                     algorithmic_gb_per_launch=round(dom["bytes"] / dom["launches"] / 1e9, 3),
                     avg_launch_us=round(dom_avg_s * 1e6, 1), launches_per_step=dom["launches"] // a.steps,
                     share_of_kernel_time=round(dom["ms"] / total_ms, 3),
@@ -167,41 +250,45 @@ def main():
         ms = sum(e["ms"] for e in film); by = sum(e["bytes"] for e in film); fl = sum(e["flops"] for e in film)
         n = sum(e["launches"] for e in film)
         # the north_star's "fused Conv1d+FiLM" unit.  With the 1x1 expansion fused in it has
-        # AI = 95 FLOP/B, above the f32-matrix ridge (157.3 TF / 8 TB/s = 19.7), so its roofline is
+        # AI ~ 70-95 FLOP/B, above the f32-matrix ridge (157.3 TF / 8 TB/s = 19.7), so its roofline is
         # the matrix one; the HBM figures are given beside it.
         tf = fl / (ms * 1e-3) / 1e12
         gbs = by / (ms * 1e-3) / 1e9
-        roofline_film = dict(kernel="pw_dw (Scale->ELU->1x1->strided DW conv->FiLM)", bound="mfma",
+        roofline_film = dict(kernel="pw_dw (ELU(s*x) -> 1x1 -> strided DW conv -> FiLM [-> ELU copy])", bound="mfma",
                              achieved=round(tf, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                              frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-                             traffic=(round(pmc["kernels"][film[0]["kernel"]]["traffic_bytes_per_launch"] / 1e9, 3)
-                                      if pmc and a.workload == "embed_detect" and B == 256 and a.precision == "f32"
-                                      and film[0]["kernel"] in pmc["kernels"] else None),
                              algorithmic_gb_per_launch=round(by / n / 1e9, 3),
                              hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4),
                              arithmetic_intensity_flop_per_byte=round(fl / by, 1),
                              launches_per_step=n // a.steps,
-                             algorithmic_mb_per_clip=round(by / n * (n // a.steps) / B / 1e6, 2))
+                             per_launch=[dict(kernel=e["kernel"], us=round(e["ms"] / e["launches"] * 1e3, 1),
+                                              tflops=round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 1),
+                                              launches_per_step=e["launches"] // a.steps) for e in film],
+                             algorithmic_mb_per_clip=round(by / a.steps / B / 1e6, 2))
     kernels = sorted(({"kernel": k, "ms_per_step": round(v["ms"] / a.steps, 3),
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] else 0.0,
                        "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] else 0.0}
                       for k, v in by_kernel.items()), key=lambda d: -d["ms_per_step"])
 
-    # ---- parity beside the number: BER / waveform error vs the oracle on a sample --------------
     metric = {"embed_detect": "clips/sec embed+detect, 1s@16kHz bs=256",
               "longform": "clips/sec embed+locate+detect, 30s@16kHz bs=32",
               "detector_stress": "clips/sec detect, 1s@16kHz bs=1024"}[a.workload]
+    step_flops = sum(v["flops"] for v in by_kernel.values()) / a.steps
     out = dict(metric=metric, value=round(world * B * a.steps / elapsed, 2),
                unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                ms_per_step=round(elapsed / a.steps * 1e3, 3), higher_is_better=True, scaling="weak",
-               vs_baseline=None, dtype=a.precision, data="synthetic",
+               vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload=f"{a.workload}: {B} clips x {a.seconds:g} s @ 16 kHz per GPU "
                                     f"(BASELINE.json configs[{dict(embed_detect=1, longform=3, detector_stress=4)[a.workload]}]), "
                                     "seeded random weights",
                            batch_per_gpu=B, global_batch=B * world, clip_samples=T,
                            parallelism=f"dp{world} (independent clip shards, no data-path collective)"),
-               roofline=roofline, roofline_film=roofline_film, kernels=kernels[:8],
-               kernel_time_ms_per_step=round(total_ms / a.steps, 3))
+               roofline=roofline, roofline_film=roofline_film, kernels=kernels[:10],
+               profiled_pass=dict(profiler_on=True, ms_per_step=round(elapsed_prof / a.steps * 1e3, 3),
+                                  kernel_time_ms_per_step=round(total_ms / a.steps, 3),
+                                  step_tflops=round(step_flops / (total_ms / a.steps * 1e-3) / 1e12, 2),
+                                  note="hipEvent pair around every launch; `value` is from the clean pass before it"),
+               scaling_measured=("N>1 not measured in this run" if world == 1 else "this line"))
     if not a.no_cpu_baseline and a.workload == "embed_detect":
         cb, wm_ref, mp_ref = cpu_baseline(cfgG, cfgD, sdG, sdD, x_np, msg_np, min(a.cpu_clips, B))
         n = wm_ref.shape[0]

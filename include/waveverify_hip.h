@@ -102,10 +102,6 @@ int wv_model_set_param_wn(wv_model* m, const char* name, const float* host_g, in
 /* Optional override of a CausalSTFT basis buffer `...spec.weight` [2F,1,n_fft] (checkpoints
  * carry it, modules/conv.py:1026); by default the basis is generated as conv.py:1003-1020 does. */
 int wv_model_set_stft_basis(wv_model* m, const char* name, const float* host_data, int64_t numel);
-/* GEMM precision of the fused units: 0 = exact f32 matrix instructions (default), 1 = split-f16
- * ("f16x3": x = hi + lo in f16, three f16 MFMAs per product, ~2^-22 relative error, 5.3x the rate).
- * May be changed at any time, also after finalize. */
-int wv_model_set_precision(wv_model* m, int precision);
 /* Pack (transpose / interleave / compose heads) and upload. Fails if a parameter is missing. */
 int wv_model_finalize(wv_model* m);
 
@@ -137,8 +133,6 @@ int wv_encoder_forward(wv_model* m, const float* x, const float* msg, int msg_ro
  * Weights / biases (w_*, *_bias, bias, basis) are HOST pointers in the reference's own layouts;
  * they are packed and uploaded per call and the call is synchronous: these entry points exist so
  * that every kernel can be parity-tested on its own, not for serving. */
-
-int wv_op_set_precision(int precision);   /* precision used by the wv_op_* calls below */
 
 /* Y = epilogue( DWconv_k,s,d( W1x1 @ act(pre_scale * X) ) + dw_bias )
  *   X [B,K,Tin], w_pw [M,K] (1x1, no bias), w_dw [M,ks], dw_bias [M] or NULL

@@ -59,6 +59,25 @@ def test_full_nets_vs_reference_golden(golden_dir, nets, T):
     assert dmax(ll[..., ::7], g["loc_logits_sub"]) <= 2e-4
 
 
+def test_narrow_margin_detector_vs_reference(golden_dir, nets):
+    """A detector whose last-layer bias keeps the reference's own small scale: time-averaged probabilities
+    crowd the 0.5 threshold (margins 1e-3 .. 4e-2 instead of >= 0.17).  Bits are compared exactly where the
+    reference's margin exceeds the measured |dp| (with a 4x guard), and that must cover every bit."""
+    from waveverify_amd.nets import HipNet
+    g = np.load(os.path.join(golden_dir, "narrow_margin_T16000.npz"))
+    cfg = default_config("detector")
+    sd = random_state_dict(cfg, 0)
+    sd["last_layer.bias"] = g["last_layer_bias"]
+    D = HipNet(cfg, sd)
+    mp = D.detector_mean_prob(torch.from_numpy(g["wm"]).cuda()).cpu().numpy()
+    err = float(np.abs(mp - g["det_mean_prob"]).max())
+    assert err <= 1e-5, err
+    decidable = g["margin"] > 4 * max(err, 1e-7)
+    assert decidable.all(), f"{(~decidable).sum()} bits closer to the threshold than 4 x |dp| = {4 * err:.1e}"
+    assert ((mp >= 0.5).astype(np.int32) == g["det_bits"])[decidable].all()
+    assert float(g["margin"].min()) < 5e-3            # the fixture really is narrow
+
+
 def test_speech_clips(golden_dir, nets):
     g = np.load(os.path.join(golden_dir, "speech_T16000.npz"))
     x, msg = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["msg"]).cuda()
@@ -152,20 +171,3 @@ def test_errors_are_loud(nets):
         HipNet(cfg, random_state_dict(cfg, 0), device="cpu")
 
 
-def test_split_f16_precision_full_nets(golden_dir, nets):
-    """precision="f16x3" (split-f16 matrix core on the K >= 256 layers): same bar as f32 against the
-    reference golden -- watermarked samples within 1e-4 (measured 7e-8), identical bits."""
-    g = np.load(os.path.join(golden_dir, "full_T16000.npz"))
-    x, msg = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["msg"]).cuda()
-    G, D = nets["generator"], nets["detector"]
-    try:
-        G.set_precision("f16x3")
-        D.set_precision("f16x3")
-        wm = G.generator(x, msg, add_input=True)
-        assert dmax(wm, g["wm"]) <= 2e-5
-        mp = D.detector_mean_prob(wm)
-        assert dmax(mp, g["det_mean_prob"]) <= 1e-5
-        assert ((mp >= 0.5).int().cpu().numpy() == g["det_bits"]).all()
-    finally:
-        G.set_precision("f32")
-        D.set_precision("f32")

@@ -293,28 +293,3 @@ def test_head(ops, D, O_, nb, hop, Fr, T):
     assert torch.equal(mean, mean_only)            # fused reduction is deterministic
 
 
-# ------------------------------------------------------------------ split-f16 ("f16x3") GEMM core
-@pytest.mark.parametrize("K,M,Tin,ks,stride,dil", [c for c in PW_DW_CASES if c[0] in (64, 128, 96, 768, 5, 512, 32)])
-def test_pw_dw_f16x3(ops, K, M, Tin, ks, stride, dil):
-    """3 x f16 MFMA on (hi, lo) halves: must stay float32-class (<= 3e-6 of max|ref|) on every K1 shape,
-    including values that make lo subnormal in f16 (tiny activations)."""
-    rng = np.random.default_rng(K + M + Tin)
-    B = 2
-    X = rnd(rng, B, K, Tin)
-    X[0, :, : Tin // 2] *= 1e-3                       # small magnitudes: lo falls below the f16 normal range
-    w_pw = rnd(rng, M, K, 1, scale=K ** -0.5)
-    w_dw = rnd(rng, M, 1, ks, scale=ks ** -0.5)
-    b_dw = rnd(rng, M, scale=0.1)
-    h = O.sconv1d(O.elu(X * np.float32(0.87)), w_pw, None)
-    ref = O.sconv1d(h, w_dw, b_dw, stride=stride, dilation=dil, groups=M)
-    ops.set_precision("f16x3")
-    try:
-        got = ops.pw_dw(cu(X), w_pw, w_dw, b_dw, stride=stride, dilation=dil, pre_scale=0.87, pre_elu=True)
-    finally:
-        ops.set_precision("f32")
-    close(got, ref.astype(np.float32), 3e-6, "pw_dw f16x3")
-    # where the inputs are tiny the absolute error must be tiny too (no flush of the lo halves)
-    half = ref[0, :, : max(1, (Tin // 2 - 8) // stride)]
-    if half.size:
-        err = np.abs(got.cpu().numpy()[0, :, : half.shape[-1]] - half).max()
-        assert err <= 3e-6 * max(1e-3, np.abs(half).max()) + 1e-7, err

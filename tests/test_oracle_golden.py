@@ -171,6 +171,20 @@ def test_metrics_pinned_to_reference_classes(golden_dir):
     assert n_raise == 4
 
 
+def test_narrow_margin_detector_fixture(golden_dir):
+    """The oracle on the narrow-margin detector fixture (tests/golden/make_golden_narrow.py): same bar as the
+    wide-margin ones, and every bit is decidable (margin > 4 x error)."""
+    g = np.load(os.path.join(golden_dir, "narrow_margin_T16000.npz"))
+    cfg = default_config("detector")
+    sd = random_state_dict(cfg, 0)
+    sd["last_layer.bias"] = g["last_layer_bias"]
+    mp = O.mean_probabilities(O.detector_forward(cfg, sd, g["wm"][:2]))
+    err = float(np.abs(mp - g["det_mean_prob"][:2]).max())
+    assert err <= 1e-5
+    assert (g["margin"][:2] > 4 * max(err, 1e-7)).all()
+    assert ((mp >= 0.5).astype(np.int32) == g["det_bits"][:2]).all()
+
+
 def test_torch_flavoured_oracle_matches_reference(golden_dir):
     """oracle/wv_oracle_torch.py (what bench.py times as the CPU baseline) is pinned like the numpy one."""
     import torch

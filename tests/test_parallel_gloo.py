@@ -63,3 +63,50 @@ def test_two_rank_sharding_matches_single_process(tmp_path, B):
     assert np.array_equal(a >= 0.5, mp_ref >= 0.5)
     wm = np.concatenate([np.load(tmp_path / f"wm_{r}.npy") for r in (0, 1)])
     assert wm.shape == wm_ref.shape and np.abs(wm - wm_ref.numpy()).max() <= 1e-6
+
+
+# ---- gradient-bucket all-reduce (BASELINE configs[2]: its microbench is bench.py --workload grad_allreduce)
+def test_bucket_plan_covers_every_parameter_once():
+    from waveverify_amd import params
+    from waveverify_amd.config import default_config
+    numels = [int(np.prod(shape)) for _, shape, _ in params.param_specs(default_config("generator"))]
+    buckets = parallel.plan_buckets(numels, bucket_bytes=8 << 20)
+    flat = [i for b in buckets for i in b]
+    assert sorted(flat) == list(range(len(numels)))                 # a partition
+    assert flat == list(reversed(range(len(numels))))               # in gradient-ready order
+    sizes = [sum(numels[i] for i in b) * 4 for b in buckets]
+    assert all(s >= 8 << 20 for s in sizes[:-1]) and len(buckets) >= 3
+    assert parallel.plan_buckets([10, 10 ** 8, 10], bucket_bytes=1 << 20) == [[2, 1], [0]]
+
+
+def _ar_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        shapes = [(7, 3), (1000,), (33, 5, 2), (1,), (257, 64)]
+        grads = [torch.randn(*s, generator=g) for s in shapes]
+        buckets = parallel.plan_buckets([t.numel() for t in grads], bucket_bytes=4096)
+        n = parallel.allreduce_mean_(grads, buckets)
+        assert n == len(buckets) >= 2
+        torch.save(grads, os.path.join(out_dir, f"g{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_allreduce_is_the_mean(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ar_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    shapes = [(7, 3), (1000,), (33, 5, 2), (1,), (257, 64)]
+    want = None
+    for r in (0, 1):
+        g = torch.Generator().manual_seed(100 + r)
+        gr = [torch.randn(*s, generator=g) for s in shapes]
+        want = gr if want is None else [a + b for a, b in zip(want, gr)]
+    want = [w / 2 for w in want]
+    for r in (0, 1):
+        got = torch.load(tmp_path / f"g{r}.pt", weights_only=True)
+        for a, b in zip(got, want):
+            assert torch.allclose(a, b, atol=1e-6)

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from waveverify_amd import ops, profile
 
 
-def run(C, T, B, M=None, ks=5, stride=1, resid=True, reps=5, film=False, prec="f32", pre_elu=True, yact=False):
+def run(C, T, B, M=None, ks=5, stride=1, resid=True, reps=5, film=False, pre_elu=True, yact=False):
     M = M or C
     rng = np.random.default_rng(0)
     X = torch.randn(B, C, T, device="cuda")
@@ -21,7 +21,6 @@ def run(C, T, B, M=None, ks=5, stride=1, resid=True, reps=5, film=False, prec="f
     Tout = -(-T // stride)
     R = torch.randn(B, M, Tout, device="cuda") if resid else None
     F = torch.randn(B, 4, 2, device="cuda") if film else None
-    ops.set_precision(prec)
     kw = dict(resid=R, film=F, bands=4 if film else 1, stride=stride, pre_scale=0.87 if pre_elu else 1.0,
               pre_elu=pre_elu, out_scale=0.5, act_scale=0.9 if yact else None)
     ops.pw_dw(X, w_pw, w_dw, b, **kw)                    # warm-up
@@ -30,7 +29,6 @@ def run(C, T, B, M=None, ks=5, stride=1, resid=True, reps=5, film=False, prec="f
         ops.pw_dw(X, w_pw, w_dw, b, **kw)
     profile.enable(False)
     e = profile.collect()[0]
-    ops.set_precision("f32")
     us = e["ms"] / e["launches"] * 1e3
     tf = e["flops"] / e["launches"] / (us * 1e-6) / 1e12
     gb = e["bytes"] / e["launches"] / (us * 1e-6) / 1e9

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-role time table of one embed+detect pass (library event profiler): where the step goes.
 
-    python tools/roles.py [--batch 256] [--seconds 1] [--precision f32]"""
+    python tools/roles.py [--batch 256] [--seconds 1]"""
 import argparse
 import os
 import sys
@@ -18,13 +18,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--seconds", type=float, default=1.0)
-    ap.add_argument("--precision", default="f32")
     ap.add_argument("--steps", type=int, default=3)
     a = ap.parse_args()
     wv = WaveVerify.random_init(seed=0, device="cuda:0")
     gen, det = wv.model.generator, wv.model.detector
-    gen.set_precision(a.precision)
-    det.set_precision(a.precision)
     T = int(16000 * a.seconds)
     x_np, msg_np = synthetic_clips(a.batch, T, seed=1)
     x, msg = torch.from_numpy(x_np).cuda(), torch.from_numpy(msg_np).cuda()

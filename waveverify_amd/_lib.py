@@ -47,8 +47,6 @@ SIGNATURES = {
     "wv_model_set_param_wn": (C.c_int, [_VP, C.c_char_p, _VP, C.c_int64, _VP, C.c_int64]),
     "wv_model_set_stft_basis": (C.c_int, [_VP, C.c_char_p, _VP, C.c_int64]),
     "wv_model_finalize": (C.c_int, [_VP]),
-    "wv_model_set_precision": (C.c_int, [_VP, C.c_int]),
-    "wv_op_set_precision": (C.c_int, [C.c_int]),
     "wv_workspace_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),
     "wv_generator_forward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int,
                                        _VP, C.c_size_t, _VP]),

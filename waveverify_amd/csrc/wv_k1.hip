@@ -412,7 +412,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Shapes this core covers; everything else stays on the round-1 kernel (launch_pw_dw falls through, also
 // when launch_k1 answers hipErrorNotSupported).
 bool k1_supported(const PwDwArgs& a) {
-    if (!a.pw.wq || a.pw.Mp % 128 || a.prec != PREC_F32) return false;
+    if (!a.pw.wq || a.pw.Mp % 128) return false;
     if (a.pw.M < 33) return false;                           // tiny layers: the round-1 core's 32-row tile
     if ((a.Tin & 3) || !aligned16(a.X) || a.pw.K < 1) return false;
     if (a.Y && !aligned16(a.Y)) return false;

@@ -19,35 +19,10 @@ inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 struct PwWeight {
     const float* wt = nullptr;
     int K = 0, M = 0, Kp = 0, Mp = 0;
-    // split-f16 fragments for the 3xf16 MFMA core: wh[Kh/8][2 (hi,lo)][Mp] of 8 halfs (16 bytes),
-    // fragment (kb, m) = W[m][8kb .. 8kb+7]; Kh = roundup(K, 32), zero padded.  May be null.
-    const void* wh = nullptr;
-    int Kh = 0;
     // k-inner f32 layout for the row-strip cores: wq[roundup(K,32)/4][Mp][4] (W[m][4kq .. 4kq+3], zero padded;
     // the LDS-DMA core reads whole 32-deep chunks); may be null
     const float* wq = nullptr;
 };
-constexpr int BKH = 32;         // K-chunk of the split-f16 core
-enum Precision { PREC_F32 = 0, PREC_F16X3 = 1 };
-
-// Host: split a [M][K] f32 weight into hi/lo f16 fragments, layout wh[Kh/8][2][Mp][8] (uint16 bits).
-inline std::vector<uint16_t> pack_split_f16(const float* w, int M, int K, int Mp, int Kh) {
-    std::vector<uint16_t> out((size_t)(Kh / 8) * 2 * Mp * 8, 0);
-    for (int m = 0; m < M; ++m)
-        for (int k = 0; k < K; ++k) {
-            float x = w[(size_t)m * K + k];
-            x = x > 65504.f ? 65504.f : (x < -65504.f ? -65504.f : x);
-            const _Float16 hi = (_Float16)x;
-            const _Float16 lo = (_Float16)(x - (float)hi);
-            uint16_t hb, lb;
-            std::memcpy(&hb, &hi, 2); std::memcpy(&lb, &lo, 2);
-            const size_t kb = k / 8, i = k % 8;
-            out[((kb * 2 + 0) * Mp + m) * 8 + i] = hb;
-            out[((kb * 2 + 1) * Mp + m) * 8 + i] = lb;
-        }
-    return out;
-}
-
 // ---- K1: 1x1 GEMM -> depth-wise stencil epilogue ------------------------------------------
 struct PwDwArgs {
     const float* X;       // [B, K, Tin]
@@ -65,7 +40,6 @@ struct PwDwArgs {
     float* Yact;          // optional SECOND output [B, M, Tout] = ELU(act_scale * y): the consumer's prologue
     float act_scale;      //   hoisted into the producer, so that the consumer stages its operand by LDS-DMA
                           //   (a pure copy).  Y may be null when only the activated copy is consumed.
-    int prec;             // Precision of the GEMM core
     int num_m, num_t;         // tile counts (filled by launch_pw_dw; XCD-aware 1-D grid)
     int stagger, first_gen;   // de-phasing of the first workgroup generation (see kernel)
     int tto, off;         // filled by launch_pw_dw: outputs per time tile; stencil offset inside

@@ -286,7 +286,7 @@ __device__ __forceinline__ void gemm_mainloop_q(f32x16 (&acc)[1][T::NT], const f
     }
 }
 
-// K1 epilogue (shared by the f32 and the split-f16 GEMM cores).  begin() runs BEFORE the GEMM:
+// K1 epilogue of the round-1 core.  begin() runs BEFORE the GEMM:
 // it fills the per-row table (taps, bias, FiLM gamma/beta) in a dedicated LDS region and issues
 // the first residual loads, so none of the epilogue's global-memory latency is exposed after
 // the matrix phase.  finish() spills the wave's 32 x BN accumulator strip two rows at a time
@@ -525,164 +525,6 @@ __global__ __launch_bounds__(T::NTHREADS, (T::NTHREADS >= 192 && T::BN == 128) ?
         gemm_mainloop_q<T>(acc, reinterpret_cast<const f32x4*>(p.pw.wq), p.pw.Mp, m0, lb, p.pw.Kp / BK,
                            reinterpret_cast<f32x4*>(smem));
     }
-    epi.finish(acc, p);
-}
-
-// ------------------------------------------------------------------------------------------
-// Split-f16 GEMM core ("f16x3").  x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 significant
-// bits.  a.b ~= ah.bh + ah.bl + al.bh on v_mfma_f32_32x32x16_f16 (f32 accumulate): three matrix
-// instructions at 16x the f32 matrix rate each = 5.3x the exact-f32 core, with a relative error
-// of ~2^-22 per product (the dropped al.bl term) -- float32-class results.  Values beyond the f16
-// range are clamped to +-65504 (never reached by audio-scale activations).
-// LDS holds 16-byte fragments (8 halfs along k): [kq][hi|lo][row]; a fragment is one MFMA
-// operand (lane l: row l&31, k = 8*(l>>5)+j), read by ds_read_b128 from consecutive slots.
-// A fragments are pre-split on the host; B is split at commit time.  B slots are XOR-swizzled
-// (n ^ ((n>>2)&3)) so a thread's four 16-byte column writes do not pile on four banks.
-// ------------------------------------------------------------------------------------------
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-
-template <class T>
-struct HT {
-    static constexpr int KB = BKH / 8;
-    static constexpr int NA = KB * 2 * T::BM;                 // A fragments per stage
-    static constexpr int NBT = KB * T::BN;                    // B micro-tiles: 8 k rows x 1 column
-    static constexpr int A_PER = (NA + T::NTHREADS - 1) / T::NTHREADS;
-    static constexpr int B_PER = (NBT + T::NTHREADS - 1) / T::NTHREADS;
-    static constexpr int STAGE = KB * 2 * (T::BM + T::BN);    // 16-byte fragments per stage
-};
-
-// B operand rows for the split-f16 core: one column, 8 consecutive k rows per micro-tile.  Lanes
-// run along time, so the 4-byte loads of a wave are one contiguous 256-byte segment per row and
-// the fragment a thread builds (8 halfs along k for its column) lands in consecutive LDS slots.
-struct ColLoaderH {
-    const float* base; int K, ld, ncols, c0; float scale; int elu;
-    __device__ __forceinline__ void fetch8(int k0, int col, float (&raw)[8]) const {
-        const int c = c0 + col;
-        const bool inb = c >= 0 && c < ncols;
-        const float* p = base + (inb ? c : 0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) raw[i] = (inb && k0 + i < K) ? p[(size_t)(k0 + i) * ld] : 0.f;
-    }
-    __device__ __forceinline__ float xform(float v) const { return act(v, scale, elu); }
-};
-
-__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
-    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
-    hi = (_Float16)x;
-    lo = (_Float16)(x - (float)hi);
-}
-
-template <class T, class LB>
-__device__ __forceinline__ void gemm_mainloop_h(f32x16 (&acc)[1][T::NT], const u32x4* __restrict__ wh,
-                                                int Mp, int m0, LB& lb, int nchunks, u32x4* smem) {
-    using H = HT<T>;
-    static_assert(T::WN == 1 && T::MT == 1, "row-strip tile");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32x4 ra[2][H::A_PER];
-    float rb[2][H::B_PER][8];
-
-    auto fetch = [&](int c, u32x4 (&xa)[H::A_PER], float (&xb)[H::B_PER][8]) {
-#pragma unroll
-        for (int r = 0; r < H::A_PER; ++r) {
-            const int idx = tid + r * T::NTHREADS;
-            if (H::NA % T::NTHREADS == 0 || idx < H::NA) {
-                const int m = idx % T::BM, rest = idx / T::BM;          // rest = kq*2 + hl
-                xa[r] = wh[(size_t)(c * H::KB * 2 + rest) * Mp + m0 + m];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < H::B_PER; ++r) {
-            const int idx = tid + r * T::NTHREADS;
-            if (H::NBT % T::NTHREADS == 0 || idx < H::NBT)
-                lb.fetch8(c * BKH + (idx / T::BN) * 8, idx % T::BN, xb[r]);
-        }
-    };
-    auto commit = [&](u32x4* buf, const u32x4 (&xa)[H::A_PER], const float (&xb)[H::B_PER][8]) {
-        u32x4* As = buf;
-        u32x4* Bs = buf + H::KB * 2 * T::BM;
-#pragma unroll
-        for (int r = 0; r < H::A_PER; ++r) {
-            const int idx = tid + r * T::NTHREADS;
-            if (H::NA % T::NTHREADS == 0 || idx < H::NA) As[idx] = xa[r];
-        }
-#pragma unroll
-        for (int r = 0; r < H::B_PER; ++r) {
-            const int idx = tid + r * T::NTHREADS;
-            if (!(H::NBT % T::NTHREADS == 0 || idx < H::NBT)) continue;
-            const int kq = idx / T::BN, col = idx % T::BN;
-            unsigned hw[4], lw[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                half2v h2, l2;
-                _Float16 h, l;
-                split_f16(lb.xform(xb[r][2 * i]), h, l);
-                h2[0] = h; l2[0] = l;
-                split_f16(lb.xform(xb[r][2 * i + 1]), h, l);
-                h2[1] = h; l2[1] = l;
-                hw[i] = __builtin_bit_cast(unsigned, h2);
-                lw[i] = __builtin_bit_cast(unsigned, l2);
-            }
-            Bs[(kq * 2 + 0) * T::BN + col] = u32x4{hw[0], hw[1], hw[2], hw[3]};
-            Bs[(kq * 2 + 1) * T::BN + col] = u32x4{lw[0], lw[1], lw[2], lw[3]};
-        }
-    };
-    const int h = lane >> 5, i31 = lane & 31;
-    auto compute = [&](const u32x4* As) {
-        const u32x4* Bs = As + H::KB * 2 * T::BM;
-#pragma unroll
-        for (int s = 0; s < BKH / 16; ++s) {
-            const int kq = 2 * s + h;
-            const half8 ah = __builtin_bit_cast(half8, As[(kq * 2 + 0) * T::BM + 32 * wave + i31]);
-            const half8 al = __builtin_bit_cast(half8, As[(kq * 2 + 1) * T::BM + 32 * wave + i31]);
-#pragma unroll
-            for (int j = 0; j < T::NT; ++j) {
-                const half8 bh = __builtin_bit_cast(half8, Bs[(kq * 2 + 0) * T::BN + 32 * j + i31]);
-                const half8 bl = __builtin_bit_cast(half8, Bs[(kq * 2 + 1) * T::BN + 32 * j + i31]);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[0][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[0][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0][j], 0, 0, 0);
-            }
-        }
-    };
-
-    // two register sets, two LDS stages: chunk c+2 is in flight across two matrix phases
-    fetch(0, ra[0], rb[0]);
-    commit(smem, ra[0], rb[0]);
-    if (nchunks > 1) fetch(1, ra[1], rb[1]);
-    __syncthreads();
-    for (int c = 0; c < nchunks; c += 2) {
-        if (c + 2 < nchunks) fetch(c + 2, ra[0], rb[0]);
-        compute(smem);
-        if (c + 1 < nchunks) commit(smem + H::STAGE, ra[1], rb[1]);
-        __syncthreads();
-        if (c + 1 >= nchunks) break;
-        if (c + 3 < nchunks) fetch(c + 3, ra[1], rb[1]);
-        compute(smem + H::STAGE);
-        if (c + 2 < nchunks) commit(smem, ra[0], rb[0]);
-        __syncthreads();
-    }
-}
-
-template <class T, int KS>
-__global__ __launch_bounds__(T::NTHREADS, 2) void pw_dw_h_kernel(PwDwArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const TileId tile = decode_tile(p);
-    if (!tile.valid) return;
-    const int m0 = tile.m_tile * T::BM;
-    const int b = tile.b;
-    const int K = p.pw.K;
-    const int to0 = tile.t_tile * p.tto;
-    const int ti0 = to0 * p.stride - p.pad - p.off;
-    PwDwEpi<T, KS, 2> epi;
-    epi.begin(p, smem + 2 * HT<T>::STAGE * 4, smem, m0, b, to0);
-    static_assert(PwDwEpi<T, KS>::STRIP_FLOATS <= 2 * HT<T>::STAGE * 4, "strips alias the stages");
-    f32x16 acc[1][T::NT];
-    zero_acc<T>(acc);
-    ColLoaderH lb{p.X + (size_t)b * K * p.Tin, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu};
-    gemm_mainloop_h<T>(acc, reinterpret_cast<const u32x4*>(p.pw.wh), p.pw.Mp, m0, lb, p.pw.Kh / BKH,
-                       reinterpret_cast<u32x4*>(smem));
     epi.finish(acc, p);
 }
 
@@ -1247,22 +1089,6 @@ static hipError_t run_pw_dw_ks(PwDwArgs a, hipStream_t s) {
     if (nblk < 4LL * a.first_gen) a.stagger = 0;
     static const std::string name = tile_name<T>(KS ? "pw_dw_k5" : "pw_dw");
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
-    // the split-f16 core pays off for the 4-wave (BM = 128) tiles; smaller tiles (C <= 96 layers,
-    // HBM-bound anyway) stay on the f32 core
-    if constexpr (T::NTHREADS == 256 && T::BN == 64) if (a.prec == PREC_F16X3 && a.pw.wh && a.pw.K >= 256 && !a.ct_w) {
-        const size_t hs = 2 * (size_t)HT<T>::STAGE * 16 + eb;
-        static std::atomic<unsigned> attr_done{0};
-        {
-            hipError_t e = set_smem(pw_dw_h_kernel<T, KS>, hs, attr_done);
-            if (e != hipSuccess) return e;
-        }
-        a.stagger = 0;
-        static const std::string hname = tile_name<T>(KS ? "pw_dw_k5_h" : "pw_dw_h");
-        prof::Scope ph(s, hname.c_str(), 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout),
-                       4.0 * Bd * (K * a.Tin + M * a.Tout * (a.resid ? 2.0 : 1.0)));
-        hipLaunchKernelGGL((pw_dw_h_kernel<T, KS>), grid, dim3(T::NTHREADS), hs, s, a);
-        return hipGetLastError();
-    }
     if constexpr (KS == 5) if (a.ct_w) {
         // upsample unit: ConvTranspose producer in the B loader, identity stencil (see pw_dw_kernel)
         static const std::string cname = tile_name<T>("convtr_pw");
@@ -1350,8 +1176,6 @@ hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
         }
     }
     const int bm = pick_bm(a.pw.M);
-    // split-f16 core: only where the layer is matrix-bound (K >= 256) and only on the 128 x 64 tile
-    if (a.prec == PREC_F16X3 && a.pw.wh && a.pw.K >= 256 && bm == 128 && need + 3 <= 64 && !a.ct_w) narrow = true;
     if (narrow) {
         switch (bm) {
             case 32: return run_pw_dw<Tile<32, 64, 1, 1>>(a, s);

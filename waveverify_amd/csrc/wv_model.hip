@@ -65,7 +65,6 @@ struct wv_model {
     std::unordered_map<std::string, int> index;
     std::unordered_map<std::string, std::vector<float>> stft_override;
     bool finalized = false;
-    int prec = wv::PREC_F32;                     // GEMM precision of the fused units
     std::vector<void*> dev;                      // owned device allocations
 
     // ---- encoder plan
@@ -227,11 +226,6 @@ struct Uploader {
         for (int mm = 0; mm < M; ++mm)
             for (int k = 0; k < K; ++k) t[(size_t)k * p.Mp + mm] = w[(size_t)mm * K + k];
         p.wt = up(t);
-        p.Kh = wv::round_up(K, wv::BKH);
-        const std::vector<uint16_t> hf = wv::pack_split_f16(w.data(), M, K, p.Mp, p.Kh);
-        std::vector<float> as_f(hf.size() / 2);
-        std::memcpy(as_f.data(), hf.data(), hf.size() * 2);
-        p.wh = up(as_f);
         std::vector<float> q((size_t)wv::round_up(K, 32) * p.Mp, 0.f);   // wq[roundup(K,32)/4][Mp][4]
         for (int mm = 0; mm < M; ++mm)
             for (int k = 0; k < K; ++k) q[((size_t)(k / 4) * p.Mp + mm) * 4 + (k & 3)] = w[(size_t)mm * K + k];
@@ -495,12 +489,12 @@ struct Stream {
 // SEANetResnetBlock (seanet.py:245-281) as two K1 launches.  next_scale > 0: also write ELU(next_scale*y);
 // want_raw: write y itself (needed when y is a later residual / raw operand).
 int run_resblock(const ResBlock& r, Stream& st, bool want_raw, float next_scale, int B, int T, hipStream_t s,
-                 const char* role, int prec) {
+                 const char* role) {
     wv::prof::set_role(role);
     // Fused form: measured slower than two K1 launches until it is made persistent;
     // opt-in with WV_FUSED_RB=1 for tools/rbbench.py and the parity tests of the in-model path.
     static const bool fused_on = getenv("WV_FUSED_RB") && atoi(getenv("WV_FUSED_RB")) != 0;
-    if (fused_on && st.act && st.raw && r.tab1 && r.dil1 == 1 && r.dil2 == 1 && prec == wv::PREC_F32) {
+    if (fused_on && st.act && st.raw && r.tab1 && r.dil1 == 1 && r.dil2 == 1) {
         // narrow layers: the whole block in one launch, the intermediate stays in LDS (wv_k1.hip)
         wv::RbArgs f{};
         f.Xa = st.act; f.Xr = st.raw; f.pw1 = r.pw1; f.pw2 = r.pw2; f.tab1 = r.tab1; f.tab2 = r.tab2;
@@ -516,7 +510,7 @@ int run_resblock(const ResBlock& r, Stream& st, bool want_raw, float next_scale,
     else { a.X = st.raw; a.pre_scale = r.pre_scale; a.pre_elu = 1; }
     a.pw = r.pw1; a.dw_w = r.dw1_w; a.dw_b = r.dw1_b; a.Y = nullptr; a.Yact = st.u; a.act_scale = 1.f;
     a.B = B; a.Tin = T; a.Tout = T; a.ks = r.ks; a.stride = 1; a.dil = r.dil1; a.pad = (r.ks - 1) * r.dil1;
-    a.out_scale = 1.f; a.bands = 1; a.prec = prec;
+    a.out_scale = 1.f; a.bands = 1;
     LAUNCH(wv::launch_pw_dw(a, s));
     wv::PwDwArgs b{};
     float* yr = want_raw ? st.other_raw() : nullptr;
@@ -524,7 +518,7 @@ int run_resblock(const ResBlock& r, Stream& st, bool want_raw, float next_scale,
     b.X = st.u; b.pw = r.pw2; b.dw_w = r.dw2_w; b.dw_b = r.dw2_b; b.resid = st.raw; b.Y = yr; b.Yact = ya;
     b.act_scale = next_scale;
     b.B = B; b.Tin = T; b.Tout = T; b.ks = r.ks; b.stride = 1; b.dil = r.dil2; b.pad = (r.ks - 1) * r.dil2;
-    b.pre_scale = 1.f; b.pre_elu = 0; b.out_scale = r.out_scale; b.bands = 1; b.prec = prec;
+    b.pre_scale = 1.f; b.pre_elu = 0; b.out_scale = r.out_scale; b.bands = 1;
     LAUNCH(wv::launch_pw_dw(b, s));
     st.raw = yr; st.act = ya;
     return WV_OK;
@@ -579,7 +573,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
                 // the last block feeds the SpecBlock add, which takes y raw (as its residual operand)
                 const bool last = j + 1 == blocks.size();
                 int rc = run_resblock(blocks[j], sm, true, last ? 0.f : blocks[j + 1].pre_scale, B, Tl, st,
-                                      "enc.resblock", m->prec);
+                                      "enc.resblock");
                 if (rc) return rc;
             }
         }
@@ -608,7 +602,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
             acc.Y = post ? sm.raw : nullptr;
             acc.Yact = post ? nullptr : sm.other_act(); acc.act_scale = down_scale;
             acc.B = B; acc.Tin = Tl; acc.Tout = Tl; acc.ks = 5; acc.stride = 1; acc.dil = 1; acc.pad = 4;
-            acc.pre_scale = 1.f; acc.pre_elu = 0; acc.out_scale = sp.scale; acc.bands = 1; acc.prec = wv::PREC_F32;
+            acc.pre_scale = 1.f; acc.pre_elu = 0; acc.out_scale = sp.scale; acc.bands = 1;
             acc.spec_add = 1;
             LAUNCH(wv::launch_pw_dw(acc, st));
             if (!post) { sm.act = acc.Yact; sm.raw = nullptr; }
@@ -629,7 +623,6 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         a.out_scale = 1.f;
         a.bands = c.freq_bands; a.film_stride = film_stride;
         a.film = film ? film + (size_t)s * c.freq_bands * 2 : nullptr;
-        a.prec = m->prec;
         if (film && (2 * C) % c.freq_bands) return fail(WV_EINVAL, "channels not divisible by freq_bands");
         LAUNCH(wv::launch_pw_dw(a, st));
         sm.raw = yr; sm.act = ya;
@@ -829,7 +822,7 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
     h.X = latent; h.pw = m->dec_pw0; h.dw_w = m->dec_dw0_w; h.dw_b = m->dec_dw0_b;
     h.Y = nullptr; h.Yact = sm.a[0]; h.act_scale = m->ups.empty() ? 1.f : m->ups[0].pre_scale;
     h.B = B; h.Tin = Fr; h.Tout = Fr; h.ks = c.kernel_size; h.stride = 1; h.dil = 1; h.pad = c.kernel_size - 1;
-    h.pre_scale = 1.f; h.pre_elu = 0; h.out_scale = 1.f; h.bands = 1; h.prec = m->prec;
+    h.pre_scale = 1.f; h.pre_elu = 0; h.out_scale = 1.f; h.bands = 1;
     LAUNCH(wv::launch_pw_dw(h, st));
     sm.raw = nullptr; sm.act = sm.a[0];
     int Tl = Fr;
@@ -849,14 +842,14 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
         a.Yact = has_blocks ? sm.other_act() : (last_up ? nullptr : sm.other_act());
         a.act_scale = has_blocks ? u.res[0].pre_scale : stage_next;
         a.B = B; a.Tin = Tl; a.Tout = Tl * u.ratio; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
-        a.pre_scale = 1.f; a.pre_elu = 0; a.out_scale = 1.f; a.bands = 1; a.prec = wv::PREC_F32;
+        a.pre_scale = 1.f; a.pre_elu = 0; a.out_scale = 1.f; a.bands = 1;
         LAUNCH(wv::launch_pw_dw(a, st));
         sm.raw = a.Y; sm.act = a.Yact;
         Tl = a.Tout;
         for (size_t j = 0; j < u.res.size(); ++j) {
             const bool last = j + 1 == u.res.size();
             const float next = last ? stage_next : u.res[j + 1].pre_scale;
-            rc = run_resblock(u.res[j], sm, !last || last_up, next, B, Tl, st, "dec.resblock", m->prec);
+            rc = run_resblock(u.res[j], sm, !last || last_up, next, B, Tl, st, "dec.resblock");
             if (rc) return rc;
         }
     }
@@ -898,11 +891,6 @@ int wv_locator_forward(wv_model* m, const float* x, float* logits, int B, int T,
     return run_head_model(m, x, logits, nullptr, B, T, ws, ws_bytes, stream);
 }
 
-int wv_model_set_precision(wv_model* m, int prec) {
-    if (!m || (prec != wv::PREC_F32 && prec != wv::PREC_F16X3)) return fail(WV_EINVAL, "precision must be 0 (f32) or 1 (f16x3)");
-    m->prec = prec;
-    return WV_OK;
-}
 int wv_profile_enable(int on) { wv::prof::enable(on != 0); return WV_OK; }
 int wv_profile_reset(void) { wv::prof::reset(); return WV_OK; }
 int wv_profile_collect(int index, char* name_out, int name_cap, int64_t* launches, double* total_ms,

@@ -34,11 +34,6 @@ struct Tmp {                       // scoped device uploads
         for (int m = 0; m < M; ++m)
             for (int k = 0; k < K; ++k) t[(size_t)k * p.Mp + m] = w[(size_t)m * K + k];
         p.wt = upv(t);
-        p.Kh = wv::round_up(K, wv::BKH);
-        const std::vector<uint16_t> hf = wv::pack_split_f16(w, M, K, p.Mp, p.Kh);
-        std::vector<float> as_f(hf.size() / 2);
-        std::memcpy(as_f.data(), hf.data(), hf.size() * 2);
-        p.wh = upv(as_f);
         std::vector<float> q((size_t)wv::round_up(K, 32) * p.Mp, 0.f);   // wq[roundup(K,32)/4][Mp][4]
         for (int mm = 0; mm < M; ++mm)
             for (int k = 0; k < K; ++k) q[((size_t)(k / 4) * p.Mp + mm) * 4 + (k & 3)] = w[(size_t)mm * K + k];
@@ -56,15 +51,7 @@ int done(Tmp& t, hipError_t e, hipStream_t s) {
 
 }  // namespace
 
-static int g_op_prec = wv::PREC_F32;
-
 extern "C" {
-
-int wv_op_set_precision(int prec) {
-    if (prec != wv::PREC_F32 && prec != wv::PREC_F16X3) return WV_EINVAL;
-    g_op_prec = prec;
-    return WV_OK;
-}
 
 int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const float* dw_bias,
                 const float* film, const float* resid, float* Y, int B, int K, int M, int Tin,
@@ -79,7 +66,6 @@ int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const floa
     a.dil = dilation; a.pad = (ks - 1) * dilation - (stride - 1);
     a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = out_scale;
     a.bands = bands > 0 ? bands : 1; a.film_stride = 2 * a.bands;
-    a.prec = g_op_prec;
     if (a.pad < 0) return WV_EINVAL;
     return done(t, wv::launch_pw_dw(a, (hipStream_t)stream), (hipStream_t)stream);
 }
@@ -114,7 +100,7 @@ int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const floa
         a.dw_w = t.upv(taps); a.dw_b = t.up(bias, M); a.Y = Y; a.Yact = Yact; a.act_scale = act_scale;
         a.B = B; a.Tin = Tin; a.Tout = Tin * ks_or_ratio; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
         a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1;
-        a.film_stride = 2; a.prec = wv::PREC_F32;
+        a.film_stride = 2;
         return done(t, wv::launch_pw_dw(a, (hipStream_t)stream), (hipStream_t)stream);
     }
     Tmp t;
@@ -133,7 +119,7 @@ int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const floa
         a.X = X; a.pw = t.pw(w_pw, M, K); a.dw_w = t.upv(taps); a.resid = Y; a.Y = Y; a.Yact = Yact; a.act_scale = act_scale;
         a.B = B; a.Tin = Tin; a.Tout = Tin; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
         a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = out_scale; a.bands = 1; a.film_stride = 2;
-        a.prec = wv::PREC_F32; a.spec_add = 1;
+        a.spec_add = 1;
         return done(t, wv::launch_pw_dw(a, (hipStream_t)stream), (hipStream_t)stream);
     }
     if (mode == 1) { a.ks = ks_or_ratio; a.dw_w = t.up(w_dw, (size_t)K * a.ks); }

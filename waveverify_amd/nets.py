@@ -55,10 +55,9 @@ def _fill_config(cfg: NetConfig) -> _lib.WvConfig:
 class HipNet:
     """One WaveVerify net resident on one GPU."""
 
-    PRECISIONS = {"f32": 0, "f16x3": 1}
 
     def __init__(self, cfg: NetConfig, state_dict: Mapping[str, object], device="cuda",
-                 strict: bool = False, precision: str = "f32"):
+                 strict: bool = False):
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -75,14 +74,6 @@ class HipNet:
         with torch.cuda.device(self.device):
             self._load(state_dict, strict)
             _lib.check(self._lib.wv_model_finalize(self._h), "wv_model_finalize")
-        self.set_precision(precision)
-
-    def set_precision(self, precision: str) -> None:
-        """'f32': exact f32 matrix instructions; 'f16x3': split-f16 MFMA (hi+lo, 3 products)."""
-        if precision not in self.PRECISIONS:
-            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
-        _lib.check(self._lib.wv_model_set_precision(self._h, self.PRECISIONS[precision]))
-        self.precision = precision
 
     # ------------------------------------------------------------------ weights
     def param_table(self) -> Dict[str, Tuple[Tuple[int, ...], bool]]:

@@ -39,10 +39,6 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def set_precision(precision: str) -> None:
-    _lib.check(_lib.load().wv_op_set_precision({"f32": 0, "f16x3": 1}[precision]))
-
-
 def pw_dw(X, w_pw, w_dw, dw_bias=None, film=None, resid=None, stride=1, dilation=1,
           pre_scale=1.0, pre_elu=True, out_scale=1.0, bands=1, act_scale: Optional[float] = None):
     """act_scale given: also returns the second output ELU(act_scale * y) -> (Y, Yact)."""

@@ -57,3 +57,57 @@ def embed_detect_sharded(embed: Callable[[torch.Tensor, torch.Tensor], torch.Ten
     wm = embed(x, m)
     mp = detect(wm)
     return wm, mp, (all_gather_rows(mp, audio.shape[0], group) if gather else None)
+
+
+# ---- training-step gradient all-reduce (BASELINE configs[2]; reference: DDP in scripts/train.py:875-876,1277,1347)
+# The forward passes need no collective; the only exchange step of the reference's data-parallel training
+# is the per-step all-reduce of the fp32 gradients: 56.1 MB (generator + detector + locator) and 170.1 MB
+# (discriminator), SURVEY.md section 2.2.  xGMI is point-to-point (one ~153 GB/s link per peer), so a ring
+# all-reduce is per-link bound: buckets of >= 25 MB keep the link busy and let bucket i's reduction overlap
+# the backward of the layers behind it.
+GRAD_PAYLOAD_BYTES = {"generator+detector+locator": 56_100_000, "discriminator": 170_100_000}
+DEFAULT_BUCKET_BYTES = 25 * 1024 * 1024
+
+
+def plan_buckets(numels, bucket_bytes: int = DEFAULT_BUCKET_BYTES, itemsize: int = 4):
+    """Greedy DDP-style bucketing of a parameter list (in reverse order: gradients become ready from the
+    last layer backwards).  -> list of lists of parameter indices; a bucket closes once it holds at least
+    `bucket_bytes`; a single tensor larger than that is a bucket of its own."""
+    if bucket_bytes < 1:
+        raise ValueError("bucket_bytes must be positive")
+    buckets, cur, cur_bytes = [], [], 0
+    for i in reversed(range(len(numels))):
+        cur.append(i)
+        cur_bytes += int(numels[i]) * itemsize
+        if cur_bytes >= bucket_bytes:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
+def allreduce_mean_(grads, buckets, group=None, async_op: bool = True):
+    """In-place mean all-reduce of `grads` (list of tensors), one flat collective per bucket.  Buckets are
+    launched back to back (async) and waited for at the end, so bucket i+1's transfer is queued while
+    bucket i is still on the links.  Returns the flat buffers' handles' count (for tests)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    world = dist.get_world_size(group)
+    flats, works = [], []
+    for b in buckets:
+        flat = torch.cat([grads[i].reshape(-1) for i in b]) if len(b) > 1 else grads[b[0]].reshape(-1).clone()
+        flats.append(flat)
+        works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+    for w in works:
+        if w is not None:
+            w.wait()
+    for b, flat in zip(buckets, flats):
+        flat.div_(world)
+        off = 0
+        for i in b:
+            n = grads[i].numel()
+            grads[i].copy_(flat[off:off + n].view_as(grads[i]))
+            off += n
+    return len(flats)
