@@ -262,6 +262,64 @@ struct K1Epi {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        } else if constexpr (EPI >= 2) {
+            // Downsample stencil (ks = 2R, stride R, pad R; R = EPI in {2, 4, 8}; seanet.py:733-772) + FiLM, from
+            // the accumulators: a lane holds H columns 4q..4q+3, the rest of an output's 2R taps sits in the
+            // next 1 (R = 2, 4) or 3 (R = 8) lanes and comes by DPP.  Outputs per lane: R = 2 -> 2q, 2q+1 (one
+            // 8-byte store), R = 4 -> q, R = 8 -> q/2 on the even lanes.  Taps are summed in ascending order like
+            // the generic path (bit-identical).  Addressing and masking as in EPI 0 (range-checked buffers).
+            static_assert(NT == 4 && !RES, "strided DPP epilogue: 128-column windows, no residual");
+            constexpr int R = EPI;
+            const int clip_bytes = M * p.Tout * 4;
+            const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(Yb ? Yb : p.Yact, 0, Yb ? clip_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(Ab ? Ab : p.Yact, 0, Ab ? clip_bytes : 0, 0x00020000);
+            const int row_bytes = p.Tout * 4;
+            const int o0 = R == 2 ? 2 * q : (R == 4 ? q : q >> 1);       // first output of this lane inside the tile
+            const bool lane_ok = (R != 8 || (q & 1) == 0) && o0 + (R == 2 ? 1 : 0) < p.tto && to0 + o0 + (R == 2 ? 1 : 0) < p.Tout;
+            const int voff = lane_ok ? ((m0 + 32 * wave + 4 * half) * p.Tout + to0 + o0) * 4 : 0x7f000000;
+            const float* Wrow = Wl + (32 * wave + 4 * half) * WLD;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2);
+                constexpr int NL = R == 8 ? 4 : 2;                   // lanes an output's taps span
+                float hh[4 * NL], cur[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cur[e] = acc[e][r]; hh[e] = cur[e]; }
+#pragma unroll
+                for (int l = 1; l < NL; ++l) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { cur[e] = dpp_next(cur[e]); hh[4 * l + e] = cur[e]; }
+                }
+                const float* wt = Wrow + cr * WLD;
+                float w[2 * R];
+#pragma unroll
+                for (int i = 0; i < 2 * R; i += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(wt + i);
+                    w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
+                }
+                const f32x4 bgb = *reinterpret_cast<const f32x4*>(wt + 16);   // bias, gamma, beta
+                const int off = voff + cr * row_bytes;
+                constexpr int NO = R == 2 ? 2 : 1;
+                float y[NO];
+#pragma unroll
+                for (int j = 0; j < NO; ++j) {
+                    const int base = R == 2 ? 2 + 2 * j : 0;            // first H column of output j relative to 4q (off = 2 for R = 2)
+                    float v = bgb.x;
+#pragma unroll
+                    for (int i = 0; i < 2 * R; ++i) v = fmaf(w[i], hh[base + i], v);
+                    y[j] = fmaf(v, bgb.y, bgb.z);
+                }
+                if constexpr (R == 2) {
+                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                    if (Yb) __builtin_amdgcn_raw_buffer_store_b64(u2{__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1])}, rY, off, 0, 0);
+                    if (Ab) __builtin_amdgcn_raw_buffer_store_b64(u2{__builtin_bit_cast(unsigned, elu1(y[0] * p.act_scale)),
+                                                                        __builtin_bit_cast(unsigned, elu1(y[1] * p.act_scale))}, rA, off, 0, 0);
+                } else {
+                    if (Yb) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[0]), rY, off, 0, 0);
+                    if (Ab) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, elu1(y[0] * p.act_scale)), rA, off, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
             float* Hw = strips + wave * (4 * HLD);
             const int ks = p.ks;
@@ -309,7 +367,7 @@ template <> struct LdrSel<5> { typedef ConvTrPair<0> type; };
 // cycles at the 2.05 GHz the chip holds under this load, profiles/r02_k1_sq_counters.txt -- and the second
 // set of per-tile state cost the fourth resident wave per SIMD, which short-K layers need to hide the DMA
 // latency.)
-template <class C, int EPI, int LDR, bool RES>
+template <class C, int EPI, int LDR, bool RES, int NS>
 __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4) void k1_kernel(PwDwArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool REG = LDR != 0;
@@ -319,7 +377,8 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
     const TileId tile = decode_tile(p);
     if (!tile.valid) return;
     f32x4* S4 = reinterpret_cast<f32x4*>(smem);
-    float* table = smem + 2 * C::STAGE4 * 4;
+    float* table = smem + NS * C::STAGE4 * 4;
+    static_assert(NS == 2 || (NS == 3 && LDR == 0), "three stages: DMA path only");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, i31 = lane & 31;
@@ -370,20 +429,36 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
             }
         }
     };
-    issue(0, 0);
-    if constexpr (REG) { lb.init(cg); fetch(0); commit(0, 0); }
+    // Pipeline depth NS.  2 stages: chunk c+1 is fetched while chunk c computes, one __syncthreads() per chunk
+    // (which drains the DMA).  3 stages (DMA path): chunk c+2 is in flight while chunk c computes and survives
+    // the barrier -- raw s_barrier behind a COUNTED vmcnt.  Measured (kbench, B = 256): +5..8 % on the
+    // matrix-bound K >= 256 layers with 128-column windows (a chunk is ~1 us of matrix work, about one HBM round
+    // trip), -3..19 % where the layer is bandwidth-bound or the third stage costs a resident workgroup (K = 128,
+    // 64-column windows with BK = 32, 64/96-row tiles) -- the launcher picks per layer.
+    constexpr int PIECES_MIN = C::A_PIECES / C::WM + C::B_PIECES / C::WM;   // DMA instructions a wave issues per chunk, at least
     f32x16 acc[C::NT];
 #pragma unroll
     for (int e = 0; e < C::NT; ++e)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-    __syncthreads();                                           // first chunk landed, table visible
+    issue(0, 0);
+    if constexpr (NS == 2) {
+        if constexpr (REG) { lb.init(cg); fetch(0); commit(0, 0); }
+        __syncthreads();                                       // first chunk landed, table visible
+    } else {
+        if (nchunks > 1) { issue(1, 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES_MIN) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the row table (ds_write in begin())
+        __builtin_amdgcn_s_barrier();                            // first chunk landed everywhere, table visible
+    }
+    int st = 0;
     for (int c = 0; c < nchunks; ++c) {
-        const int st = c & 1;
         const f32x4* S = S4 + st * C::STAGE4;
-        if (c + 1 < nchunks) {
-            issue(c + 1, st ^ 1);
-            fetch(c + 1);
+        const int stn = st + 1 == NS ? 0 : st + 1;
+        if constexpr (NS == 2) {
+            if (c + 1 < nchunks) { issue(c + 1, stn); fetch(c + 1); }
+        } else {
+            if (c + 2 < nchunks) issue(c + 2, stn + 1 == NS ? 0 : stn + 1);
         }
         const float* Bf = reinterpret_cast<const float*>(S + C::A4) + C::NT * i31;
 #pragma unroll
@@ -400,8 +475,16 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
             WV_K1_STEP(a1.z, 16 * g + 8 + 4 * h + 2) WV_K1_STEP(a1.w, 16 * g + 8 + 4 * h + 3)
 #undef WV_K1_STEP
         }
-        if (c + 1 < nchunks) commit(c + 1, st ^ 1);
-        __syncthreads();
+        if constexpr (NS == 2) {
+            if (c + 1 < nchunks) commit(c + 1, stn);
+            __syncthreads();
+        } else {
+            // chunk c+1 must have landed (all waves' pieces) before anyone reads it; chunk c+2 may stay in flight
+            if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES_MIN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        st = stn;
     }
     epi.finish(acc, p, smem);              // strips (EPI 1) alias the stages: the main loop ended with a barrier
 }
@@ -423,9 +506,9 @@ bool k1_supported(const PwDwArgs& a) {
     return true;
 }
 
-template <class C, int EPI, int LDR, bool RES>
+template <class C, int EPI, int LDR, bool RES, int NS = 2>
 static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
-    const size_t smem = 2 * (size_t)C::STAGE4 * 16 + (size_t)K1Epi<C, EPI, RES>::TABLE_FLOATS * sizeof(float);
+    const size_t smem = NS * (size_t)C::STAGE4 * 16 + (size_t)K1Epi<C, EPI, RES>::TABLE_FLOATS * sizeof(float);
     static_assert(C::WM * 4 * C::HLD <= 2 * C::STAGE4 * 4, "strips alias the stages");
     a.num_m = (a.pw.M + C::BM - 1) / C::BM;
     a.num_t = (a.Tout + a.tto - 1) / a.tto;
@@ -435,12 +518,12 @@ static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     std::string name;
     if (prof::enabled())
-        name = std::string(base) + "<" + std::to_string(C::BM) + "," + std::to_string(C::BN) + (LDR == 0 ? ",dma>" : ",reg>");
+        name = std::string(base) + "<" + std::to_string(C::BM) + "," + std::to_string(C::BN) + (LDR == 0 ? (NS == 3 ? ",dma3>" : ",dma>") : ",reg>");
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
     const double outs = (a.Y ? 1.0 : 0.0) + (a.Yact ? 1.0 : 0.0) + (a.resid ? 1.0 : 0.0);
     const double flops = a.ct_w ? 2.0 * Bd * a.Tout * K * (M + 2.0) : 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout);
     prof::Scope ps(s, name.c_str(), flops, 4.0 * Bd * (K * a.Tin + M * a.Tout * outs));
-    hipLaunchKernelGGL((k1_kernel<C, EPI, LDR, RES>), dim3((unsigned)nblk), dim3(C::NTHREADS), smem, s, a);
+    hipLaunchKernelGGL((k1_kernel<C, EPI, LDR, RES, NS>), dim3((unsigned)nblk), dim3(C::NTHREADS), smem, s, a);
     return hipGetLastError();
 }
 
@@ -456,8 +539,11 @@ static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
         }
         return hipErrorInvalidValue;
     }
-    const char* base = a.spec_add ? "spec_add" : (EPI == 0 ? (RES ? "pw_dw_k5" : "pw_dw_k5_nr") : "pw_dw");
+    const char* base = a.spec_add ? "spec_add" : (EPI == 0 ? (RES ? "pw_dw_k5" : "pw_dw_k5_nr") : (EPI == 1 ? "pw_dw" : "pw_dw_s"));
     if (a.pre_elu || a.pre_scale != 1.f) return k1_run<C, EPI, 1, RES>(a, s, base);
+    if constexpr (C::NT == 4 && C::BM == 128) {
+        if (a.pw.K >= 256) return k1_run<C, EPI, 0, RES, 3>(a, s, base);       // matrix-bound: deeper DMA pipeline
+    }
     return k1_run<C, EPI, 0, RES>(a, s, base);
 }
 
@@ -465,6 +551,14 @@ template <class C>
 static hipError_t k1_pick_epi(const PwDwArgs& a, hipStream_t s, bool k5) {
     const bool res = a.resid != nullptr;
     if (k5) return res ? k1_pick_ldr<C, 0, true>(a, s) : k1_pick_ldr<C, 0, false>(a, s);
+    if constexpr (C::NT == 4) {                              // the net's downsample stencils: ks = 2r, stride r, pad r
+        if (!res && !a.ct_w && a.dil == 1 && a.ks == 2 * a.stride && a.pad == a.stride &&
+            a.off == (a.stride == 2 ? 2 : 0)) {
+            if (a.stride == 2) return k1_pick_ldr<C, 2, false>(a, s);
+            if (a.stride == 4) return k1_pick_ldr<C, 4, false>(a, s);
+            if (a.stride == 8) return k1_pick_ldr<C, 8, false>(a, s);
+        }
+    }
     return res ? k1_pick_ldr<C, 1, true>(a, s) : k1_pick_ldr<C, 1, false>(a, s);
 }
 

@@ -99,6 +99,8 @@ struct DwPwArgs {
     int l2norm;           // normalise over channels * sqrt(M) (needs M <= 128)
     int accumulate;       // Y += out_scale * result
     float out_scale;
+    float* Yact;          // optional second output ELU(act_scale * y) (see PwDwArgs::Yact); full aligned tiles and the
+    float act_scale;      //   ragged path both write it
 };
 hipError_t launch_dw_pw(const DwPwArgs& a, hipStream_t s);
 

@@ -589,7 +589,8 @@ __device__ __forceinline__ void dw_pw_body(const DwPwArgs& p, LB& lb, float* sme
     }
     // Full, 16-byte aligned tiles: float4 rows, LPR lanes per row, U passes batched so the
     // read-modify-write of an accumulate layer has U independent loads in flight per lane.
-    if (ncol == T::BN && (p.Tout & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0) {
+    if (ncol == T::BN && (p.Tout & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(p.Yact) & 15) == 0) {
         constexpr int LPR = T::BN / 4, RPP = 64 / LPR, RPW = T::BM / 4, NP = RPW / RPP;
         constexpr int U = NP % 8 == 0 ? 8 : (NP % 4 == 0 ? 4 : (NP % 2 == 0 ? 2 : 1));
         static_assert(RPW % RPP == 0, "rows per wave");
@@ -620,6 +621,9 @@ __device__ __forceinline__ void dw_pw_body(const DwPwArgs& p, LB& lb, float* sme
                 }
                 if (p.l2norm) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
                 *reinterpret_cast<f32x4*>(Yb + (size_t)gm * p.Tout + t0 + c4) = v;
+                if (p.Yact)
+                    *reinterpret_cast<f32x4*>(p.Yact + ((size_t)b * M + gm) * p.Tout + t0 + c4) =
+                        f32x4{elu1(v.x * p.act_scale), elu1(v.y * p.act_scale), elu1(v.z * p.act_scale), elu1(v.w * p.act_scale)};
             }
         }
         return;
@@ -636,6 +640,7 @@ __device__ __forceinline__ void dw_pw_body(const DwPwArgs& p, LB& lb, float* sme
             else v += bias;
             if (p.l2norm) v *= inv[c];
             yrow[c] = v;
+            if (p.Yact) p.Yact[((size_t)b * M + gm) * p.Tout + t0 + c] = elu1(v * p.act_scale);
         }
     }
 }

@@ -594,8 +594,9 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
             wv::DwPwArgs k2{};
             k2.X = P; k2.pw = sp.pw; k2.Y = sm.raw; k2.B = B; k2.Tin = Tl; k2.Tout = Tl; k2.mode = 0;
             k2.pre_scale = 1.f; k2.pre_elu = 0; k2.accumulate = 1; k2.out_scale = sp.scale;
+            k2.Yact = post ? nullptr : sm.other_act(); k2.act_scale = down_scale;    // the downsample's ELU(s * x')
             LAUNCH(wv::launch_dw_pw(k2, st));
-            sm.act = nullptr;
+            sm.act = k2.Yact;
         } else {
             wv::PwDwArgs acc{};
             acc.X = P; acc.pw = sp.pw; acc.dw_w = sp.id_taps; acc.dw_b = nullptr; acc.resid = sm.raw;
