@@ -479,6 +479,18 @@ WsLayout layout(const wv_model* m, int B, int T) {
 // The residual stream of a net: `raw` = x, `act` = ELU(s * x) for the NEXT consumer's scale s (written
 // by the producer's epilogue, PwDwArgs::Yact, so that the consumer stages it by LDS-DMA), either may be
 // null.  r[2] / a[2] are the ping-pong buffers behind them, u the ResnetBlock intermediate.
+// Does a ResnetBlock of C channels want its input pre-activated by the producer (second output, one more HBM
+// write pass) or does its first unit apply scale -> ELU itself while staging through registers?  Narrow layers
+// (one m-tile: no redundant activation work, and they are bandwidth-bound) activate themselves.
+static int g_act_copy_min_c = -1;
+inline bool wants_act_copy(int C) {
+    if (g_act_copy_min_c < 0) {
+        const char* e = getenv("WV_ACT_COPY_MIN_C");
+        g_act_copy_min_c = e ? atoi(e) : 129;
+    }
+    return C >= g_act_copy_min_c;
+}
+
 struct Stream {
     float* r[2]; float* a[2]; float* u;
     float* raw = nullptr; float* act = nullptr;
@@ -560,7 +572,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
     }
     wv::prof::set_role("enc.conv_pre");
     sm.raw = sm.r[0];
-    sm.act = m->enc_blocks[0].empty() ? nullptr : sm.a[0];     // also ELU(c1 * y) for the first ResnetBlock
+    sm.act = (m->enc_blocks[0].empty() || !wants_act_copy(c.channels_enc)) ? nullptr : sm.a[0];   // also ELU(c1 * y) for the first ResnetBlock
     LAUNCH(wv::launch_conv_pre(x, m->pre_w, m->pre_b, sm.raw, sm.act, sm.act ? m->enc_blocks[0][0].pre_scale : 0.f,
                                B, c.channels_enc, T, c.kernel_size, 1.f / c.wav_std, st));
     int Tl = T, C = c.channels_enc;
@@ -572,7 +584,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
             for (size_t j = 0; j < blocks.size(); ++j) {
                 // the last block feeds the SpecBlock add, which takes y raw (as its residual operand)
                 const bool last = j + 1 == blocks.size();
-                int rc = run_resblock(blocks[j], sm, true, last ? 0.f : blocks[j + 1].pre_scale, B, Tl, st,
+                int rc = run_resblock(blocks[j], sm, true, (last || !wants_act_copy(C)) ? 0.f : blocks[j + 1].pre_scale, B, Tl, st,
                                       "enc.resblock");
                 if (rc) return rc;
             }
@@ -614,7 +626,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         wv::PwDwArgs a{};
         if (sm.act) { a.X = sm.act; a.pre_scale = 1.f; a.pre_elu = 0; }
         else { a.X = sm.raw; a.pre_scale = d.pre_scale; a.pre_elu = 1; }
-        const bool next_has_blocks = s + 1 < c.n_strides && !m->enc_blocks[s + 1].empty();
+        const bool next_has_blocks = s + 1 < c.n_strides && !m->enc_blocks[s + 1].empty() && wants_act_copy(2 * C);
         float* yr = sm.raw ? sm.other_raw() : sm.r[0];
         float* ya = next_has_blocks ? (sm.act ? sm.other_act() : sm.a[0]) : nullptr;
         a.pw = d.pw; a.dw_w = d.dw_w; a.dw_b = d.dw_b; a.Y = yr; a.Yact = ya;
@@ -840,7 +852,8 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
         a.X = sm.act; a.ct_w = u.ct_w; a.ct_wt = u.ct_wt; a.ratio = u.ratio; a.pw = u.pw; a.dw_w = u.id_taps; a.dw_b = u.pw_b;
         const bool has_blocks = !u.res.empty();
         a.Y = (has_blocks || last_up) ? sm.r[0] : nullptr;
-        a.Yact = has_blocks ? sm.other_act() : (last_up ? nullptr : sm.other_act());
+        const bool blocks_act = has_blocks && wants_act_copy(u.pw.M);
+        a.Yact = has_blocks ? (blocks_act ? sm.other_act() : nullptr) : (last_up ? nullptr : sm.other_act());
         a.act_scale = has_blocks ? u.res[0].pre_scale : stage_next;
         a.B = B; a.Tin = Tl; a.Tout = Tl * u.ratio; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
         a.pre_scale = 1.f; a.pre_elu = 0; a.out_scale = 1.f; a.bands = 1;
@@ -849,7 +862,7 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
         Tl = a.Tout;
         for (size_t j = 0; j < u.res.size(); ++j) {
             const bool last = j + 1 == u.res.size();
-            const float next = last ? stage_next : u.res[j + 1].pre_scale;
+            const float next = last ? stage_next : (wants_act_copy(u.pw.M) ? u.res[j + 1].pre_scale : 0.f);
             rc = run_resblock(u.res[j], sm, !last || last_up, next, B, Tl, st, "dec.resblock");
             if (rc) return rc;
         }
