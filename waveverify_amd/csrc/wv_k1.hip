@@ -497,7 +497,9 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 bool k1_supported(const PwDwArgs& a) {
     if (!a.pw.wq || a.pw.Mp % 128) return false;
     if (a.pw.M < 33) return false;                           // tiny layers: the round-1 core's 32-row tile
-    if ((a.Tin & 3) || !aligned16(a.X) || a.pw.K < 1) return false;
+    // DMA'd activation rows need 16-byte aligned rows; the ConvTranspose producer gathers scalars, only its
+    // output rows (Tout = Tin * ratio) must be aligned
+    if (((a.ct_w ? a.Tout : a.Tin) & 3) || !aligned16(a.X) || a.pw.K < 1) return false;
     if (a.Y && !aligned16(a.Y)) return false;
     if (a.Yact && !aligned16(a.Yact)) return false;
     if (a.resid && !aligned16(a.resid)) return false;
@@ -567,7 +569,7 @@ hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
     const bool k5 = a.ks == 5 && a.stride == 1 && a.dil == 1 && a.pad == 4 && !a.film;   // FiLM: generic epilogue
     // window width: 64 columns when that computes fewer columns (tile quantisation) or the layer is short
     const int need = (a.ks - 1) * a.dil + 1;
-    bool narrow = a.Tin + a.pad + 3 <= 64;
+    bool narrow = (a.ct_w ? a.Tout : a.Tin) + a.pad + 3 <= 64;        // the H window runs over output times for the upsample unit
     if (!narrow) {
         PwDwArgs g128 = a, g64 = a;
         if (pw_dw_geometry(g128, 128) && pw_dw_geometry(g64, 64)) {

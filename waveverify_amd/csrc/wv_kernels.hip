@@ -1159,15 +1159,15 @@ static int pick_bm(int M) {
 }
 
 hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
-    if (k1_supported(a)) {                                   // the LDS-DMA core (wv_k1.hip)
-        const hipError_t e = launch_k1(a, s);
-        if (e != hipErrorNotSupported) return e;
-    }
     if (a.ct_w && (!a.ct_wt || (reinterpret_cast<uintptr_t>(a.ct_wt) & 7) || a.ratio < 1 || a.Tout != a.Tin * a.ratio || a.ks != 5 || a.stride != 1 || a.dil != 1 || a.pad != 4 ||
                    (reinterpret_cast<uintptr_t>(a.ct_w) & 15)))
         return hipErrorInvalidValue;
     if (a.ks < 1 || a.ks > 16 || a.stride < 1 || a.dil < 1 || a.pad < 0 || a.pw.Mp % M_ALIGN || a.pw.Kp % BK || !a.pw.wq)
         return hipErrorInvalidValue;
+    if (k1_supported(a)) {                                   // the LDS-DMA core (wv_k1.hip)
+        const hipError_t e = launch_k1(a, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     const int need = (a.ks - 1) * a.dil + 1;            // H columns one output needs
     bool narrow = a.Tin + a.pad + 3 <= 64 && need + 3 <= 64;
     if (!narrow && need + 3 <= 64) {

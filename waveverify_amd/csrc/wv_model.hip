@@ -602,7 +602,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         // downsample only ELU(s * x') is consumed, so only that is written; spec_post keeps x' raw
         // (in place: every element is read and then written by the same lane).
         const float down_scale = post ? 0.f : m->downs[s].pre_scale;
-        if (sp.pw.M < 128) {                  // small layers: the plain 1x1 kernel streams better
+        if (sp.pw.M < 33 || (Tl & 3)) {       // tiny or ragged layers: the plain 1x1 kernel
             wv::DwPwArgs k2{};
             k2.X = P; k2.pw = sp.pw; k2.Y = sm.raw; k2.B = B; k2.Tin = Tl; k2.Tout = Tl; k2.mode = 0;
             k2.pre_scale = 1.f; k2.pre_elu = 0; k2.accumulate = 1; k2.out_scale = sp.scale;
