@@ -1,0 +1,62 @@
+"""CPU restatement (numpy float64) of the forward AND backward pass of one SEANetResnetBlock half with live
+weight normalisation -- TEST INFRASTRUCTURE for the first training-step slice, pinned to
+the reference's own autograd by tests/golden/grads_half_*.npz (tests/golden/make_golden_grads.py).
+
+    a = ELU(s * x);  W = g_pw * v_pw / ||v_pw||;  h = W @ a          (1x1 conv, no bias)
+    w = g_dw * v_dw / ||v_dw||;  y[m,t] = b[m] + sum_i w[m,i] * h[m, t - 4 + i]   (causal depth-wise k = 5)
+
+Reference: modules/seanet.py:39-116 (dws_conv_block), modules/conv.py:47-88 (weight norm = torch
+parametrizations.weight_norm: norm over all dims but 0), conv.py:715-763 (SConv1d causal padding).
+Only tests/ import this module; the product path never does."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def fold(g: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """w = g * v / ||v||, norm over all dims but 0 (conv.py:73-74)."""
+    n = np.sqrt((v.reshape(v.shape[0], -1) ** 2).sum(1)).reshape((-1,) + (1,) * (v.ndim - 1))
+    return g * v / n
+
+
+def fold_backward(g, v, dw):
+    """(dg, dv) of w = g * v / ||v|| given dw."""
+    ax = tuple(range(1, v.ndim))
+    n = np.sqrt((v ** 2).sum(ax, keepdims=True))
+    dot = (dw * v).sum(ax, keepdims=True)
+    dg = dot / n
+    dv = g / n * (dw - dot / (n * n) * v)
+    return dg, dv
+
+
+def half_forward(x, s, g_pw, v_pw, g_dw, v_dw, b):
+    x = x.astype(np.float64)
+    z = s * x
+    a = np.where(z > 0, z, np.expm1(z))
+    W = fold(g_pw.astype(np.float64), v_pw.astype(np.float64))[:, :, 0]          # [M, K]
+    w = fold(g_dw.astype(np.float64), v_dw.astype(np.float64))[:, 0, :]          # [M, ks]
+    h = np.einsum("mk,bkt->bmt", W, a)
+    ks = w.shape[1]
+    hp = np.pad(h, ((0, 0), (0, 0), (ks - 1, 0)))
+    T = x.shape[2]
+    y = b.astype(np.float64)[None, :, None] + sum(w[None, :, i, None] * hp[:, :, i:i + T] for i in range(ks))
+    return y, (z, a, W, w, h)
+
+
+def half_backward(x, s, g_pw, v_pw, g_dw, v_dw, b, dy):
+    """-> dict(dx, dg_pw, dv_pw, dg_dw, dv_dw, db_dw) in float64."""
+    y, (z, a, W, w, h) = half_forward(x, s, g_pw, v_pw, g_dw, v_dw, b)
+    dy = dy.astype(np.float64)
+    T = x.shape[2]
+    ks = w.shape[1]
+    db = dy.sum((0, 2))
+    hp = np.pad(h, ((0, 0), (0, 0), (ks - 1, 0)))
+    dw = np.stack([(dy * hp[:, :, i:i + T]).sum((0, 2)) for i in range(ks)], 1)            # [M, ks]
+    dyp = np.pad(dy, ((0, 0), (0, 0), (0, ks - 1)))
+    dh = sum(w[None, :, i, None] * dyp[:, :, ks - 1 - i:ks - 1 - i + T] for i in range(ks))  # dh[t] = sum_i w[i] dy[t + 4 - i]
+    dW = np.einsum("bmt,bkt->mk", dh, a)
+    da = np.einsum("mk,bmt->bkt", W, dh)
+    dx = da * np.where(z > 0, 1.0, np.exp(z)) * s
+    dg_pw, dv_pw = fold_backward(g_pw.astype(np.float64), v_pw.astype(np.float64), dW[:, :, None])
+    dg_dw, dv_dw = fold_backward(g_dw.astype(np.float64), v_dw.astype(np.float64), dw[:, None, :])
+    return dict(y=y, dx=dx, dg_pw=dg_pw, dv_pw=dv_pw, dg_dw=dg_dw, dv_dw=dv_dw, db_dw=db)

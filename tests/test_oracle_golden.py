@@ -202,3 +202,16 @@ def test_torch_flavoured_oracle_matches_reference(golden_dir):
     _close(mp, g["det_mean_prob"], 1e-5)
     assert ((mp >= 0.5).astype(int) == g["det_bits"]).all()
     _close(OT.detector_logits(L, g["wm"]).numpy()[..., ::7], g["loc_logits_sub"], 1e-4, "loc (torch oracle)")
+
+
+@pytest.mark.parametrize("tag", ["small", "c64", "c96", "c160"])
+def test_training_half_oracle_vs_reference_autograd(golden_dir, tag):
+    """First training-step slice: forward + backward of a ResnetBlock half with live weight norm.
+    oracle/wv_oracle_train.py against the reference modules' autograd (tests/golden/make_golden_grads.py)."""
+    from oracle import wv_oracle_train as OT
+    g = np.load(os.path.join(golden_dir, f"grads_half_{tag}.npz"))
+    out = OT.half_backward(g["x"], float(g["pre_scale"]), g["g_pw"], g["v_pw"], g["g_dw"], g["v_dw"], g["b_dw"], g["dy"])
+    for k in ("y", "dx", "dg_pw", "dv_pw", "dg_dw", "dv_dw", "db_dw"):
+        ref = g[k]
+        err = np.abs(out[k].reshape(ref.shape) - ref).max() / max(1.0, np.abs(ref).max())
+        assert err <= 2e-6, (k, err)

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Reduce two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) to HBM bytes per launch per kernel.
+"""Reduce rocprofv3 counter passes over the headline bench command (tools/profile_bench.sh) to per-kernel figures.
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/rNN_pmc_traffic.json
+    python tools/pmc_traffic.py traffic <pmc_fetch dir> <pmc_write dir>  > profiles/rNN_pmc_traffic.json
+    python tools/pmc_traffic.py busy    <pmc_sq dir>                     > profiles/rNN_mfma_busy.json
 
-Counters are KiB; on gfx950 FETCH_SIZE counts 64 B requests as 32 B, hence traffic = 2*FETCH + WRITE
-(MI355X_MICROARCH.md, HBM section)."""
+traffic: HBM bytes per launch.  Counters are KiB; on gfx950 FETCH_SIZE counts 64 B requests as 32 B, hence
+         traffic = 2*FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section).
+busy:    MFMA utilisation per kernel symbol = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles * 1024 SIMDs), with the
+         kernel's cycles taken from GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs), plus the effective clock."""
 import csv
 import glob
 import json
@@ -17,6 +18,17 @@ from collections import defaultdict
 
 def short(name: str) -> str:
     """Kernel symbol -> the name the library's profiler (and bench.py) uses."""
+    m = re.match(r"void wv::k1_kernel<wv::K1<(\d+), (\d+), (\d+)>, (-?\d+), (\d+), (true|false|[01]), (\d+)>", name)
+    if m:
+        nt, bkc, bm, epi, ldr, res, ns = m.groups()
+        epi, ldr = int(epi), int(ldr)
+        res = res in ("true", "1")
+        base = "convtr_pw" if ldr >= 2 else ("pw_dw_k5" if epi == 0 and res else "pw_dw_k5_nr" if epi == 0 else "pw_dw" if epi == 1 else "pw_dw_s")
+        tag = "reg" if ldr else ("dma3" if ns == "3" else "dma")
+        return f"{base}<{bm},{32 * int(nt)},{tag}>"          # spec_add launches share the pw_dw_k5 symbol
+    m = re.match(r"void wv::resblock_kernel<wv::RB<(\d+), (\d+)>", name)
+    if m:
+        return f"resblock<{m.group(1)},{32 * int(m.group(2))}>"
     m = re.match(r"void wv::(\w+)_kernel<wv::Tile<(\d+), (\d+), (\d+), (\d+)>((?:, [-\w]+)*)\s*>", name)
     if not m:
         m2 = re.match(r"(?:void )?wv::(\w+)_kernel", name)
@@ -35,40 +47,89 @@ def short(name: str) -> str:
             base = "convtr_pw"
         elif ks == "5":
             base = "pw_dw_k5" if res in ("true", "1") else "pw_dw_k5_nr"
-    elif base == "pw_dw_h":
-        base = "pw_dw_k5_h" if ex and ex[0] == "5" else "pw_dw_h"
     return f"{base}<{bm},{bn},{wm},{wn}>"
 
 
-def reduce_pass(d: str, counter: str):
-    tot, n = defaultdict(float), defaultdict(int)
-    for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
+def rows(d: str, suffix: str):
+    for f in glob.glob(f"{d}/**/*_{suffix}.csv", recursive=True):
         with open(f) as fh:
-            for r in csv.DictReader(fh):
-                if r["Counter_Name"] != counter or "wv::" not in r["Kernel_Name"]:
-                    continue
-                k = short(r["Kernel_Name"])
-                tot[k] += float(r["Counter_Value"]) * 1024.0
-                n[k] += 1
+            yield from csv.DictReader(fh)
+
+
+def reduce_pass(d: str, counters):
+    tot = {c: defaultdict(float) for c in counters}
+    n = {c: defaultdict(int) for c in counters}
+    for r in rows(d, "counter_collection"):
+        c = r["Counter_Name"]
+        if c not in tot or "wv::" not in r["Kernel_Name"]:
+            continue
+        k = short(r["Kernel_Name"])
+        tot[c][k] += float(r["Counter_Value"])
+        n[c][k] += 1
     return tot, n
 
 
-def main():
-    fetch, nf = reduce_pass(sys.argv[1], "FETCH_SIZE")
-    write, nw = reduce_pass(sys.argv[2], "WRITE_SIZE")
-    out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 2 "
-                   "--warmup 1 --no-cpu-baseline` (f32); counters are KiB; gfx950 correction per "
+def durations(d: str):
+    t, n = defaultdict(float), defaultdict(int)
+    for r in rows(d, "kernel_trace"):
+        if "wv::" not in r["Kernel_Name"]:
+            continue
+        k = short(r["Kernel_Name"])
+        t[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        n[k] += 1
+    return t, n
+
+
+def traffic(fetch_dir, write_dir):
+    f, nf = reduce_pass(fetch_dir, ["FETCH_SIZE"])
+    w, nw = reduce_pass(write_dir, ["WRITE_SIZE"])
+    f, nf, w, nw = f["FETCH_SIZE"], nf["FETCH_SIZE"], w["WRITE_SIZE"], nw["WRITE_SIZE"]
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 5 --warmup 2 "
+                   "--no-cpu-baseline` (tools/profile_bench.sh); counters are KiB; gfx950 correction per "
                    "MI355X_MICROARCH.md section HBM: traffic = 2*FETCH_SIZE + WRITE_SIZE",
            "kernels": {}}
-    for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0.0))):
+    for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0.0))):
         if not nw.get(k):
             continue
-        f, w = fetch[k] / nf[k], write[k] / nw[k]
-        out["kernels"][k] = {"launches": nf[k], "fetch_size_bytes_per_launch": f,
-                             "write_size_bytes_per_launch": w, "traffic_bytes_per_launch": 2 * f + w}
-    json.dump(out, sys.stdout, indent=1)
-    print()
+        fb, wb = f[k] * 1024.0 / nf[k], w[k] * 1024.0 / nw[k]
+        out["kernels"][k] = {"launches": nf[k], "fetch_size_bytes_per_launch": fb,
+                             "write_size_bytes_per_launch": wb, "traffic_bytes_per_launch": 2 * fb + wb}
+    return out
+
+
+def busy(sq_dir):
+    names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+             "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE"]
+    tot, n = reduce_pass(sq_dir, names)
+    dur, nd = durations(sq_dir)
+    out = {"note": "rocprofv3 --pmc pass over the bench command (tools/profile_bench.sh).  mfma_busy = "
+                   "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs): the share of all SIMD cycles in "
+                   "which the matrix pipe is busy; clock_ghz = GRBM_GUI_ACTIVE / 8 / kernel time (profiled passes "
+                   "clock ~3 % lower than un-profiled ones); wait_any / wait_inst = SQ_WAIT_ANY / SQ_WAIT_INST_ANY "
+                   "over SQ_WAVE_CYCLES (waves parked at s_waitcnt or a barrier / stalled at issue, e.g. behind the "
+                   "matrix pipe); valu_per_mfma = other VALU instructions per MFMA",
+           "kernels": {}}
+    tt = sum(dur.values())
+    for k in sorted(dur, key=lambda k: -dur[k]):
+        L = n["GRBM_GUI_ACTIVE"].get(k, 0)
+        if not L:
+            continue
+        cyc = tot["GRBM_GUI_ACTIVE"][k] / 8.0
+        mf = tot["SQ_INSTS_MFMA"][k]
+        out["kernels"][k] = {
+            "launches": L, "share_of_kernel_time": round(dur[k] / tt, 4),
+            "avg_us": round(dur[k] / nd[k] / 1e3, 1),
+            "mfma_busy": round(tot["SQ_VALU_MFMA_BUSY_CYCLES"][k] / (cyc * 1024.0), 4) if cyc else None,
+            "clock_ghz": round(cyc / dur[k], 3) if dur[k] else None,
+            "wait_any": round(tot["SQ_WAIT_ANY"][k] / tot["SQ_WAVE_CYCLES"][k], 3) if tot["SQ_WAVE_CYCLES"][k] else None,
+            "wait_inst": round(tot["SQ_WAIT_INST_ANY"][k] / tot["SQ_WAVE_CYCLES"][k], 3) if tot["SQ_WAVE_CYCLES"][k] else None,
+            "valu_per_mfma": round((tot["SQ_INSTS_VALU"][k] - mf) / mf, 2) if mf else None}
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1] == "traffic":
+        json.dump(traffic(sys.argv[2], sys.argv[3]), sys.stdout, indent=1)
+    else:
+        json.dump(busy(sys.argv[2]), sys.stdout, indent=1)
+    print()
