@@ -200,6 +200,28 @@ int wv_op_head(const float* Z, const float* w_rev, const float* b_rev,
  * film [B,n_scales,bands,2]; uses the model's parameters. */
 int wv_model_film(wv_model* m, const float* msg, int msg_rows, float* film, int B, void* stream);
 
+/* ---- first training-step slice ------------------------------------------------------
+ * Forward and backward of one SEANetResnetBlock half with LIVE weight normalisation
+ * (modules/seanet.py:39-116 dws_conv_block; modules/conv.py:47-88 weight norm recomputed every step;
+ *  scripts/train.py:1421-1480):
+ *     y = DW5( (g_pw v_pw/||v_pw||) @ ELU(pre_scale * x) ; g_dw v_dw/||v_dw|| ) + bias
+ * ALL pointers are DEVICE pointers (parameters live on the GPU while training): x, y, dy, dx [B,C,T];
+ * g_pw [C], v_pw [C,C] (the 1x1), g_dw [C], v_dw [C,5] (the depth-wise conv), bias [C]; gradients have the
+ * shapes of what they differentiate.  Needs C >= 33, T % 4 == 0, 16-byte aligned tensors.
+ * The weight-norm fold runs on the device in every call (wv_train_half_forward and _backward both fold). */
+typedef struct wv_train_half wv_train_half;
+int wv_train_half_create(int C, wv_train_half** out);
+void wv_train_half_destroy(wv_train_half* h);
+size_t wv_train_half_workspace_bytes(const wv_train_half* h, int B, int T);   /* backward only */
+int wv_train_half_forward(wv_train_half* h, const float* x, const float* g_pw, const float* v_pw,
+                          const float* g_dw, const float* v_dw, const float* bias, float pre_scale,
+                          float* y, int B, int T, void* stream);
+int wv_train_half_backward(wv_train_half* h, const float* x, const float* g_pw, const float* v_pw,
+                           const float* g_dw, const float* v_dw, float pre_scale, const float* dy,
+                           float* dx, float* dg_pw, float* dv_pw, float* dg_dw, float* dv_dw, float* db,
+                           int B, int T, void* workspace, size_t workspace_bytes, void* stream);
+const char* wv_train_last_error(void);
+
 /* ---- measurement hook (bench.py's roofline figures) ---------------------------------------
  * When enabled, every kernel launch is bracketed by a hipEvent pair on the launch stream and
  * aggregated by "<kernel>|<role>" together with its ALGORITHMIC flops and bytes (the per-unit

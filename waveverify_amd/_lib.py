@@ -63,6 +63,12 @@ SIGNATURES = {
     "wv_op_pw_dw": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
                               C.c_int, _VP, C.c_float, _VP]),
+    "wv_train_half_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
+    "wv_train_half_destroy": (None, [_VP]),
+    "wv_train_half_workspace_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),
+    "wv_train_half_forward": (C.c_int, [_VP] * 7 + [C.c_float, _VP, C.c_int, C.c_int, _VP]),
+    "wv_train_half_backward": (C.c_int, [_VP] * 6 + [C.c_float] + [_VP] * 7 + [C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_train_last_error": (C.c_char_p, []),
     "wv_op_resblock": (C.c_int, [_VP] * 10 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _VP]),
     "wv_op_dw_pw": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, _VP, C.c_float, _VP]),

@@ -1,0 +1,331 @@
+// First slice of the training step: forward AND backward of one SEANetResnetBlock
+// half with LIVE weight normalisation, on the GPU.
+//
+//     a = ELU(s * x);  W = g_pw * v_pw / ||v_pw||;  h = W @ a                         (1x1, no bias)
+//     w = g_dw * v_dw / ||v_dw||;  y[m,t] = b[m] + sum_i w[m,i] * h[m, t - 4 + i]     (causal depth-wise k = 5)
+// Reference: modules/seanet.py:39-116 (dws_conv_block), modules/conv.py:47-88 (weight norm, recomputed every
+// forward while training), scripts/train.py:1421-1480 (where the step runs).
+//
+// What is new here (the inference library folds weight norm once on the host):
+//   * wn_fold_kernel -- the fold on the device, re-run every step: one workgroup per output channel reduces
+//     ||v||, scales, and writes the weight straight into the layouts the kernels read (the LDS-DMA core's
+//     wq[k/4][m][4] for W, the same for W^T, the row table of the stencil) plus 1/||v|| for the backward pass.
+//   * the backward pass: dh = corr(dy, w) with the bias / tap reductions (dw_bwd_kernel, deterministic two-stage
+//     sums), da = W^T @ dh on the SAME K1 kernel as the forward GEMM (W^T packed by the fold), dx = da * ELU'(sx) * s,
+//     dW = sum_{b,t} dh a^T (gemm_nt_kernel: both operands contract over their contiguous time axis; f32 MFMA, LDS
+//     staged, split over clips with a fixed-order final sum), and the weight-norm backward (wn_bwd_kernel).
+// Gradient parity against the reference's autograd: tests/test_gpu_train.py (fixtures tests/golden/grads_half_*).
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/waveverify_hip.h"
+#include "wv_dev.h"
+
+namespace wv {
+
+// ---- weight-norm fold (conv.py:73-74: norm over all dims but 0) ------------------------------------------------
+// v [M][K], g [M] -> w [M][K] (plain), inv_norm [M]; optional packs: wq[k/4][Mp][4] (A operand of W @ X) and
+// wqT[m/4][Kp'][4] (A operand of W^T @ X, Kp' = padded K as the row count).  Padding is zeroed once by the host.
+__global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                      float* __restrict__ w, float* __restrict__ inv_norm,
+                                                      float* __restrict__ wq, float* __restrict__ wqT,
+                                                      int M, int K, int Mp, int KpT) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float* vr = v + (size_t)m * K;
+    float ss = 0.f;
+    for (int k = tid; k < K; k += 256) ss = fmaf(vr[k], vr[k], ss);
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.f / sqrtf(ss);
+    const float sc = g[m] * inv;
+    if (tid == 0) inv_norm[m] = inv;
+    for (int k = tid; k < K; k += 256) {
+        const float x = vr[k] * sc;
+        w[(size_t)m * K + k] = x;
+        if (wq) wq[((size_t)(k >> 2) * Mp + m) * 4 + (k & 3)] = x;
+        if (wqT) wqT[((size_t)(m >> 2) * KpT + k) * 4 + (m & 3)] = x;
+    }
+}
+
+// (dg, dv) of w = g * v / ||v||:  dot = <dw, v>;  dg = dot / ||v||;  dv = g / ||v|| * (dw - dot / ||v||^2 * v)
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                     const float* __restrict__ inv_norm, const float* __restrict__ dw,
+                                                     float* __restrict__ dg, float* __restrict__ dv, int K) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float* vr = v + (size_t)m * K;
+    const float* dr = dw + (size_t)m * K;
+    float dot = 0.f;
+    for (int k = tid; k < K; k += 256) dot = fmaf(dr[k], vr[k], dot);
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+    if ((tid & 63) == 0) red[tid >> 6] = dot;
+    __syncthreads();
+    dot = red[0] + red[1] + red[2] + red[3];
+    const float inv = inv_norm[m];
+    if (tid == 0) dg[m] = dot * inv;
+    const float a = g[m] * inv, c = dot * inv * inv;
+    for (int k = tid; k < K; k += 256) dv[(size_t)m * K + k] = a * (dr[k] - c * vr[k]);
+}
+
+// ---- depth-wise stencil backward ---------------------------------------------------------------------------------
+// One workgroup per (channel m, clip b) row:  dh[t] = sum_i w[m][i] * dy[t + 4 - i]  (dy = 0 past T);
+// partial[b][m][0..4] = sum_t dy[t] * h[t - 4 + i]  (h = 0 before 0), partial[b][m][5] = sum_t dy[t].
+__global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ h,
+                                                     const float* __restrict__ w, float* __restrict__ dh,
+                                                     float* __restrict__ partial, int M, int T) {
+    __shared__ float red[4][6];
+    const int m = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const size_t row = ((size_t)b * M + m) * T;
+    const float* dyr = dy + row;
+    const float* hr = h + row;
+    float wt[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wt[i] = w[m * 5 + i];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = tid; t < T; t += 256) {
+        const float d = dyr[t];
+        float g = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int tf = t + 4 - i;                              // dh[t] += w[i] * dy[t + 4 - i]
+            if (tf < T) g = fmaf(wt[i], dyr[tf], g);
+            const int tb = t - 4 + i;                              // dw[i] += dy[t] * h[t - 4 + i]
+            if (tb >= 0) acc[i] = fmaf(d, hr[tb], acc[i]);
+        }
+        acc[5] += d;
+        dh[row + t] = g;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float s = acc[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if ((tid & 63) == 0) red[tid >> 6][i] = s;
+    }
+    __syncthreads();
+    if (tid < 6) partial[((size_t)b * M + m) * 6 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// out[j] = sum_{s < S} part[s][j], fixed order (deterministic)
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int S, size_t n) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += part[(size_t)i * n + j];
+    out[j] = s;
+}
+
+// tap / bias gradient rows: dwdb[m][0..5] -> dw_dw[m][5] and db[m]
+__global__ void split_dwdb_kernel(const float* __restrict__ dwdb, float* __restrict__ dw, float* __restrict__ db, int M) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    for (int i = 0; i < 5; ++i) dw[m * 5 + i] = dwdb[m * 6 + i];
+    db[m] = dwdb[m * 6 + 5];
+}
+
+// dx = da * ELU'(s x) * s,  ELU'(z) = z > 0 ? 1 : exp(z)
+__global__ __launch_bounds__(256) void elu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ x,
+                                                      float* __restrict__ dx, float s, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 a = reinterpret_cast<const f32x4*>(da)[i], xv = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float z = s * xv[e]; o[e] = a[e] * (z > 0.f ? 1.f : __expf(z)) * s; }
+    reinterpret_cast<f32x4*>(dx)[i] = o;
+}
+__global__ void elu_bwd_tail_kernel(const float* da, const float* x, float* dx, float s, size_t lo, size_t n) {
+    const size_t i = lo + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float z = s * x[i];
+    dx[i] = da[i] * (z > 0.f ? 1.f : __expf(z)) * s;
+}
+
+// ---- dW = sum_{b,t} dh[b,m,t] * ELU(s x[b,k,t]) -----------------------------------------------------------------
+// "NT" GEMM: both operands contract over their contiguous time axis.  Workgroup = 4 waves = a 64 x 64 tile of dW,
+// one 32 x 32 block per wave; clips are dealt round-robin to the gridDim.z splits.  Per step 64 time samples of 64
+// rows of each operand are staged in LDS with coalesced 16-byte row loads ([row][t], row stride 65 floats so that the
+// 32 lanes of a fragment read -- same t, consecutive rows -- hit 32 banks), the ELU of the second operand is applied
+// on the way in.  part[split][M][K] partial sums; a fixed-order pass adds the splits.
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                      float* __restrict__ part, float s, int B, int M, int K, int T) {
+    constexpr int LD = 65;
+    __shared__ float As[64 * LD], Bs[64 * LD];
+    const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 64, split = blockIdx.z, S = gridDim.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wk = wave & 1;
+    const int i31 = lane & 31, hh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lr = tid >> 2, lc = (tid & 3) * 16;              // loader: row lr (0..63), 16 consecutive t from lc
+    for (int b = split; b < B; b += S) {
+        const float* dhb = dh + (size_t)b * M * T;
+        const float* xb = x + (size_t)b * K * T;
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int t = t0 + lc + q;
+                const bool tv = t < T;
+                As[lr * LD + lc + q] = (tv && m0 + lr < M) ? dhb[(size_t)(m0 + lr) * T + t] : 0.f;
+                float xv = (tv && k0 + lr < K) ? xb[(size_t)(k0 + lr) * T + t] : 0.f;
+                xv *= s;
+                Bs[lr * LD + lc + q] = xv > 0.f ? xv : (__expf(xv) - 1.f);     // ELU(0) = 0 keeps the padding neutral
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 64; kk += 2) {
+                const float a = As[(32 * wm + i31) * LD + kk + hh];
+                const float bq = Bs[(32 * wk + i31) * LD + kk + hh];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+            }
+        }
+    }
+    float* P = part + (size_t)split * M * K;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hh, k = k0 + 32 * wk + i31;
+        if (m < M && k < K) P[(size_t)m * K + k] = acc[r];
+    }
+}
+
+}  // namespace wv
+
+// ================================================================================================ C ABI
+namespace {
+thread_local std::string g_terr;
+int tfail(int code, const std::string& msg) { g_terr = msg; return code; }
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+}  // namespace
+
+struct wv_train_half {
+    int C = 0, Mp = 0;
+    float *w_pw = nullptr, *inv_pw = nullptr, *wq = nullptr, *wqT = nullptr;      // folded 1x1 weight + packs
+    float *w_dw = nullptr, *inv_dw = nullptr, *id_taps = nullptr;                 // folded taps [C][5]
+    float *dW = nullptr, *dwdb = nullptr, *dw_taps = nullptr;                     // weight-gradient scratch
+    std::vector<void*> owned;
+    ~wv_train_half() { for (void* p : owned) (void)hipFree(p); }
+};
+
+extern "C" {
+
+const char* wv_train_last_error(void) { return g_terr.c_str(); }
+
+int wv_train_half_create(int C, wv_train_half** out) {
+    if (!out || C < 1 || C > 4096) return tfail(WV_EINVAL, "bad channel count");
+    auto* h = new wv_train_half();
+    h->C = C; h->Mp = wv::round_up(C, wv::M_ALIGN);
+    const size_t kq = (size_t)wv::round_up(C, 32) * h->Mp;
+    auto alloc = [&](float** p, size_t n, bool zero) {
+        if (hipMalloc((void**)p, n * sizeof(float)) != hipSuccess) return false;
+        h->owned.push_back(*p);
+        return !zero || hipMemset(*p, 0, n * sizeof(float)) == hipSuccess;
+    };
+    std::vector<float> taps((size_t)C * 5, 0.f);
+    for (int m = 0; m < C; ++m) taps[(size_t)m * 5 + 4] = 1.f;
+    bool ok = alloc(&h->w_pw, (size_t)C * C, false) && alloc(&h->inv_pw, C, false) && alloc(&h->wq, kq, true) &&
+              alloc(&h->wqT, kq, true) && alloc(&h->w_dw, (size_t)C * 5, false) && alloc(&h->inv_dw, C, false) &&
+              alloc(&h->id_taps, (size_t)C * 5, false) && alloc(&h->dW, (size_t)C * C, false) &&
+              alloc(&h->dwdb, (size_t)C * 6, false) && alloc(&h->dw_taps, (size_t)C * 5, false) &&
+              hipMemcpy(h->id_taps, taps.data(), taps.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { delete h; return tfail(WV_EHIP, "device allocation failed"); }
+    *out = h;
+    return WV_OK;
+}
+
+void wv_train_half_destroy(wv_train_half* h) { delete h; }
+
+static int nt_splits(int B) { return B < 32 ? B : 32; }
+
+size_t wv_train_half_workspace_bytes(const wv_train_half* h, int B, int T) {
+    if (!h || B < 1 || T < 1) return 0;
+    const size_t act = al256((size_t)B * h->C * T * 4);
+    return 3 * act + al256((size_t)B * h->C * 6 * 4) + al256((size_t)nt_splits(B) * h->C * h->C * 4);
+}
+
+#define T_LAUNCH(expr)                                                                              \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) return tfail(WV_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+// fold both weights of the half for this step (live weight norm)
+static int fold_step(wv_train_half* h, const float* g_pw, const float* v_pw, const float* g_dw, const float* v_dw, hipStream_t s) {
+    const int C = h->C;
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(C), dim3(256), 0, s, g_pw, v_pw, h->w_pw, h->inv_pw, h->wq, h->wqT, C, C, h->Mp, h->Mp);
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(C), dim3(256), 0, s, g_dw, v_dw, h->w_dw, h->inv_dw, (float*)nullptr, (float*)nullptr, C, 5, 0, 0);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+static wv::PwWeight pack_of(const wv_train_half* h, bool transposed) {
+    wv::PwWeight p;
+    p.M = h->C; p.K = h->C; p.Mp = h->Mp; p.Kp = wv::round_up(h->C, wv::BK);
+    p.wq = transposed ? h->wqT : h->wq;
+    return p;
+}
+
+int wv_train_half_forward(wv_train_half* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
+                          const float* v_dw, const float* bias, float pre_scale, float* y, int B, int T, void* stream) {
+    if (!h || !x || !g_pw || !v_pw || !g_dw || !v_dw || !y || B < 1 || T < 1) return tfail(WV_EINVAL, "null / bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = fold_step(h, g_pw, v_pw, g_dw, v_dw, s);
+    if (rc) return rc;
+    wv::PwDwArgs a{};
+    a.X = x; a.pw = pack_of(h, false); a.dw_w = h->w_dw; a.dw_b = bias; a.Y = y;
+    a.B = B; a.Tin = T; a.Tout = T; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
+    a.pre_scale = pre_scale; a.pre_elu = 1; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
+    if (!wv::k1_supported(a)) return tfail(WV_EINVAL, "training slice: needs C >= 33, T % 4 == 0 and 16-byte aligned tensors");
+    T_LAUNCH(wv::launch_pw_dw(a, s));
+    return WV_OK;
+}
+
+int wv_train_half_backward(wv_train_half* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
+                           const float* v_dw, float pre_scale, const float* dy, float* dx, float* dg_pw, float* dv_pw,
+                           float* dg_dw, float* dv_dw, float* db, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !x || !g_pw || !v_pw || !g_dw || !v_dw || !dy || !dx || !dg_pw || !dv_pw || !dg_dw || !dv_dw || !db)
+        return tfail(WV_EINVAL, "null argument");
+    if (B < 1 || T < 1 || !ws || ws_bytes < wv_train_half_workspace_bytes(h, B, T)) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = h->C;
+    const size_t act = al256((size_t)B * C * T * 4);
+    char* w = (char*)ws;
+    float* H = (float*)w; float* DH = (float*)(w + act); float* DA = (float*)(w + 2 * act);
+    float* partial = (float*)(w + 3 * act);
+    float* parts = (float*)(w + 3 * act + al256((size_t)B * C * 6 * 4));
+    int rc = fold_step(h, g_pw, v_pw, g_dw, v_dw, s);                          // the step's weights (forward ran the same fold)
+    if (rc) return rc;
+    // h = W @ ELU(s x), recomputed (forward keeps no activations): K1 with the identity stencil
+    wv::PwDwArgs a{};
+    a.X = x; a.pw = pack_of(h, false); a.dw_w = h->id_taps; a.dw_b = nullptr; a.Y = H;
+    a.B = B; a.Tin = T; a.Tout = T; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
+    a.pre_scale = pre_scale; a.pre_elu = 1; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
+    if (!wv::k1_supported(a)) return tfail(WV_EINVAL, "training slice: needs C >= 33, T % 4 == 0 and 16-byte aligned tensors");
+    T_LAUNCH(wv::launch_pw_dw(a, s));
+    // dh, and the per-clip partial sums of the tap / bias gradients
+    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(C, B), dim3(256), 0, s, dy, H, h->w_dw, DH, partial, C, T);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((C * 6 + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)C * 6);
+    hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((C + 255) / 256), dim3(256), 0, s, h->dwdb, h->dw_taps, db, C);
+    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g_dw, v_dw, h->inv_dw, h->dw_taps, dg_dw, dv_dw, 5);
+    T_LAUNCH(hipGetLastError());
+    // da = W^T @ dh on the forward's GEMM kernel, then through the ELU
+    wv::PwDwArgs t{};
+    t.X = DH; t.pw = pack_of(h, true); t.dw_w = h->id_taps; t.dw_b = nullptr; t.Y = DA;
+    t.B = B; t.Tin = T; t.Tout = T; t.ks = 5; t.stride = 1; t.dil = 1; t.pad = 4;
+    t.pre_scale = 1.f; t.pre_elu = 0; t.out_scale = 1.f; t.bands = 1; t.film_stride = 2;
+    T_LAUNCH(wv::launch_pw_dw(t, s));
+    const size_t n = (size_t)B * C * T, n4 = n / 4;
+    if (n4) hipLaunchKernelGGL(wv::elu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, DA, x, dx, pre_scale, n4);
+    if (n % 4) hipLaunchKernelGGL(wv::elu_bwd_tail_kernel, dim3(1), dim3(256), 0, s, DA, x, dx, pre_scale, n4 * 4, n);
+    // dW = sum dh a^T, then the weight-norm backward
+    const int S = nt_splits(B);
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((C + 63) / 64, (C + 63) / 64, S), dim3(256), 0, s, DH, x, parts, pre_scale, B, C, C, T);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)C * C + 255) / 256)), dim3(256), 0, s, parts, h->dW, S, (size_t)C * C);
+    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, C);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+}  // extern "C"
