@@ -164,6 +164,32 @@ def test_fused_resblock(ops, C, T):
     close(gact, O.elu(y.astype(np.float32) * s_act), what="fused resblock (activated copy)")
 
 
+@pytest.mark.parametrize("B,C,T", [(6, 128, 400), (7, 128, 36), (5, 96, 200), (9, 64, 60), (3, 256, 2000), (16, 192, 12), (4, 384, 124)])
+@pytest.mark.parametrize("mode", ["copy", "copy+resid+act"])
+def test_pw_dw_flat_clip_time_tiling(ops, B, C, T, mode):
+    """Flattened (clip, time) tiling of the k5 units on the LDS-DMA core: tiles run across clip boundaries over the
+    per-clip padded axis (several short clips per tile, a clip split over many tiles).  The causal zero padding in
+    front of EVERY clip and the outputs of every clip must come out exactly as with per-clip tiles."""
+    rng = np.random.default_rng(B * 100 + C + T)
+    X = rnd(rng, B, C, T)
+    w_pw = rnd(rng, C, C, 1, scale=C ** -0.5)
+    w_dw = rnd(rng, C, 1, 5, scale=0.45)
+    b_dw = rnd(rng, C, scale=0.1)
+    ref = O.sconv1d(O.sconv1d(X, w_pw, None), w_dw, b_dw, groups=C)
+    kw = {}
+    if "resid" in mode:
+        R = rnd(rng, *ref.shape)
+        ref = ref * np.float32(0.37) + R
+        kw.update(resid=cu(R), out_scale=0.37)
+    ref = ref.astype(np.float32)
+    if "act" in mode:
+        got, gact = ops.pw_dw(cu(X), w_pw, w_dw, b_dw, pre_elu=False, act_scale=0.7071, **kw)
+        close(gact, O.elu(ref * np.float32(0.7071)), what="flat tiling (activated copy)")
+    else:
+        got = ops.pw_dw(cu(X), w_pw, w_dw, b_dw, pre_elu=False, **kw)
+    close(got, ref, what="flat tiling")
+
+
 def test_pw_dw_no_prologue_no_bias(ops):
     """decoder head: 1x1 (128->1536, no bias) -> DW k5 (seanet.py:1070-1091)."""
     rng = np.random.default_rng(5)

@@ -86,6 +86,16 @@ struct DmaRows {                        // LDR 0: B = X rows, pure copy (global_
         K = K_;
         (void)wave;
     }
+    // flattened (clip, time) axis: global column g = b * Tv + u, u = t + pad (see k1_kernel)
+    __device__ __forceinline__ void init_flat(const float* X, int K_, int Tin, int B, int Tv, int pad, long long g0, int lane) {
+        const long long g = g0 + 4 * (lane % C::CG);
+        const int b = (int)(g / Tv), t = (int)(g - (long long)b * Tv) - pad;
+        rbase = lane / C::CG;
+        const bool inr = b < B && t >= 0;                      // t + 3 < Tin holds: Tv, pad and g are multiples of 4
+        src = inr ? X + (size_t)b * K_ * Tin + t : g_zero16;
+        ld = inr ? (size_t)Tin : 0;
+        K = K_;
+    }
     __device__ __forceinline__ void issue(int c, f32x4* Bst, int wave) const {
 #pragma unroll
         for (int i = 0; i < C::B_PER_DMA; ++i) {
@@ -140,6 +150,7 @@ struct K1Epi {
     int M, m0, b, to0, lane, wave, half, q, o, to;
     bool act_lane, vec;
     const float* Rb; float* Yb; float* Ab; float* Wl;
+    int voff0, nrec;                                             // EPI 0: lane's first byte offset (or an out-of-range marker), buffer size
 
     __device__ __forceinline__ int row_of(int r) const { return 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half; }
     __device__ __forceinline__ ovec load_res(const PwDwArgs& p, int r) const {
@@ -180,7 +191,7 @@ struct K1Epi {
             }
         }
     }
-    __device__ __forceinline__ void begin(const PwDwArgs& p, float* table, int m0_, int b_, int to0_) {
+    __device__ __forceinline__ void begin(const PwDwArgs& p, float* table, int m0_, int b_, int to0_, long long gflat = 0) {
         M = p.pw.M; m0 = m0_; b = b_; to0 = to0_;
         const int tid = threadIdx.x;
         lane = tid & 63;
@@ -194,6 +205,18 @@ struct K1Epi {
         o = NT * q; to = to0 + o;
         act_lane = o < p.tto && to < p.Tout;
         vec = act_lane && to + NT - 1 < p.Tout && o + NT - 1 < p.tto && (p.Tout % NT) == 0;
+        nrec = M * p.Tout * 4;
+        voff0 = act_lane ? ((m0 + 32 * wave + 4 * half) * p.Tout + to) * 4 : 0x7f000000;
+        if (EPI == 0 && p.flat) {
+            // flattened tiling: this lane's outputs sit at global columns gflat + pad + NT*q .. of the padded
+            // (clip, time) axis; whole-tensor buffers (rows are whole: M % BM == 0, checked by the launcher)
+            const long long gc = gflat + p.pad + o;
+            const int bo2 = (int)(gc / p.Tv), t = (int)(gc - (long long)bo2 * p.Tv) - p.pad;
+            const bool ok = o < p.tto && bo2 < p.B && t >= 0;
+            Yb = p.Y; Ab = p.Yact; Rb = RES ? p.resid : nullptr;
+            nrec = (int)((long long)p.B * M * p.Tout * 4);
+            voff0 = ok ? (int)((((long long)bo2 * M + m0 + 32 * wave + 4 * half) * p.Tout + t) * 4) : (int)0x80000000u;
+        }
         const int bw = p.film ? (M / p.bands) : 1;
         const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
         for (int m = tid; m < C::BM; m += C::NTHREADS) {
@@ -228,12 +251,12 @@ struct K1Epi {
     __device__ __forceinline__ void finish(f32x16 (&acc)[NT], const PwDwArgs& p, float* strips) {
         if constexpr (EPI == 0) {
             constexpr int NSH = 4 / NT;                          // lane shifts that bring 4 more columns
-            const int clip_bytes = M * p.Tout * 4;
+            const int clip_bytes = nrec;
             const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(Yb ? Yb : p.Yact, 0, Yb ? clip_bytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(Ab ? Ab : p.Yact, 0, Ab ? clip_bytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Rb ? Rb : p.X), 0, Rb ? clip_bytes : 0, 0x00020000);
             const int row_bytes = p.Tout * 4;
-            const int voff = act_lane ? ((m0 + 32 * wave + 4 * half) * p.Tout + to) * 4 : 0x7f000000;
+            const int voff = voff0;
             const float* Wrow = Wl + (32 * wave + 4 * half) * 8;
             ovec res4[RES ? 4 : 1];                              // RES instantiations always have a residual operand
             if constexpr (RES) {
@@ -398,8 +421,19 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
     typedef K1Epi<C, EPI, RES> Epi;
     typedef typename LdrSel<LDR>::type LB;
     typedef typename NVec<C::NT>::type bvec;
-    const TileId tile = decode_tile(p);
+    // Tile decode.  Per-clip tiling: (m-tile, time tile, clip).  Flattened tiling (p.flat; k5 stencil + DMA operand
+    // only): the clips' time axes, each with its `pad` causal zero columns in front, are laid end to end (period
+    // Tv = T + pad, a multiple of 4) and tiles of tto = BN - 4 outputs run straight across the clip boundaries, so
+    // the only columns computed twice are the 4 halo columns per tile and the 4 pad columns per clip: 4 % instead
+    // of 9 % (T = 2000) or 12 % (T = 400, which also moves from 64- to 128-column windows).
+    TileId tile = decode_tile(p);
+    if (EPI == 0 && LDR == 0 && p.flat) {
+        const unsigned L = blockIdx.x, j = L >> 3;
+        tile.m_tile = j % p.num_m; tile.t_tile = (j / p.num_m) * 8 + (L & 7); tile.b = 0;
+        tile.valid = tile.t_tile < p.num_t;                    // num_t = flat tile count
+    }
     if (!tile.valid) return;
+    const long long gflat = (long long)tile.t_tile * p.tto;      // flat tiling: first global column of this tile
     f32x4* S4 = reinterpret_cast<f32x4*>(smem);
     float* table = smem + NS * C::STAGE4 * 4;
     static_assert(NS == 2 || (NS == 3 && LDR == 0), "three stages: DMA path only");
@@ -416,13 +450,16 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
     const float* Xb = p.X + (size_t)b * K * p.Tin;
 
     Epi epi;
-    epi.begin(p, table, m0, b, to0);
+    epi.begin(p, table, m0, b, to0, gflat);
     DmaRows<C> db{};
     DmaA<C> da;
     da.init(wq, Mp, m0, nchunks, wave, lane);
     LB lb{};
     float raw[REG ? C::B_PER : 1][REG ? LB::NRAW : 1];
-    if constexpr (LDR == 0) db.init(Xb, K, p.Tin, ti0, wave, lane);
+    if constexpr (LDR == 0) {
+        if (EPI == 0 && p.flat) db.init_flat(p.X, K, p.Tin, p.B, p.Tv, p.pad, gflat, lane);
+        else db.init(Xb, K, p.Tin, ti0, wave, lane);
+    }
     else if constexpr (LDR == 1) lb = LB{Xb, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
     else lb = LB{Xb, p.ct_w, p.ct_wt, K, p.pw.Kp, p.Tin, p.Tout, ti0, p.ratio, p.pre_scale, p.pre_elu, 0, 0, {}, {}};
 
@@ -543,12 +580,18 @@ static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
     a.num_m = (a.pw.M + C::BM - 1) / C::BM;
     a.num_t = (a.Tout + a.tto - 1) / a.tto;
     a.stagger = 0; a.first_gen = 0;
-    const long long n_act = (long long)a.num_t * a.B;
+    long long n_act = (long long)a.num_t * a.B;
+    if (a.flat) {                                            // flat tiles over the padded (clip, time) axis
+        if (!(EPI == 0 && LDR == 0 && C::NT == 4)) return hipErrorInvalidValue;
+        n_act = ((long long)a.B * a.Tv - a.pad + a.tto - 1) / a.tto;
+        if (n_act > 0x7fffffffLL) return hipErrorInvalidValue;
+        a.num_t = (int)n_act;
+    }
     const long long nblk = ((n_act + 7) / 8) * 8 * a.num_m;
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     std::string name;
     if (prof::enabled())
-        name = std::string(base) + "<" + std::to_string(C::BM) + "," + std::to_string(C::BN) + (LDR == 0 ? (NS == 3 ? ",dma3>" : ",dma>") : ",reg>");
+        name = std::string(base) + "<" + std::to_string(C::BM) + "," + std::to_string(C::BN) + (LDR == 0 ? (NS == 3 ? ",dma3" : ",dma") : ",reg") + (a.flat ? ",flat>" : ">");
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
     const double outs = (a.Y ? 1.0 : 0.0) + (a.Yact ? 1.0 : 0.0) + (a.resid ? 1.0 : 0.0);
     const double flops = a.ct_w ? 2.0 * Bd * a.Tout * K * (M + 2.0) : 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout);
@@ -607,6 +650,25 @@ hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
         }
     }
     (void)need;
+    // Flattened (clip, time) tiling for the k5 stencil with a DMA'd operand (see k1_kernel): taken when it computes
+    // at least 2 % fewer columns than per-clip tiles, rows are whole tiles and one tensor stays below 2 GB (32-bit
+    // buffer offsets).  WV_K1_FLAT=0 switches it off (A/B runs).
+    static const int flat_on = getenv("WV_K1_FLAT") ? atoi(getenv("WV_K1_FLAT")) : 1;
+    a.flat = 0;
+    if (flat_on && k5 && !a.ct_w && !a.pre_elu && a.pre_scale == 1.f && a.B > 1 && (a.Tin & 3) == 0) {
+        int bm = 128, best = (a.pw.M + 127) / 128 * 128;
+        for (int cand : {96, 64}) { const int pd = (a.pw.M + cand - 1) / cand * cand; if (pd < best) { best = pd; bm = cand; } }
+        const long long Tv = a.Tin + 4;
+        const long long flat_cols = ((long long)a.B * Tv - 4 + 123) / 124 * 128;
+        PwDwArgs g = a;
+        const int bn = narrow ? 64 : 128;
+        long long clip_cols = -1;
+        if (pw_dw_geometry(g, bn)) clip_cols = (long long)a.B * ((a.Tout + g.tto - 1) / g.tto) * bn;
+        if (a.pw.M % bm == 0 && (long long)a.B * a.pw.M * a.Tout * 4 < 0x7fffffffLL && clip_cols > 0 &&
+            flat_cols * 100 < clip_cols * 98) {
+            a.flat = 1; a.Tv = (int)Tv; narrow = false;
+        }
+    }
     if (!pw_dw_geometry(a, narrow ? 64 : 128)) return hipErrorNotSupported;
     // every tile's window must start on a multiple of 4 samples (16-byte DMA source addresses)
     if ((a.tto * a.stride) % 4 != 0 || (a.pad + a.off) % 4 != 0) return hipErrorNotSupported;

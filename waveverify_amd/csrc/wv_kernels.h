@@ -45,6 +45,7 @@ struct PwDwArgs {
     int tto, off;         // filled by launch_pw_dw: outputs per time tile; stencil offset inside
                           // the 4-aligned H window
     int spec_add;         // 1: the SpecBlock add (identity stencil, resid == Y): own kernel instantiation
+    int flat, Tv;         // LDS-DMA core, filled by its launcher: flattened (clip, time) tiling with period Tv = T + pad
     const float* ct_w;    // upsample unit only: DW ConvTranspose taps [K, 2*ratio] and ratio; X is then
     int ratio;            //   [B, K, Tin], Tout = Tin*ratio
     const float* ct_wt;   // the same taps transposed and zero padded, [2*ratio][pw.Kp] (pack_ct_wt)
