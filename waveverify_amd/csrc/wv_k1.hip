@@ -427,7 +427,7 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
     // the only columns computed twice are the 4 halo columns per tile and the 4 pad columns per clip: 4 % instead
     // of 9 % (T = 2000) or 12 % (T = 400, which also moves from 64- to 128-column windows).
     TileId tile = decode_tile(p);
-    if (EPI == 0 && LDR == 0 && p.flat) {
+    if (EPI == 0 && p.flat) {
         const unsigned L = blockIdx.x, j = L >> 3;
         tile.m_tile = j % p.num_m; tile.t_tile = (j / p.num_m) * 8 + (L & 7); tile.b = 0;
         tile.valid = tile.t_tile < p.num_t;                    // num_t = flat tile count
@@ -460,8 +460,21 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
         if (EPI == 0 && p.flat) db.init_flat(p.X, K, p.Tin, p.B, p.Tv, p.pad, gflat, lane);
         else db.init(Xb, K, p.Tin, ti0, wave, lane);
     }
-    else if constexpr (LDR == 1) lb = LB{Xb, K, p.Tin, p.Tin, ti0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
-    else lb = LB{Xb, p.ct_w, p.ct_wt, K, p.pw.Kp, p.Tin, p.Tout, ti0, p.ratio, p.pre_scale, p.pre_elu, 0, 0, {}, {}};
+    else {
+        // register path: per-clip tiles share one clip base and window start; with flat tiling every thread derives
+        // the clip and the local time of its own 4-column group (c0 is chosen so that the loader's c0 + 4*cg is it)
+        const float* Xt = Xb;
+        int c0 = ti0, ncols = p.Tin, tout = p.Tout;
+        if (EPI == 0 && p.flat) {
+            const long long g = gflat + 4 * cg;
+            const int bb = (int)(g / p.Tv), t = (int)(g - (long long)bb * p.Tv) - p.pad;
+            const bool inb = bb < p.B;
+            Xt = p.X + (size_t)(inb ? bb : 0) * K * p.Tin;
+            c0 = t - 4 * cg; ncols = inb ? p.Tin : 0; tout = inb ? p.Tout : 0;
+        }
+        if constexpr (LDR == 1) lb = LB{Xt, K, p.Tin, ncols, c0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
+        else lb = LB{Xt, p.ct_w, p.ct_wt, K, p.pw.Kp, p.Tin, tout, c0, p.ratio, p.pre_scale, p.pre_elu, 0, 0, {}, {}};
+    }
 
     auto issue = [&](int c, int st) {
         f32x4* S = S4 + st * C::STAGE4;
@@ -582,7 +595,7 @@ static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
     a.stagger = 0; a.first_gen = 0;
     long long n_act = (long long)a.num_t * a.B;
     if (a.flat) {                                            // flat tiles over the padded (clip, time) axis
-        if (!(EPI == 0 && LDR == 0 && C::NT == 4)) return hipErrorInvalidValue;
+        if (!(EPI == 0 && C::NT == 4)) return hipErrorInvalidValue;
         n_act = ((long long)a.B * a.Tv - a.pad + a.tto - 1) / a.tto;
         if (n_act > 0x7fffffffLL) return hipErrorInvalidValue;
         a.num_t = (int)n_act;
@@ -655,10 +668,10 @@ hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
     // buffer offsets).  WV_K1_FLAT=0 switches it off (A/B runs).
     static const int flat_on = getenv("WV_K1_FLAT") ? atoi(getenv("WV_K1_FLAT")) : 1;
     a.flat = 0;
-    if (flat_on && k5 && !a.ct_w && !a.pre_elu && a.pre_scale == 1.f && a.B > 1 && (a.Tin & 3) == 0) {
+    if (flat_on && k5 && a.B > 1 && (a.Tout & 3) == 0) {
         int bm = 128, best = (a.pw.M + 127) / 128 * 128;
         for (int cand : {96, 64}) { const int pd = (a.pw.M + cand - 1) / cand * cand; if (pd < best) { best = pd; bm = cand; } }
-        const long long Tv = a.Tin + 4;
+        const long long Tv = a.Tout + 4;                    // the H window runs over OUTPUT times (= input times for stride 1)
         const long long flat_cols = ((long long)a.B * Tv - 4 + 123) / 124 * 128;
         PwDwArgs g = a;
         const int bn = narrow ? 64 : 128;
