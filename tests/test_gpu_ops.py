@@ -247,7 +247,10 @@ def test_pointwise_accumulate(ops, F, C, T):
 
 
 @pytest.mark.parametrize("n_fft,hop,T", [(64, 1, 1000), (128, 2, 1001), (256, 8, 4000), (512, 40, 4001),
-                                         (1024, 320, 16000), (16, 1, 5), (32, 4, 1), (256, 32, 777)])
+                                         (1024, 320, 16000), (16, 1, 5), (32, 4, 1), (256, 32, 777),
+                                         # frame counts that are multiples of the vector width: the LDS-DMA core
+                                         (128, 2, 1000), (192, 4, 800), (16, 1, 8), (32, 4, 1024), (512, 40, 4000),
+                                         (64, 2, 2024), (1024, 64, 4096), (256, 16, 16000)])
 def test_stft_logmag(ops, n_fft, hop, T):
     rng = np.random.default_rng(n_fft + hop)
     wav = np.clip(rnd(rng, 2, 1, T, scale=0.1), -1, 1)

@@ -7,6 +7,7 @@ namespace wv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));   // 4-byte aligned pair (global loads may be unaligned)
 constexpr int NT_ = 256;   // threads per workgroup
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
@@ -53,6 +54,18 @@ struct RowPairLoader {
         for (int i = 0; i < 8; ++i) o[i] = xform(raw[i]);
     }
 };
+
+// log-magnitude feature of one STFT bin (modules/conv.py:1078, seanet.py:487-494):
+//   (log(max(sqrt(max(re^2 + im^2, 1e-12)), 1e-5)) - mean) / std.
+// sqrt(max(p, 1e-12)) >= 1e-6 and the outer clamp at 1e-5 = sqrt(1e-10) supersedes the inner one, so this is
+// 0.5 * log(max(p, 1e-10)) -- one v_log_f32 and one fma instead of a correctly rounded sqrt, a log and two
+// more operations per value (the matrix pipe waits for every VALU instruction of the epilogue).  The two forms
+// differ by rounding of the log only (<= 2e-7 relative); the parity bar on the feature is 2e-5.
+//   c1 = 0.5 * ln(2) / std,  c0 = -mean / std
+__device__ __forceinline__ float stft_logmag(float re, float im, float c1, float c0) {
+    const float pw = fmaxf(fmaf(re, re, im * im), 1e-10f);
+    return fmaf(__builtin_amdgcn_logf(pw), c1, c0);
+}
 
 // B operand of the upsample unit for the k-inner core: act(s*x) -> depth-wise ConvTranspose1d(2r, r),
 // right-trimmed (modules/conv.py SConvTranspose1d causal trim), produced on the fly:

@@ -29,6 +29,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 #include "wv_dev.h"
 
@@ -701,6 +702,217 @@ hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
     return k1_pick_epi<K1<4, 16, 64>>(a, s, k5);
 }
 
+
+// =================================================================================================
+// CausalSTFT -> log-magnitude on the LDS-DMA core (modules/conv.py:1036-1086, seanet.py:479-494).
+// The STFT is a GEMM against the windowed DFT basis: A = basis rows packed like a 1x1 weight (wq layout, rows
+// arranged so that an accumulator register pair (2f, 2f+1) of one lane is (re, im) of bin f; row pair 0 =
+// (cos_0, cos_Nyquist)), by descriptor DMA; B[k][t] = wav[t*hop + k - (n_fft-1)] (left zero history) gathered
+// through registers into the natural [k][t] stage -- loads go to clamped addresses, the zero-selects happen at
+// commit time.  The two left-over basis rows sin_0 / sin_Nyquist (see StftArgs) are two plain dot products per
+// frame, accumulated per thread next to the commit (first m-tile only) and reduced through LDS after the loop.
+// Epilogue: a lane holds 4 (2) consecutive frames of both halves of a bin -> sqrt(max(re^2+im^2,1e-12)) ->
+// log(max(.,1e-5)) -> (y - mean)/std -> one 16-byte (8-byte) store.  Round 1's kernel (generic core, 4-byte
+// scattered stores, 74 TFLOP/s) stays for frame counts that are not a multiple of the vector width.
+// =================================================================================================
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS, C::B_PER > 1 ? 3 : 4) void stft_k1_kernel(StftArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef typename NVec<C::NT>::type bvec;
+    typedef unsigned uvec __attribute__((ext_vector_type(C::NT)));
+    const unsigned L = blockIdx.x, j = L >> 3;
+    const int m_tile = j % p.num_m;
+    const unsigned n_idx = (j / p.num_m) * 8 + (L & 7);
+    if (n_idx >= (unsigned)p.num_t * p.B) return;
+    const int t_tile = n_idx % p.num_t, b = n_idx / p.num_t;
+    f32x4* S4 = reinterpret_cast<f32x4*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, i31 = lane & 31, cg = tid % C::CG;
+    const int K = p.n_fft, m0 = m_tile * C::BM, t0 = t_tile * C::BN;
+    const int nchunks = (K + C::BKC - 1) / C::BKC;
+    const float* wb = p.wav + (size_t)b * p.T;
+    DmaA<C> da;
+    da.init(reinterpret_cast<const f32x4*>(p.basis_q), p.Mp, m0, nchunks, wave, lane);
+
+    // frame gather: this thread's 4 frames t0 + 4cg + e; rows 2kp, 2kp + 1 of a chunk are adjacent samples
+    int sbase[4]; bool fv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int t = t0 + 4 * cg + e;
+        fv[e] = t < p.Tf;
+        sbase[e] = t * p.hop - (p.n_fft - 1);
+    }
+    // interior tiles (all but the first few and the last of a clip): every sample of the window exists -> one
+    // unaligned 8-byte load per frame and row pair, no clamps, no selects
+    const bool interior = (K % C::BKC) == 0 && t0 + C::BN <= p.Tf && (long long)t0 * p.hop - (p.n_fft - 1) >= 0 &&
+                          (long long)(t0 + C::BN - 1) * p.hop < p.T;
+    float raw[C::B_PER][8];
+    const bool side_on = m_tile == 0;                          // workgroup-uniform
+    float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int c, auto FAST) {
+#pragma unroll
+        for (int r = 0; r < C::B_PER; ++r) {
+            const int idx = tid + r * C::NTHREADS;
+            if (!(C::NBT % C::NTHREADS == 0 || idx < C::NBT)) continue;
+            const int k0 = c * C::BKC + 2 * (idx / C::CG);
+            if constexpr (decltype(FAST)::value) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2u v = *reinterpret_cast<const f32x2u*>(wb + (sbase[e] + k0));
+                    raw[r][e] = v.x; raw[r][4 + e] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) raw[r][4 * i + e] = wb[min(max(sbase[e] + k0 + i, 0), p.T - 1)];
+            }
+        }
+    };
+    auto commit = [&](int c, int st, auto FAST) {
+        f32x4* Bq = S4 + st * C::STAGE4 + C::A4;
+#pragma unroll
+        for (int r = 0; r < C::B_PER; ++r) {
+            const int idx = tid + r * C::NTHREADS;
+            if (!(C::NBT % C::NTHREADS == 0 || idx < C::NBT)) continue;
+            const int kp = idx / C::CG, k0 = c * C::BKC + 2 * kp;
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (decltype(FAST)::value) o[4 * i + e] = raw[r][4 * i + e];
+                    else {
+                        const int sidx = sbase[e] + k0 + i;
+                        o[4 * i + e] = (fv[e] && k0 + i < K && sidx >= 0 && sidx < p.T) ? raw[r][4 * i + e] : 0.f;
+                    }
+                }
+            Bq[(2 * kp) * C::CG + cg] = f32x4{o[0], o[1], o[2], o[3]};
+            Bq[(2 * kp + 1) * C::CG + cg] = f32x4{o[4], o[5], o[6], o[7]};
+            if (side_on) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int k = min(k0 + i, K - 1);           // rows past K carry zeros
+                    const float s0 = p.side[k], s1 = p.side[K + k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { d0[e] = fmaf(s0, o[4 * i + e], d0[e]); d1[e] = fmaf(s1, o[4 * i + e], d1[e]); }
+                }
+            }
+        }
+    };
+    f32x16 acc[C::NT];
+#pragma unroll
+    for (int e = 0; e < C::NT; ++e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+    auto gemm = [&](auto FAST) {
+        da.issue(0, S4, wave);
+        fetch(0, FAST); commit(0, 0, FAST);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int st = c & 1;
+            const f32x4* S = S4 + st * C::STAGE4;
+            if (c + 1 < nchunks) { da.issue(c + 1, S4 + (st ^ 1) * C::STAGE4, wave); fetch(c + 1, FAST); }
+            const float* Bf = reinterpret_cast<const float*>(S + C::A4) + C::NT * i31;
+#pragma unroll
+            for (int g = 0; g < C::BKC / 16; ++g) {
+                const f32x4 a0 = S[(4 * g + h) * C::BM + 32 * wave + i31];
+                const f32x4 a1 = S[(4 * g + h + 2) * C::BM + 32 * wave + i31];
+#define WV_ST_STEP(AV, ROW)                                                                        \
+    { const bvec bv = *reinterpret_cast<const bvec*>(Bf + (ROW) * C::BN);                          \
+      _Pragma("unroll") for (int e = 0; e < C::NT; ++e)                                            \
+          acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, bv[e], acc[e], 0, 0, 0); }
+                WV_ST_STEP(a0.x, 16 * g + 4 * h + 0) WV_ST_STEP(a0.y, 16 * g + 4 * h + 1)
+                WV_ST_STEP(a0.z, 16 * g + 4 * h + 2) WV_ST_STEP(a0.w, 16 * g + 4 * h + 3)
+                WV_ST_STEP(a1.x, 16 * g + 8 + 4 * h + 0) WV_ST_STEP(a1.y, 16 * g + 8 + 4 * h + 1)
+                WV_ST_STEP(a1.z, 16 * g + 8 + 4 * h + 2) WV_ST_STEP(a1.w, 16 * g + 8 + 4 * h + 3)
+#undef WV_ST_STEP
+            }
+            if (c + 1 < nchunks) commit(c + 1, st ^ 1, FAST);
+            __syncthreads();
+        }
+    };
+    if (interior) gemm(std::true_type{});
+    else gemm(std::false_type{});
+    // the side rows: per-thread partial dot products -> LDS [slot][column][2] (aliases the stages) -> summed per column
+    float* sd = smem;
+    if (side_on) {                                               // one slot per row group of threads (tid / CG)
+        const int slot = tid / C::CG;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sd[(slot * C::BN + 4 * cg + e) * 2] = d0[e];
+            sd[(slot * C::BN + 4 * cg + e) * 2 + 1] = d1[e];
+        }
+        __syncthreads();
+    }
+    constexpr int NSLOT = C::NTHREADS / C::CG;
+    const int clip_bytes = p.F * p.Tf * 4;
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(p.P + (size_t)b * p.F * p.Tf, 0, clip_bytes, 0x00020000);
+    const int tq = t0 + C::NT * i31;                            // Tf % NT == 0: the lane's frames are all in or all out
+    const bool lane_ok = tq < p.Tf;
+    auto logmag = [&](float re, float im) { return stft_logmag(re, im, p.c1, p.c0); };
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const int row = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;          // even: (re, im) rows 2f, 2f + 1
+        const bool row_ok = lane_ok && row < p.n_fft;
+        if (row == 0) {                                          // (cos_0, cos_Nyquist) + the two side rows
+            bvec y0, y1;
+#pragma unroll
+            for (int e = 0; e < C::NT; ++e) {
+                float s0 = 0.f, s1 = 0.f;
+                const int col = C::NT * i31 + e;
+                for (int sl = 0; sl < NSLOT; ++sl) { s0 += sd[(sl * C::BN + col) * 2]; s1 += sd[(sl * C::BN + col) * 2 + 1]; }
+                y0[e] = logmag(acc[e][r], s0);
+                y1[e] = logmag(acc[e][r + 1], s1);
+            }
+            const int v0 = lane_ok ? tq * 4 : 0x7f000000, v1 = lane_ok ? ((p.F - 1) * p.Tf + tq) * 4 : 0x7f000000;
+            if constexpr (C::NT == 4) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y0), rP, v0, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y1), rP, v1, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y0), rP, v0, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y1), rP, v1, 0, 0);
+            }
+        } else {
+            bvec y;
+#pragma unroll
+            for (int e = 0; e < C::NT; ++e) y[e] = logmag(acc[e][r], acc[e][r + 1]);
+            const int v = row_ok ? ((row >> 1) * p.Tf + tq) * 4 : 0x7f000000;
+            if constexpr (C::NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y), rP, v, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y), rP, v, 0, 0);
+        }
+    }
+}
+
+template <class C>
+static hipError_t stft_k1_run(StftArgs a, hipStream_t s) {
+    a.num_m = (a.n_fft + C::BM - 1) / C::BM;
+    a.num_t = (a.Tf + C::BN - 1) / C::BN;
+    const long long n_act = (long long)a.num_t * a.B;
+    const long long nblk = ((n_act + 7) / 8) * 8 * a.num_m;
+    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    const size_t side_bytes = (size_t)(C::NTHREADS / C::CG) * C::BN * 2 * sizeof(float);
+    const size_t smem = std::max<size_t>(2 * (size_t)C::STAGE4 * 16, side_bytes);
+    std::string name;
+    if (prof::enabled()) name = "stft_logmag<" + std::to_string(C::BM) + "," + std::to_string(C::BN) + ",k1>";
+    prof::Scope ps(s, name.c_str(), 2.0 * a.B * (2.0 * a.F) * a.n_fft * a.Tf, 4.0 * a.B * ((double)a.T + (double)a.F * a.Tf));
+    hipLaunchKernelGGL(stft_k1_kernel<C>, dim3((unsigned)nblk), dim3(C::NTHREADS), smem, s, a);
+    return hipGetLastError();
+}
+
+// hipErrorNotSupported: use the round-1 kernel (no k-inner basis, or a frame count that is not a multiple of the vector width)
+hipError_t launch_stft_k1(const StftArgs& a, hipStream_t s) {
+    if (!a.basis_q || a.n_fft < 4 || (a.n_fft & 1) || (long long)a.F * a.Tf * 4 >= OOB_VOFF) return hipErrorNotSupported;
+    // <= 64 frames per clip (one 64-column tile, never interior: measured 416 vs 376 us on the 1024-point scale):
+    // the round-1 kernel keeps those
+    if (a.Tf <= 64 || a.Tf % 4) return hipErrorNotSupported;
+    int bm = 128, best = (a.n_fft + 127) / 128 * 128;
+    for (int cand : {96, 64}) { const int pd = (a.n_fft + cand - 1) / cand * cand; if (pd < best) { best = pd; bm = cand; } }
+    if (bm == 128) return stft_k1_run<K1<4, 16, 128>>(a, s);
+    if (bm == 96) return stft_k1_run<K1<4, 16, 96>>(a, s);
+    return stft_k1_run<K1<4, 16, 64>>(a, s);
+}
 
 // =================================================================================================
 // Whole SEANetResnetBlock in ONE launch for narrow layers (C <= 192; modules/seanet.py:245-281, 39-116):

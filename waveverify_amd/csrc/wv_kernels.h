@@ -119,7 +119,18 @@ struct StftArgs {
     float* P;             // [B, F, Tf]
     int B, T, Tf, n_fft, hop, F, Mp;
     float mean, inv_std;
+    const float* basis_q; // the same matrix in the k-inner layout of the LDS-DMA core, [roundup(n_fft,32)/4][Mp][4] (pack_stft_q); may be null
+    int num_m, num_t;     // filled by the launcher
+    float c1, c0;         // filled by the launcher: 0.5 ln2 / std, -mean / std
 };
+// host: basis_t[Kp][Mp] (pack_stft_basis) -> basis_q[roundup(n_fft,32)/4][Mp][4]
+inline std::vector<float> pack_stft_q(const std::vector<float>& bt, int n_fft, int Mp) {
+    std::vector<float> q((size_t)round_up(n_fft, 32) * Mp, 0.f);
+    for (int n = 0; n < n_fft; ++n)
+        for (int m = 0; m < Mp; ++m) q[((size_t)(n >> 2) * Mp + m) * 4 + (n & 3)] = bt[(size_t)n * Mp + m];
+    return q;
+}
+hipError_t launch_stft_k1(const StftArgs& a, hipStream_t s);   // wv_k1.hip; hipErrorNotSupported -> round-1 kernel
 // host: basis [2F][n_fft] (cos rows, then sin rows; modules/conv.py:1003-1026) -> basis_t, side
 inline void pack_stft_basis(const float* basis, int n_fft, std::vector<float>& bt, std::vector<float>& side, int* Mp_out) {
     const int F = n_fft / 2 + 1, Mp = round_up(n_fft, M_ALIGN), Kp = round_up(n_fft, BK);

@@ -741,10 +741,7 @@ __global__ __launch_bounds__(NT_) void stft_logmag_kernel(StftArgs p) {
                 const int t = t0 + col;
                 if (row >= p.n_fft || t >= p.Tf) continue;
                 const float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
-                auto logmag = [&](float re, float im) {
-                    const float mag = sqrtf(fmaxf(fmaf(re, re, im * im), 1e-12f));       // conv.py:1078
-                    return (__logf(fmaxf(mag, 1e-5f)) - p.mean) * p.inv_std;
-                };
+                auto logmag = [&](float re, float im) { return stft_logmag(re, im, p.c1, p.c0); };
                 if (row == 0) {                          // (cos_0, cos_{F-1}) + the vector-side sin rows
                     Pb[t] = logmag(v0, sd[col]);
                     Pb[(size_t)(p.F - 1) * p.Tf + t] = logmag(v1, sd[T::BN + col]);
@@ -1250,9 +1247,17 @@ static hipError_t run_stft(const StftArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_stft_logmag(const StftArgs& a, hipStream_t s) {
+hipError_t launch_stft_logmag(const StftArgs& a_in, hipStream_t s) {
+    StftArgs a = a_in;
+    a.c1 = 0.5f * 0.69314718055994531f * a.inv_std;             // see stft_logmag (wv_dev.h)
+    a.c0 = -a.mean * a.inv_std;
     if (a.Mp % M_ALIGN || a.Mp < a.n_fft || a.n_fft < 4 || (a.n_fft & 1) || a.F != a.n_fft / 2 + 1 || !a.side)
         return hipErrorInvalidValue;
+    static const bool use_k1 = []{ const char* e = getenv("WV_STFT_K1"); return !e || atoi(e) != 0; }();
+    if (use_k1) {
+        const hipError_t e = launch_stft_k1(a, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (a.Tf <= 64) return run_stft<Tile<128, 64, 2, 2>>(a, s);
     if (a.n_fft <= 64) return run_stft<Tile<64, 128, 1, 4>>(a, s);
     // n_fft rows: pick the tile height that pads them least

@@ -45,7 +45,7 @@ struct ResBlock {
     int ks, dil1, dil2;
 };
 struct SpecLayer {
-    const float* basis_t; const float* side; int n_fft, hop, F, Mp; float mean, inv_std;
+    const float* basis_t; const float* basis_q; const float* side; int n_fft, hop, F, Mp; float mean, inv_std;
     PwWeight pw; float scale;
     const float* id_taps;      // [C][5] = (0,0,0,0,1): the spec add runs on K1 with an identity stencil
 };
@@ -260,10 +260,12 @@ std::vector<float> make_basis(int n_fft) {
 }
 
 // [2F][n_fft] reference layout -> basis_t[Kp][Mp] with column 2f = cos row f, 2f+1 = sin row f
-const float* pack_basis(Uploader& U, const std::vector<float>& basis, int n_fft, int* Mp_out, const float** side_out) {
+const float* pack_basis(Uploader& U, const std::vector<float>& basis, int n_fft, int* Mp_out, const float** side_out,
+                        const float** q_out) {
     std::vector<float> bt, side;
     wv::pack_stft_basis(basis.data(), n_fft, bt, side, Mp_out);
     *side_out = U.up(side);
+    *q_out = U.up(wv::pack_stft_q(bt, n_fft, *Mp_out));
     return U.up(bt);
 }
 
@@ -310,7 +312,7 @@ int pack_model(wv_model* m) {
         sp.n_fft = mult * c.n_fft_base; sp.hop = stride; sp.F = sp.n_fft / 2 + 1;
         auto ov = m->stft_override.find(pre + ".spec.weight");
         sp.basis_t = pack_basis(U, ov != m->stft_override.end() ? ov->second : make_basis(sp.n_fft),
-                                sp.n_fft, &sp.Mp, &sp.side);
+                                sp.n_fft, &sp.Mp, &sp.side, &sp.basis_q);
         const int mi = post ? WV_MAX_STRIDES : s;                           // spec_post uses [-1]
         sp.mean = post ? c.spec_means[WV_MAX_STRIDES] : c.spec_means[s];
         sp.inv_std = 1.f / (post ? c.spec_stds[WV_MAX_STRIDES] : c.spec_stds[s]);
@@ -592,7 +594,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         wv::prof::set_role("enc.spec");
         const SpecLayer& sp = m->specs[s];
         wv::StftArgs sa{};
-        sa.wav = x; sa.basis_t = sp.basis_t; sa.side = sp.side; sa.P = P; sa.B = B; sa.T = T;
+        sa.wav = x; sa.basis_t = sp.basis_t; sa.basis_q = sp.basis_q; sa.side = sp.side; sa.P = P; sa.B = B; sa.T = T;
         sa.Tf = (T + sp.hop - 1) / sp.hop; sa.n_fft = sp.n_fft; sa.hop = sp.hop; sa.F = sp.F; sa.Mp = sp.Mp;
         sa.mean = sp.mean; sa.inv_std = sp.inv_std;
         if (sa.Tf != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");

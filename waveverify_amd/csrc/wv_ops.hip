@@ -154,7 +154,7 @@ int wv_op_stft_logmag(const float* wav, const float* host_basis, float* P, int B
     wv::pack_stft_basis(basis.data(), n_fft, bt, side, &Mp);
     Tmp t;
     wv::StftArgs a{};
-    a.wav = wav; a.basis_t = t.upv(bt); a.side = t.upv(side); a.P = P; a.B = B; a.T = T; a.Tf = (T + hop - 1) / hop;
+    a.wav = wav; a.basis_t = t.upv(bt); a.basis_q = t.upv(wv::pack_stft_q(bt, n_fft, Mp)); a.side = t.upv(side); a.P = P; a.B = B; a.T = T; a.Tf = (T + hop - 1) / hop;
     a.n_fft = n_fft; a.hop = hop; a.F = F; a.Mp = Mp; a.mean = mean; a.inv_std = 1.f / std;
     return done(t, wv::launch_stft_logmag(a, (hipStream_t)stream), (hipStream_t)stream);
 }
