@@ -236,10 +236,21 @@ def main():
             return round(pmc["kernels"][kernel]["traffic_bytes_per_launch"] / 1e9, 3)
         return None
 
-    roofline = dict(bound="mfma", kernel=dom_name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                    unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic_of(dom_name),
+    # which roof bounds the dominant kernel: its algorithmic arithmetic intensity against the f32-matrix ridge
+    dom_ai = dom["flops"] / max(dom["bytes"], 1.0)
+    ridge = PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)          # 19.7 FLOP/B
+    gbs_dom = dom["bytes"] / dom["launches"] / dom_avg_s / 1e9
+    if dom_ai >= ridge:
+        roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4))
+    else:
+        roof = dict(bound="hbm", achieved=round(gbs_dom, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                    frac=round(gbs_dom / PEAK_HBM_GBS, 4))
+    roofline = dict(kernel=dom_name, **roof, traffic=traffic_of(dom_name),
                     traffic_source=("profiles/r02_pmc_traffic.json: GB per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, "
                                     "separate rocprofv3 --pmc passes over this command") if traffic_of(dom_name) else None,
+                    arithmetic_intensity_flop_per_byte=round(dom_ai, 1), ridge_flop_per_byte=round(ridge, 1),
+                    tflops=round(ach, 2), hbm_gbs=round(gbs_dom, 1),
                     algorithmic_gb_per_launch=round(dom["bytes"] / dom["launches"] / 1e9, 3),
                     avg_launch_us=round(dom_avg_s * 1e6, 1), launches_per_step=dom["launches"] // a.steps,
                     share_of_kernel_time=round(dom["ms"] / total_ms, 3),

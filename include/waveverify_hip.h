@@ -222,6 +222,34 @@ int wv_train_half_backward(wv_train_half* h, const float* x, const float* g_pw, 
                            int B, int T, void* workspace, size_t workspace_bytes, void* stream);
 const char* wv_train_last_error(void);
 
+/* ---- temporal augmentations of the training step ------------------------------------
+ * One bandwidth-bound pass that replaces the reference's per-clip / per-segment Python loops and its GPU->CPU->GPU
+ * hop (model/watermarking.py:487-519,540).  All pointers are DEVICE pointers, tensors [B,C,T] contiguous f32.
+ *
+ * wv_aug_localize_sequence = LocalizationAugmentation.forward (utils/localization_augmentation.py:212-321) followed
+ * by SequenceAugmentation.forward (utils/seq_augmentation.py:100-273), i.e. AudioWatermarking._apply_augmentations:
+ *   plan  int32 [B][nseg], nseg = ceil(T / seg_len): what happens to segment s of clip b --
+ *         0 keep | 1 revert to the original | 2 replace by zeros | 3 + j substitute clip j's ORIGINAL (0 <= j < B);
+ *         NULL = no localisation augmentation.  The host draws it (waveverify_amd/augment.py, same RNG call order
+ *         as the reference) and validates j.
+ *   seq_* the sequence map applied afterwards (WV_SEQ_*); out[t] = in[src(t)] for all three outputs:
+ *         REVERSE: torch.flip;  ROLL: torch.roll(shifts = seq_a), 0 < seq_a < T;
+ *         PERMUTE: segments of seq_a samples, output segment i = input segment perm[i] (device int32, T_out / seq_a
+ *                  entries, the caller validates the range); T_out = n_segments * seq_a <= T (the reference drops the tail);
+ *         CHUNK_SWAP: chunks [seq_a, seq_a + seq_c) and [seq_b, seq_b + seq_c) exchanged (non-overlapping).
+ *   outputs: wm_out (augmented watermarked), orig_out (updated original), mask_out (1 = watermark present), [B,C,T_out].
+ * wv_aug_sequence applies only the sequence map to up to three [rows,T] tensors (NULL inputs are skipped). */
+#define WV_SEQ_IDENTITY 0
+#define WV_SEQ_REVERSE 1
+#define WV_SEQ_ROLL 2
+#define WV_SEQ_PERMUTE 3
+#define WV_SEQ_CHUNK_SWAP 4
+int wv_aug_localize_sequence(const float* original, const float* watermarked, const int* plan, int nseg, int seg_len,
+                             int seq_mode, int seq_a, int seq_b, int seq_c, const int* perm,
+                             float* wm_out, float* orig_out, float* mask_out, int B, int C, int T, int T_out, void* stream);
+int wv_aug_sequence(const float* in0, const float* in1, const float* in2, float* out0, float* out1, float* out2,
+                    int seq_mode, int seq_a, int seq_b, int seq_c, const int* perm, int rows, int T, int T_out, void* stream);
+
 /* ---- measurement hook (bench.py's roofline figures) ---------------------------------------
  * When enabled, every kernel launch is bracketed by a hipEvent pair on the launch stream and
  * aggregated by "<kernel>|<role>" together with its ALGORITHMIC flops and bytes (the per-unit

@@ -55,6 +55,10 @@ SIGNATURES = {
     "wv_encoder_forward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_int, _VP,
                                      C.c_size_t, _VP]),
     "wv_model_film": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP]),
+    "wv_aug_localize_sequence": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP,
+                                           _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
+    "wv_aug_sequence": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP,
+                                  C.c_int, C.c_int, C.c_int, _VP]),
     "wv_profile_enable": (C.c_int, [C.c_int]),
     "wv_profile_reset": (C.c_int, []),
     "wv_profile_collect": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
