@@ -220,6 +220,31 @@ int wv_train_half_backward(wv_train_half* h, const float* x, const float* g_pw, 
                            const float* g_dw, const float* v_dw, float pre_scale, const float* dy,
                            float* dx, float* dg_pw, float* dv_pw, float* dg_dw, float* dv_dw, float* db,
                            int B, int T, void* workspace, size_t workspace_bytes, void* stream);
+/* Whole SEANetResnetBlock with live weight norm (modules/seanet.py:245-281, identity shortcut):
+ *     y = x + s * half2(half1(pre_scale * x)),   s = res_scale * res_scale_param[0]  (res_scale_param may be NULL: s = res_scale)
+ * forward keeps the two intermediate activations in `saved` (wv_train_block_saved_bytes) for backward, which returns
+ * dx, both halves' parameter gradients and d(res_scale_param).  Same shape limits as the half. */
+typedef struct wv_train_block wv_train_block;
+typedef struct { const float *g_pw, *v_pw, *g_dw, *v_dw, *bias; } wv_half_params;     /* device pointers */
+typedef struct { float *dg_pw, *dv_pw, *dg_dw, *dv_dw, *db; } wv_half_grads;          /* device pointers */
+int wv_train_block_create(int C, wv_train_block** out);
+void wv_train_block_destroy(wv_train_block* b);
+size_t wv_train_block_saved_bytes(const wv_train_block* b, int B, int T);
+size_t wv_train_block_workspace_bytes(const wv_train_block* b, int B, int T);       /* backward only */
+int wv_train_block_forward(wv_train_block* b, const float* x, const wv_half_params* p /*[2]*/, const float* res_scale_param,
+                           float pre_scale, float res_scale, float* y, void* saved, size_t saved_bytes, int B, int T, void* stream);
+int wv_train_block_backward(wv_train_block* b, const float* x, const wv_half_params* p /*[2]*/, const float* res_scale_param,
+                            float pre_scale, float res_scale, const float* dy, const void* saved, float* dx,
+                            const wv_half_grads* g /*[2]*/, float* d_res_scale_param, int B, int T,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* The two BCE-with-logits losses of the training step (scripts/loss.py:947-1099), forward + gradient in one pass:
+ *   LocalizationLoss: msg = NULL, Cz = 1:  mean BCE(logits[B,1,T], mask[B,1,T])
+ *   DecodingLoss:     mean BCE(logits[B,Cz,T], msg[B,Cz] * mask[B,1,T])        (mask NULL = all ones)
+ * loss: one device float; dlogits (optional, [B,Cz,T]) = grad_scale * dLoss/dlogits.  Fixed-order two-stage sum. */
+size_t wv_train_bce_workspace_bytes(void);
+int wv_train_bce_logits(const float* logits, const float* mask, const float* msg, float* loss, float* dlogits, float grad_scale,
+                        int B, int Cz, int T, void* workspace, size_t workspace_bytes, void* stream);
 const char* wv_train_last_error(void);
 
 /* ---- temporal augmentations of the training step ------------------------------------

@@ -60,3 +60,34 @@ def half_backward(x, s, g_pw, v_pw, g_dw, v_dw, b, dy):
     dg_pw, dv_pw = fold_backward(g_pw.astype(np.float64), v_pw.astype(np.float64), dW[:, :, None])
     dg_dw, dv_dw = fold_backward(g_dw.astype(np.float64), v_dw.astype(np.float64), dw[:, None, :])
     return dict(y=y, dx=dx, dg_pw=dg_pw, dv_pw=dv_pw, dg_dw=dg_dw, dv_dw=dv_dw, db_dw=db)
+
+
+def block_forward(x, ps, res_scale_param, pre_scale, res_scale):
+    """Whole SEANetResnetBlock, identity shortcut (seanet.py:245-281): y = x + s * half2(half1(pre_scale * x)),
+    s = res_scale * res_scale_param (or res_scale).  ps = two dicts (g_pw, v_pw, g_dw, v_dw, b_dw)."""
+    u, _ = half_forward(x, pre_scale, ps[0]["g_pw"], ps[0]["v_pw"], ps[0]["g_dw"], ps[0]["v_dw"], ps[0]["b_dw"])
+    v, _ = half_forward(u, 1.0, ps[1]["g_pw"], ps[1]["v_pw"], ps[1]["g_dw"], ps[1]["v_dw"], ps[1]["b_dw"])
+    s = res_scale * (1.0 if res_scale_param is None else float(np.asarray(res_scale_param).reshape(-1)[0]))
+    return x.astype(np.float64) + s * v, (u, v, s)
+
+
+def block_backward(x, ps, res_scale_param, pre_scale, res_scale, dy):
+    """-> dict(y, dx, halves=[grads of half 1, grads of half 2], d_res_scale_param) in float64."""
+    y, (u, v, s) = block_forward(x, ps, res_scale_param, pre_scale, res_scale)
+    dy = dy.astype(np.float64)
+    g2 = half_backward(u, 1.0, ps[1]["g_pw"], ps[1]["v_pw"], ps[1]["g_dw"], ps[1]["v_dw"], ps[1]["b_dw"], s * dy)
+    g1 = half_backward(x, pre_scale, ps[0]["g_pw"], ps[0]["v_pw"], ps[0]["g_dw"], ps[0]["v_dw"], ps[0]["b_dw"], g2["dx"])
+    return dict(y=y, dx=g1["dx"] + dy, halves=[g1, g2], d_res_scale_param=res_scale * float((dy * v).sum()))
+
+
+def bce_logits(z, mask=None, msg=None):
+    """LocalizationLoss / DecodingLoss (scripts/loss.py:947-1099): mean BCE-with-logits against
+    y[b,c,t] = (msg[b,c] or 1) * (mask[b,0,t] or 1) -> (loss, dloss/dz) in float64."""
+    z = z.astype(np.float64)
+    y = np.ones_like(z)
+    if mask is not None:
+        y = y * mask.astype(np.float64)
+    if msg is not None:
+        y = y * msg.astype(np.float64)[:, :, None]
+    loss = np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))
+    return loss.mean(), (1.0 / (1.0 + np.exp(-z)) - y) / z.size

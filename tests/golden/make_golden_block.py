@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/grads_block_*.npz and tests/golden/bce_losses.npz from the REFERENCE (build container only):
+
+* forward + backward of whole SEANetResnetBlock modules (/root/reference/modules/seanet.py:123-281: identity
+  shortcut, pre_scale from idx, res_scale and the trainable res_scale_param of zero_init blocks) through the
+  reference's CPU autograd, in float64 (res_scale is always set, as in the shipped configurations: with res_scale=None
+  the block's first in-place ELU would overwrite the tensor its identity shortcut aliases);
+* LocalizationLoss / DecodingLoss (/root/reference/scripts/loss.py:947-1099) values and input gradients.  loss.py
+  imports audiotools at module level (absent, unused by these two classes): loaded by path with an empty stand-in.
+
+Only data is written.  Usage (from repo root):  python tests/golden/make_golden_block.py"""
+import importlib.util
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+SHORT = {"1.conv.conv.parametrizations.weight.original0": "g_pw", "1.conv.conv.parametrizations.weight.original1": "v_pw",
+         "2.conv.conv.parametrizations.weight.original0": "g_dw", "2.conv.conv.parametrizations.weight.original1": "v_dw",
+         "2.conv.conv.bias": "b_dw"}
+SHORT2 = {k.replace("1.", "4.", 1).replace("2.conv", "5.conv"): v for k, v in SHORT.items()}
+
+
+def main():
+    import torch
+    sys.dont_write_bytecode = True
+    logging.disable(logging.CRITICAL)
+    sys.path.insert(0, REF)
+    from modules.seanet import SEANetResnetBlock
+    torch.set_num_threads(4)
+    for tag, (B, C, T, res_scale, idx, zero_init) in {"small": (3, 40, 36, 0.5773503, 1, True), "c64": (2, 64, 200, 0.5, 2, True),
+                                                       "c96": (2, 96, 132, 0.7071068, 0, False), "c160": (1, 160, 64, 0.4472136, 3, True)}.items():
+        rng = np.random.default_rng(C + T)
+        blk = SEANetResnetBlock(C, kernel_size=5, dilations=[1, 1], skip="identity", causal=True, res_scale=res_scale, idx=idx,
+                                zero_init=zero_init).double()
+        sd = {}
+        for k, v in blk.state_dict().items():
+            a = rng.standard_normal(tuple(v.shape))
+            if k.endswith("original0"):
+                a = 0.5 + np.abs(a)
+            elif k.endswith("original1"):
+                a = a * (1.0 / np.sqrt(np.prod(v.shape[1:])))
+            elif k == "res_scale_param":
+                a = 0.7 + 0.2 * a
+            else:
+                a = a * 0.1
+            sd[k] = torch.from_numpy(a.astype(np.float32)).double()
+        blk.load_state_dict(sd)
+        x = torch.from_numpy(rng.standard_normal((B, C, T)).astype(np.float32)).double().requires_grad_(True)
+        dy = torch.from_numpy(rng.standard_normal((B, C, T)).astype(np.float32)).double()
+        y = blk(x * 1.0)          # (the block's first ELU is in-place: give it a non-leaf tensor)
+        y.backward(dy)
+        out = dict(x=x.detach().numpy().astype(np.float32), dy=dy.numpy().astype(np.float32), y=y.detach().numpy().astype(np.float32),
+                   dx=x.grad.numpy().astype(np.float32), pre_scale=np.float32(blk.pre_scale if blk.pre_scale is not None else 1.0),
+                   res_scale=np.float32(1.0 if res_scale is None else res_scale))
+        for name, p in blk.named_parameters():
+            if name == "res_scale_param":
+                out["res_scale_param"], out["d_res_scale_param"] = p.detach().numpy().astype(np.float32), p.grad.numpy().astype(np.float32)
+                continue
+            key = name[len("block."):]
+            half, short = (1, SHORT[key]) if key in SHORT else (2, SHORT2[key])
+            out[f"h{half}_{short}"] = p.detach().numpy().astype(np.float32)
+            out[f"h{half}_d{short}"] = p.grad.numpy().astype(np.float32)
+        path = os.path.join(HERE, f"grads_block_{tag}.npz")
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}: B={B} C={C} T={T} pre_scale={float(out['pre_scale']):.4f} keys={len(out)}")
+
+    # ---- losses ----------------------------------------------------------------------------------------------------
+    sys.modules["audiotools"] = types.ModuleType("audiotools")
+    sys.modules["audiotools"].AudioSignal = type("AudioSignal", (), {})
+    sys.modules["audiotools"].STFTParams = type("STFTParams", (), {})
+    spec = importlib.util.spec_from_file_location("ref_loss", f"{REF}/scripts/loss.py")
+    L = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(L)
+    rng = np.random.default_rng(7)
+    out = {}
+    for i, (B, nb, T) in enumerate(((2, 16, 400), (3, 16, 37), (1, 8, 1), (4, 16, 301))):
+        z = torch.from_numpy((3.0 * rng.standard_normal((B, nb, T))).astype(np.float32)).requires_grad_(True)
+        zl = torch.from_numpy((3.0 * rng.standard_normal((B, 1, T))).astype(np.float32)).requires_grad_(True)
+        if i == 0:
+            with torch.no_grad():
+                z[0, 0, :4] = torch.tensor([60.0, -60.0, 0.0, 1e-4])          # saturated / zero logits
+        mask = torch.from_numpy((rng.random((B, 1, T)) < 0.7).astype(np.float32))
+        msg = torch.from_numpy(rng.integers(0, 2, (B, nb)).astype(np.float32))
+        ld = L.DecodingLoss()(z, mask, msg)
+        ld.backward()
+        ll = L.LocalizationLoss()(zl, mask)
+        ll.backward()
+        for k, v in dict(z=z, zl=zl, mask=mask, msg=msg, dec=ld, loc=ll, dz=z.grad, dzl=zl.grad).items():
+            out[f"c{i}_{k}"] = v.detach().numpy().astype(np.float32) if v.dim() else np.float64(float(v))
+    np.savez_compressed(os.path.join(HERE, "bce_losses.npz"), **out)
+    print("wrote bce_losses.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -69,3 +69,101 @@ def test_training_slice_rejects_unsupported_shapes():
              v_dw=torch.randn(64, 5, device="cuda"), b_dw=torch.zeros(64, device="cuda"))
     with pytest.raises(RuntimeError, match="T % 4"):
         half.forward(x, p, 1.0)
+
+
+# ---- whole SEANetResnetBlock ----------------------------------------------------------------------------------------
+def _cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_block(x, ps, rsp, pre, rs, dy):
+    from waveverify_amd.train import TrainBlock
+    blk = TrainBlock(x.shape[1])
+    pt = [{k: _cu(v) for k, v in p.items()} for p in ps]
+    rt = None if rsp is None else _cu(rsp)
+    y, saved = blk.forward(_cu(x), pt, rt, pre, rs)
+    g = blk.backward(_cu(x), pt, rt, pre, rs, _cu(dy), saved)
+    g2 = blk.backward(_cu(x), pt, rt, pre, rs, _cu(dy), saved)
+    assert torch.equal(g["dx"], g2["dx"]) and all(torch.equal(g["halves"][i][k], g2["halves"][i][k]) for i in (0, 1) for k in KEYS[1:])
+    if rsp is not None:
+        assert torch.equal(g["d_res_scale_param"], g2["d_res_scale_param"])
+    return y, g
+
+
+@pytest.mark.parametrize("tag", ["small", "c64", "c96", "c160"])
+def test_block_gradients_vs_reference_autograd(golden_dir, tag):
+    f = np.load(os.path.join(golden_dir, f"grads_block_{tag}.npz"))
+    ps = [{k: f[f"h{i}_{k}"] for k in ("g_pw", "v_pw", "g_dw", "v_dw", "b_dw")} for i in (1, 2)]
+    rsp = f["res_scale_param"] if "res_scale_param" in f else None
+    y, g = run_block(f["x"], ps, rsp, float(f["pre_scale"]), float(f["res_scale"]), f["dy"])
+    assert rel(y, f["y"]) <= 2e-5 and rel(g["dx"], f["dx"]) <= 1e-4
+    for i in (1, 2):
+        for k in KEYS[1:]:
+            assert rel(g["halves"][i - 1][k], f[f"h{i}_{k}"]) <= 1e-4, (i, k)
+    if rsp is not None:
+        ref = float(f["d_res_scale_param"][0])
+        assert abs(float(g["d_res_scale_param"].item()) - ref) <= 1e-4 * max(1.0, abs(ref))
+
+
+@pytest.mark.parametrize("B,C,T,with_param", [(4, 128, 1000, True), (2, 64, 16000, False), (3, 192, 400, True)])
+def test_block_gradients_vs_oracle(B, C, T, with_param):
+    rng = np.random.default_rng(B * 77 + C + T)
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    dy = rng.standard_normal((B, C, T)).astype(np.float32)
+    ps = [dict(g_pw=(0.5 + np.abs(rng.standard_normal((C, 1, 1)))).astype(np.float32),
+               v_pw=(rng.standard_normal((C, C, 1)) * C ** -0.5).astype(np.float32),
+               g_dw=(0.5 + np.abs(rng.standard_normal((C, 1, 1)))).astype(np.float32),
+               v_dw=(rng.standard_normal((C, 1, 5)) * 0.45).astype(np.float32),
+               b_dw=(rng.standard_normal(C) * 0.1).astype(np.float32)) for _ in range(2)]
+    rsp = np.array([0.8], np.float32) if with_param else None
+    pre, rs = 0.8164966, 0.5773503
+    ref = OT.block_backward(x, ps, rsp, pre, rs, dy)
+    y, g = run_block(x, ps, rsp, pre, rs, dy)
+    assert rel(y, ref["y"]) <= 2e-5 and rel(g["dx"], ref["dx"]) <= 1e-4
+    for i in (0, 1):
+        for k in KEYS[1:]:
+            assert rel(g["halves"][i][k], ref["halves"][i][k]) <= 1e-4, (i, k)
+    if with_param:
+        assert abs(float(g["d_res_scale_param"].item()) - ref["d_res_scale_param"]) <= 1e-4 * max(1.0, abs(ref["d_res_scale_param"]))
+
+
+# ---- BCE losses ---------------------------------------------------------------------------------------------------------
+def test_bce_losses_vs_reference_classes(golden_dir):
+    from waveverify_amd.train import bce_logits
+    f = np.load(os.path.join(golden_dir, "bce_losses.npz"))
+    for i in range(4):
+        z, zl, mask, msg = (_cu(f[f"c{i}_{k}"]) for k in ("z", "zl", "mask", "msg"))
+        ld, dz = bce_logits(z, mask, msg)
+        ll, dzl = bce_logits(zl, mask, None)
+        assert abs(float(ld.item()) - float(f[f"c{i}_dec"])) <= 2e-6 * abs(float(f[f"c{i}_dec"]))
+        assert abs(float(ll.item()) - float(f[f"c{i}_loc"])) <= 2e-6 * abs(float(f[f"c{i}_loc"]))
+        n, nl = z.numel(), zl.numel()
+        assert float((dz.cpu() - torch.from_numpy(f[f"c{i}_dz"])).abs().max()) <= 2e-7 / n * max(1.0, n ** 0.5) + 1e-7 / n
+        assert float((dzl.cpu() - torch.from_numpy(f[f"c{i}_dzl"])).abs().max()) <= 2e-7 / nl * max(1.0, nl ** 0.5) + 1e-7 / nl
+        l2, dz2 = bce_logits(z, mask, msg)
+        assert torch.equal(ld, l2) and torch.equal(dz, dz2)                    # fixed-order reduction
+
+
+def test_bce_at_training_size_vs_oracle_and_errors():
+    """64 clips x 16 bits x 16000 samples (BASELINE configs[2] per-GPU batch): loss and gradient against the float64
+    oracle; grad_scale scales the gradient only; shape errors are ValueError as in the reference."""
+    from waveverify_amd.train import bce_logits
+    rng = np.random.default_rng(5)
+    B, nb, T = 64, 16, 16000
+    z = (2.0 * rng.standard_normal((B, nb, T))).astype(np.float32)
+    mask = (rng.random((B, 1, T)) < 0.8).astype(np.float32)
+    msg = rng.integers(0, 2, (B, nb)).astype(np.float32)
+    ref_l, ref_g = OT.bce_logits(z, mask, msg)
+    l, dz = bce_logits(_cu(z), _cu(mask), _cu(msg), grad_scale=3.0)
+    assert abs(float(l.item()) - ref_l) <= 2e-6 * ref_l
+    assert float(np.abs(dz.cpu().numpy() / 3.0 - ref_g).max()) <= 2e-7 / z.size
+    l0, none = bce_logits(_cu(z), None, _cu(msg), want_grad=False)
+    assert none is None and abs(float(l0.item()) - OT.bce_logits(z, None, msg)[0]) <= 2e-6 * ref_l
+    with pytest.raises(ValueError, match="3D"):
+        bce_logits(_cu(z[0]), None, None)
+    with pytest.raises(ValueError, match="ground_truth_message"):
+        bce_logits(_cu(z), _cu(mask), _cu(msg[:, :8]))
+    with pytest.raises(ValueError, match="ground_truth_presence"):
+        bce_logits(_cu(z), _cu(mask[:, :, :100]), _cu(msg))
+    with pytest.raises(ValueError, match="same shape"):
+        bce_logits(_cu(z), _cu(mask), None)

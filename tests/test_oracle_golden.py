@@ -215,3 +215,35 @@ def test_training_half_oracle_vs_reference_autograd(golden_dir, tag):
         ref = g[k]
         err = np.abs(out[k].reshape(ref.shape) - ref).max() / max(1.0, np.abs(ref).max())
         assert err <= 2e-6, (k, err)
+
+
+# ---- training slice: whole block and the BCE losses vs the reference's autograd ---------------------------------
+def _block_params(g):
+    return [{k: g[f"h{i}_{k}"] for k in ("g_pw", "v_pw", "g_dw", "v_dw", "b_dw")} for i in (1, 2)]
+
+
+@pytest.mark.parametrize("tag", ["small", "c64", "c96", "c160"])
+def test_train_oracle_block_vs_reference_autograd(golden_dir, tag):
+    from oracle import wv_oracle_train as OT
+    g = np.load(os.path.join(golden_dir, f"grads_block_{tag}.npz"))
+    rsp = g["res_scale_param"] if "res_scale_param" in g else None
+    r = OT.block_backward(g["x"], _block_params(g), rsp, float(g["pre_scale"]), float(g["res_scale"]), g["dy"])
+
+    def rel(a, b):
+        return float(np.abs(a.reshape(b.shape) - b).max() / max(np.abs(b).max(), 1e-30))
+    assert rel(r["y"], g["y"]) <= 2e-6 and rel(r["dx"], g["dx"]) <= 2e-6
+    for i in (1, 2):
+        for k in ("g_pw", "v_pw", "g_dw", "v_dw", "b_dw"):
+            assert rel(r["halves"][i - 1]["d" + k], g[f"h{i}_d{k}"]) <= 2e-6, (i, k)
+    if rsp is not None:
+        assert abs(r["d_res_scale_param"] - float(g["d_res_scale_param"][0])) <= 2e-6 * abs(float(g["d_res_scale_param"][0]))
+
+
+def test_train_oracle_bce_vs_reference_losses(golden_dir):
+    from oracle import wv_oracle_train as OT
+    g = np.load(os.path.join(golden_dir, "bce_losses.npz"))
+    for i in range(4):
+        ld, dz = OT.bce_logits(g[f"c{i}_z"], g[f"c{i}_mask"], g[f"c{i}_msg"])
+        ll, dzl = OT.bce_logits(g[f"c{i}_zl"], g[f"c{i}_mask"], None)
+        assert abs(ld - float(g[f"c{i}_dec"])) <= 2e-6 * abs(ld) and abs(ll - float(g[f"c{i}_loc"])) <= 2e-6 * abs(ll)
+        assert np.abs(dz - g[f"c{i}_dz"]).max() <= 1e-6 / dz.size ** 0.5 and np.abs(dzl - g[f"c{i}_dzl"]).max() <= 1e-6 / dzl.size ** 0.5

@@ -55,6 +55,15 @@ SIGNATURES = {
     "wv_encoder_forward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_int, _VP,
                                      C.c_size_t, _VP]),
     "wv_model_film": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP]),
+    "wv_train_block_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
+    "wv_train_block_destroy": (None, [_VP]),
+    "wv_train_block_saved_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),
+    "wv_train_block_workspace_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),
+    "wv_train_block_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, C.c_size_t, C.c_int, C.c_int, _VP]),
+    "wv_train_block_backward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int,
+                                          _VP, C.c_size_t, _VP]),
+    "wv_train_bce_workspace_bytes": (C.c_size_t, []),
+    "wv_train_bce_logits": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_float, C.c_int, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     "wv_aug_localize_sequence": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP,
                                            _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "wv_aug_sequence": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP,

@@ -194,6 +194,79 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     }
 }
 
+// ---- residual block glue: y = x + s * v;  dv = s * dy and sum(dy * v);  dx += dy ---------------------------------
+// s = res_scale * (*param) when the block carries the trainable res_scale_param (seanet.py:237-241,271-275), else res_scale
+__device__ __forceinline__ float res_s(const float* param, float res_scale) { return param ? res_scale * param[0] : res_scale; }
+
+__global__ __launch_bounds__(256) void axpy_res_kernel(const float4* __restrict__ x, const float4* __restrict__ v, float4* __restrict__ y,
+                                                        const float* __restrict__ param, float res_scale, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float s = res_s(param, res_scale);
+    const float4 a = x[i], b = v[i];
+    y[i] = make_float4(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z), fmaf(b.w, s, a.w));   // y.mul_(scale).add_(shortcut)
+}
+
+constexpr int RED_BLOCKS = 1024;        // fixed grid of the two-stage reductions: the sum order never depends on the device
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return threadIdx.x == 0 ? (sh[0] + sh[1]) + (sh[2] + sh[3]) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void scale_dot_kernel(const float4* __restrict__ dy, const float4* __restrict__ v, float4* __restrict__ dv,
+                                                         const float* __restrict__ param, float res_scale, float* __restrict__ partial, size_t n4) {
+    __shared__ float sh[4];
+    const float s = res_s(param, res_scale);
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)RED_BLOCKS * 256) {
+        const float4 g = dy[i], b = v[i];
+        dv[i] = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+        acc += (g.x * b.x + g.y * b.y) + (g.z * b.z + g.w * b.w);
+    }
+    const float t = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ void finish_sum_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
+    if (threadIdx.x || blockIdx.x) return;
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) a += (double)partial[i];
+    out[0] = (float)(a * (double)scale);
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float4* __restrict__ dx, const float4* __restrict__ dy, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 a = dx[i], b = dy[i];
+    dx[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// ---- BCE-with-logits losses of the training step (scripts/loss.py:947-1099) -----------------------------------------
+//   LocalizationLoss: mean BCE(z[B,1,T], mask[B,1,T]);  DecodingLoss: mean BCE(z[B,nb,T], msg[B,nb] * mask[B,1,T]).
+// One pass gives the loss partials and dL/dz = grad_scale * (sigmoid(z) - y) / N.  The loss term is torch's stable
+// form max(z,0) - z*y + log1p(exp(-|z|)).
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ z, const float* __restrict__ mask, const float* __restrict__ msg,
+                                                   float* __restrict__ dz, float* __restrict__ partial, float gscale, int Cz, int T, size_t n) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)RED_BLOCKS * 256) {
+        const size_t bc = i / T;
+        const int t = (int)(i - bc * T);
+        const size_t b = bc / Cz;
+        float y = mask ? mask[b * T + t] : 1.f;
+        if (msg) y *= msg[bc];
+        const float v = z[i];
+        acc += fmaxf(v, 0.f) - v * y + log1pf(expf(-fabsf(v)));
+        if (dz) dz[i] = (1.f / (1.f + expf(-v)) - y) * gscale;
+    }
+    const float t = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
 }  // namespace wv
 
 // ================================================================================================ C ABI
@@ -324,6 +397,96 @@ int wv_train_half_backward(wv_train_half* h, const float* x, const float* g_pw, 
     hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((C + 63) / 64, (C + 63) / 64, S), dim3(256), 0, s, DH, x, parts, pre_scale, B, C, C, T);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)C * C + 255) / 256)), dim3(256), 0, s, parts, h->dW, S, (size_t)C * C);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, C);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+// ---- whole SEANetResnetBlock: y = x + s * half2(half1(pre_scale * x)) (seanet.py:245-281) ------------------------------
+struct wv_train_block {
+    wv_train_half* h[2] = {nullptr, nullptr};
+    float* partial = nullptr;
+    ~wv_train_block() { delete h[0]; delete h[1]; if (partial) (void)hipFree(partial); }
+};
+
+int wv_train_block_create(int C, wv_train_block** out) {
+    if (!out) return tfail(WV_EINVAL, "null argument");
+    auto* b = new wv_train_block();
+    int rc = wv_train_half_create(C, &b->h[0]);
+    if (!rc) rc = wv_train_half_create(C, &b->h[1]);
+    if (!rc && hipMalloc((void**)&b->partial, wv::RED_BLOCKS * sizeof(float)) != hipSuccess) rc = tfail(WV_EHIP, "device allocation failed");
+    if (rc) { delete b; return rc; }
+    *out = b;
+    return WV_OK;
+}
+
+void wv_train_block_destroy(wv_train_block* b) { delete b; }
+
+size_t wv_train_block_saved_bytes(const wv_train_block* b, int B, int T) {
+    return (b && B > 0 && T > 0) ? 2 * al256((size_t)B * b->h[0]->C * T * 4) : 0;
+}
+
+size_t wv_train_block_workspace_bytes(const wv_train_block* b, int B, int T) {
+    if (!b || B < 1 || T < 1) return 0;
+    return wv_train_half_workspace_bytes(b->h[0], B, T) + 2 * al256((size_t)B * b->h[0]->C * T * 4);
+}
+
+int wv_train_block_forward(wv_train_block* b, const float* x, const wv_half_params* p, const float* res_scale_param,
+                           float pre_scale, float res_scale, float* y, void* saved, size_t saved_bytes, int B, int T, void* stream) {
+    if (!b || !x || !p || !y || !saved) return tfail(WV_EINVAL, "null argument");
+    if (B < 1 || T < 1 || (T & 3) || saved_bytes < wv_train_block_saved_bytes(b, B, T)) return tfail(WV_ENOMEM, "saved-activation buffer too small (or T % 4 != 0)");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t act = al256((size_t)B * b->h[0]->C * T * 4);
+    float* u = (float*)saved; float* v = (float*)((char*)saved + act);
+    int rc = wv_train_half_forward(b->h[0], x, p[0].g_pw, p[0].v_pw, p[0].g_dw, p[0].v_dw, p[0].bias, pre_scale, u, B, T, stream);
+    if (!rc) rc = wv_train_half_forward(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, p[1].bias, 1.f, v, B, T, stream);
+    if (rc) return rc;
+    const size_t n4 = (size_t)B * b->h[0]->C * T / 4;
+    hipLaunchKernelGGL(wv::axpy_res_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float4*)x, (const float4*)v, (float4*)y,
+                       res_scale_param, res_scale, n4);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+int wv_train_block_backward(wv_train_block* b, const float* x, const wv_half_params* p, const float* res_scale_param,
+                            float pre_scale, float res_scale, const float* dy, const void* saved, float* dx, const wv_half_grads* g,
+                            float* d_res_scale_param, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!b || !x || !p || !dy || !saved || !dx || !g) return tfail(WV_EINVAL, "null argument");
+    if (B < 1 || T < 1 || (T & 3) || !ws || ws_bytes < wv_train_block_workspace_bytes(b, B, T)) return tfail(WV_ENOMEM, "workspace too small (or T % 4 != 0)");
+    if (res_scale_param && !d_res_scale_param) return tfail(WV_EINVAL, "res_scale_param without a gradient slot");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = b->h[0]->C;
+    const size_t act = al256((size_t)B * C * T * 4), n4 = (size_t)B * C * T / 4;
+    const float* u = (const float*)saved; const float* v = (const float*)((const char*)saved + act);
+    float* DV = (float*)ws; float* DU = (float*)((char*)ws + act);
+    void* hws = (char*)ws + 2 * act;
+    const size_t hws_bytes = ws_bytes - 2 * act;
+    // dv = s * dy, d(res_scale_param) = res_scale * sum(dy * v)
+    hipLaunchKernelGGL(wv::scale_dot_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, (const float4*)dy, (const float4*)v, (float4*)DV,
+                       res_scale_param, res_scale, b->partial, n4);
+    if (d_res_scale_param) hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, b->partial, wv::RED_BLOCKS, res_scale, d_res_scale_param);
+    T_LAUNCH(hipGetLastError());
+    int rc = wv_train_half_backward(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, 1.f, DV, DU, g[1].dg_pw, g[1].dv_pw,
+                                    g[1].dg_dw, g[1].dv_dw, g[1].db, B, T, hws, hws_bytes, stream);
+    if (!rc) rc = wv_train_half_backward(b->h[0], x, p[0].g_pw, p[0].v_pw, p[0].g_dw, p[0].v_dw, pre_scale, DU, dx, g[0].dg_pw, g[0].dv_pw,
+                                         g[0].dg_dw, g[0].dv_dw, g[0].db, B, T, hws, hws_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wv::add_inplace_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (float4*)dx, (const float4*)dy, n4);   // the identity shortcut
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+// ---- BCE losses -----------------------------------------------------------------------------------------------------------
+size_t wv_train_bce_workspace_bytes(void) { return wv::RED_BLOCKS * sizeof(float); }
+
+int wv_train_bce_logits(const float* logits, const float* mask, const float* msg, float* loss, float* dlogits, float grad_scale,
+                        int B, int Cz, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!logits || !loss || B < 1 || Cz < 1 || T < 1) return tfail(WV_EINVAL, "null / bad argument");
+    if (!ws || ws_bytes < wv_train_bce_workspace_bytes()) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * Cz * T;
+    hipLaunchKernelGGL(wv::bce_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, logits, mask, msg, dlogits, (float*)ws,
+                       grad_scale / (float)n, Cz, T, n);
+    hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, wv::RED_BLOCKS, 1.f / (float)n, loss);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }

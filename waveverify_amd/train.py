@@ -1,7 +1,11 @@
-"""First slice of the training step on the GPU: one SEANetResnetBlock half with live weight
-normalisation, forward and backward, behind the C ABI (wv_train_half_*, include/waveverify_hip.h).
+"""First slices of the training step on the GPU, behind the C ABI (wv_train_*,
+include/waveverify_hip.h): a SEANetResnetBlock half and the whole block with live weight normalisation, forward and
+backward, and the two BCE-with-logits losses with their gradients.
 
     half = TrainHalf(C); y = half.forward(x, params, pre_scale); grads = half.backward(x, params, pre_scale, dy)
+    blk = TrainBlock(C); y, saved = blk.forward(x, [p1, p2], res_scale_param, pre_scale, res_scale)
+    grads = blk.backward(x, [p1, p2], res_scale_param, pre_scale, res_scale, dy, saved)
+    loss, dlogits = bce_logits(logits, mask, msg)
 
 `params` = dict(g_pw [C], v_pw [C,C], g_dw [C], v_dw [C,5], b_dw [C]) of CUDA float32 tensors -- the live layout of
 torch's weight_norm parametrization (original0 = g, original1 = v; /root/reference/modules/conv.py:47-88).
@@ -74,3 +78,105 @@ class TrainHalf:
                 self._h = C.c_void_p()
         except Exception:
             pass
+
+
+class _HalfParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("g_pw", "v_pw", "g_dw", "v_dw", "bias")]
+
+
+class _HalfGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dg_pw", "dv_pw", "dg_dw", "dv_dw", "db")]
+
+
+class TrainBlock:
+    """Whole SEANetResnetBlock (/root/reference/modules/seanet.py:245-281, identity shortcut):
+    y = x + res_scale * res_scale_param * half2(half1(pre_scale * x)); `res_scale_param` is the trainable [1]
+    tensor of zero_init blocks or None."""
+
+    def __init__(self, channels: int):
+        self._lib = _lib.load()
+        self.C = int(channels)
+        self._h = C.c_void_p()
+        if self._lib.wv_train_block_create(self.C, C.byref(self._h)) != 0:
+            raise RuntimeError(f"wv_train_block_create: {self._lib.wv_train_last_error().decode()}")
+
+    def _params(self, ps):
+        keep, arr = [], (_HalfParams * 2)()
+        for i, p in enumerate(ps):
+            t = [_f(p["g_pw"]).reshape(self.C), _f(p["v_pw"]).reshape(self.C, self.C), _f(p["g_dw"]).reshape(self.C),
+                 _f(p["v_dw"]).reshape(self.C, 5), _f(p["b_dw"]).reshape(self.C)]
+            keep.append(t)
+            arr[i] = _HalfParams(*[x.data_ptr() for x in t])
+        return arr, keep
+
+    def forward(self, x, ps, res_scale_param, pre_scale: float, res_scale: float):
+        x = _f(x)
+        B, _, T = x.shape
+        arr, keep = self._params(ps)
+        rsp = None if res_scale_param is None else _f(res_scale_param).reshape(1)
+        y = torch.empty_like(x)
+        saved = torch.empty(int(self._lib.wv_train_block_saved_bytes(self._h, B, T)), dtype=torch.uint8, device=x.device)
+        rc = self._lib.wv_train_block_forward(self._h, x.data_ptr(), arr, None if rsp is None else rsp.data_ptr(), float(pre_scale),
+                                              float(res_scale), y.data_ptr(), saved.data_ptr(), saved.numel(), B, T, TrainHalf._stream())
+        if rc != 0:
+            raise RuntimeError(f"wv_train_block_forward: {self._lib.wv_train_last_error().decode()}")
+        return y, saved
+
+    def backward(self, x, ps, res_scale_param, pre_scale: float, res_scale: float, dy, saved):
+        x, dy = _f(x), _f(dy)
+        B, _, T = x.shape
+        arr, keep = self._params(ps)
+        rsp = None if res_scale_param is None else _f(res_scale_param).reshape(1)
+        dev = x.device
+        grads, garr = [], (_HalfGrads * 2)()
+        for i in range(2):
+            g = dict(dg_pw=torch.empty(self.C, device=dev), dv_pw=torch.empty(self.C, self.C, device=dev), dg_dw=torch.empty(self.C, device=dev),
+                     dv_dw=torch.empty(self.C, 5, device=dev), db_dw=torch.empty(self.C, device=dev))
+            grads.append(g)
+            garr[i] = _HalfGrads(g["dg_pw"].data_ptr(), g["dv_pw"].data_ptr(), g["dg_dw"].data_ptr(), g["dv_dw"].data_ptr(), g["db_dw"].data_ptr())
+        dx = torch.empty_like(x)
+        drsp = None if rsp is None else torch.empty(1, device=dev)
+        ws = torch.empty(int(self._lib.wv_train_block_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=dev)
+        rc = self._lib.wv_train_block_backward(
+            self._h, x.data_ptr(), arr, None if rsp is None else rsp.data_ptr(), float(pre_scale), float(res_scale), dy.data_ptr(),
+            saved.data_ptr(), dx.data_ptr(), garr, None if drsp is None else drsp.data_ptr(), B, T, ws.data_ptr(), ws.numel(),
+            TrainHalf._stream())
+        if rc != 0:
+            raise RuntimeError(f"wv_train_block_backward: {self._lib.wv_train_last_error().decode()}")
+        return dict(dx=dx, halves=grads, d_res_scale_param=drsp)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._lib.wv_train_block_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def bce_logits(logits: torch.Tensor, mask=None, msg=None, grad_scale: float = 1.0, want_grad: bool = True):
+    """LocalizationLoss (msg None, logits [B,1,T], mask [B,1,T]) / DecodingLoss (logits [B,nb,T], msg [B,nb], mask [B,1,T])
+    of /root/reference/scripts/loss.py:947-1099 -> (loss [1] tensor, d loss / d logits * grad_scale or None).
+    Shape errors are ValueError, like the reference's."""
+    if logits.dim() != 3:
+        raise ValueError(f"detector_outputs must be 3D, got {logits.dim()}D")
+    B, Cz, T = logits.shape
+    if mask is not None and (mask.dim() != 3 or mask.shape[0] != B or mask.shape[1] != 1 or mask.shape[2] != T):
+        raise ValueError(f"ground_truth_presence must be [batch, 1, samples] = [{B}, 1, {T}], got {tuple(mask.shape)}")
+    if msg is not None and (msg.dim() != 2 or msg.shape[0] != B or msg.shape[1] != Cz):
+        raise ValueError(f"ground_truth_message must be [batch, bits] = [{B}, {Cz}], got {tuple(msg.shape)}")
+    if msg is None and Cz != 1:
+        raise ValueError("localization loss: logits and presence mask must have the same shape")
+    lib = _lib.load()
+    z = _f(logits)
+    m = None if mask is None else _f(mask)
+    g = None if msg is None else _f(msg)
+    loss = torch.empty(1, device=z.device)
+    dz = torch.empty_like(z) if want_grad else None
+    ws = torch.empty(int(lib.wv_train_bce_workspace_bytes()), dtype=torch.uint8, device=z.device)
+    rc = lib.wv_train_bce_logits(z.data_ptr(), None if m is None else m.data_ptr(), None if g is None else g.data_ptr(), loss.data_ptr(),
+                                 None if dz is None else dz.data_ptr(), float(grad_scale), B, Cz, T, ws.data_ptr(), ws.numel(),
+                                 TrainHalf._stream())
+    if rc != 0:
+        raise RuntimeError(f"wv_train_bce_logits: {lib.wv_train_last_error().decode()}")
+    return loss, dz
