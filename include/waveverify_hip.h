@@ -209,7 +209,8 @@ int wv_model_film(wv_model* m, const float* msg, int msg_rows, float* film, int 
  * g_pw [C], v_pw [C,C] (the 1x1), g_dw [C], v_dw [C,5] (the depth-wise conv), bias [C]; gradients have the
  * shapes of what they differentiate.  Needs C >= 33, T % 4 == 0, 16-byte aligned tensors.
  * The weight-norm fold runs on the device in every call (wv_train_half_forward and _backward both fold). */
-typedef struct wv_train_half wv_train_half;
+typedef struct wv_train_unit wv_train_unit;
+typedef wv_train_unit wv_train_half;
 int wv_train_half_create(int C, wv_train_half** out);
 void wv_train_half_destroy(wv_train_half* h);
 size_t wv_train_half_workspace_bytes(const wv_train_half* h, int B, int T);   /* backward only */
@@ -220,6 +221,21 @@ int wv_train_half_backward(wv_train_half* h, const float* x, const float* g_pw, 
                            const float* g_dw, const float* v_dw, float pre_scale, const float* dy,
                            float* dx, float* dg_pw, float* dv_pw, float* dg_dw, float* dv_dw, float* db,
                            int B, int T, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The general fused unit of the encoder/decoder trunk, forward and backward:
+ *     y[B,M,Tout] = DW_{ks,stride}( (g_pw v_pw/||v_pw||) @ act(pre_scale * x[B,K,Tin]) ; g_dw v_dw/||v_dw|| ) + bias
+ * act = ELU (pre_elu = 1) or identity; causal SConv1d geometry (conv.py:715-763): left pad ks - stride, Tout = ceil(Tin/stride).
+ * K = M, ks = 5, stride = 1 is the ResnetBlock half above; M = 2K, ks = 2r, stride = r is the encoder's Downsample unit
+ * (seanet.py:733-772).  v_pw [M,K], v_dw [M,ks]; ks <= 16.  dx may be NULL (first layer: no input gradient). */
+int wv_train_unit_create(int K, int M, int ks, int stride, wv_train_unit** out);
+void wv_train_unit_destroy(wv_train_unit* u);
+size_t wv_train_unit_workspace_bytes(const wv_train_unit* u, int B, int Tin);   /* backward only */
+int wv_train_unit_forward(wv_train_unit* u, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
+                          const float* v_dw, const float* bias, float pre_scale, int pre_elu, float* y, int B, int Tin, void* stream);
+int wv_train_unit_backward(wv_train_unit* u, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
+                           const float* v_dw, float pre_scale, int pre_elu, const float* dy, float* dx, float* dg_pw, float* dv_pw,
+                           float* dg_dw, float* dv_dw, float* db, int B, int Tin, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Whole SEANetResnetBlock with live weight norm (modules/seanet.py:245-281, identity shortcut):
  *     y = x + s * half2(half1(pre_scale * x)),   s = res_scale * res_scale_param[0]  (res_scale_param may be NULL: s = res_scale)
  * forward keeps the two intermediate activations in `saved` (wv_train_block_saved_bytes) for backward, which returns

@@ -91,3 +91,39 @@ def bce_logits(z, mask=None, msg=None):
         y = y * msg.astype(np.float64)[:, :, None]
     loss = np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))
     return loss.mean(), (1.0 / (1.0 + np.exp(-z)) - y) / z.size
+
+
+def unit_forward(x, s, g_pw, v_pw, g_dw, v_dw, b, stride=1, elu=True):
+    """The general trunk unit (SConv1d geometry, conv.py:715-763): act(s x) -> 1x1 [M,K] -> causal depth-wise conv
+    (ks taps, stride, left pad ks - stride, right zero pad up to Tout = ceil(T / stride)) + bias.  Stride 1 / ks 5 is
+    half_forward; M = 2K, ks = 2r, stride = r is the encoder's Downsample unit (seanet.py:733-772)."""
+    x = x.astype(np.float64)
+    z = s * x
+    a = np.where(z > 0, z, np.expm1(z)) if elu else z
+    W = fold(g_pw.astype(np.float64), v_pw.astype(np.float64))[:, :, 0]
+    w = fold(g_dw.astype(np.float64), v_dw.astype(np.float64))[:, 0, :]
+    h = np.einsum("mk,bkt->bmt", W, a)
+    ks, T = w.shape[1], x.shape[2]
+    Tout, pad = -(-T // stride), ks - stride
+    hp = np.pad(h, ((0, 0), (0, 0), (pad, (Tout - 1) * stride + ks - pad - T)))
+    y = b.astype(np.float64)[None, :, None] + sum(w[None, :, i, None] * hp[:, :, i:i + (Tout - 1) * stride + 1:stride] for i in range(ks))
+    return y, (z, a, W, w, h, hp.shape[2], pad, Tout)
+
+
+def unit_backward(x, s, g_pw, v_pw, g_dw, v_dw, b, dy, stride=1, elu=True):
+    y, (z, a, W, w, h, Tp, pad, Tout) = unit_forward(x, s, g_pw, v_pw, g_dw, v_dw, b, stride, elu)
+    dy = dy.astype(np.float64)
+    ks, T = w.shape[1], x.shape[2]
+    hp = np.pad(h, ((0, 0), (0, 0), (pad, Tp - pad - T)))
+    sl = lambda i: slice(i, i + (Tout - 1) * stride + 1, stride)          # noqa: E731
+    dw = np.stack([(dy * hp[:, :, sl(i)]).sum((0, 2)) for i in range(ks)], 1)
+    dhp = np.zeros_like(hp)
+    for i in range(ks):
+        dhp[:, :, sl(i)] += w[None, :, i, None] * dy
+    dh = dhp[:, :, pad:pad + T]
+    dW = np.einsum("bmt,bkt->mk", dh, a)
+    da = np.einsum("mk,bmt->bkt", W, dh)
+    dx = da * (np.where(z > 0, 1.0, np.exp(z)) if elu else 1.0) * s
+    dg_pw, dv_pw = fold_backward(g_pw.astype(np.float64), v_pw.astype(np.float64), dW[:, :, None])
+    dg_dw, dv_dw = fold_backward(g_dw.astype(np.float64), v_dw.astype(np.float64), dw[:, None, :])
+    return dict(y=y, dx=dx, dg_pw=dg_pw, dv_pw=dv_pw, dg_dw=dg_dw, dv_dw=dv_dw, db_dw=dy.sum((0, 2)))

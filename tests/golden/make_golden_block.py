@@ -69,6 +69,44 @@ def main():
         np.savez_compressed(path, **out)
         print(f"wrote {path}: B={B} C={C} T={T} pre_scale={float(out['pre_scale']):.4f} keys={len(out)}")
 
+    # ---- the encoder's Downsample unit (seanet.py:733-772): Scale -> ELU -> 1x1 (C -> 2C, no bias) -> depth-wise k = 2r, stride r
+    from modules.seanet import Scale
+    from modules.conv import SConv1d
+    for tag, (B, C, T, r) in {"r2": (2, 40, 64, 2), "r4": (2, 64, 200, 4), "r5": (1, 48, 100, 5), "r8": (2, 64, 96, 8)}.items():
+        rng = np.random.default_rng(C + T + r)
+        sc = 0.7071068
+        ds = torch.nn.Sequential(Scale(1, value=sc, learnable=False, inplace=True), torch.nn.ELU(inplace=True),
+                                 SConv1d(C, 2 * C, 1, norm="weight_norm", bias=False, nonlinearity="relu"),
+                                 SConv1d(2 * C, 2 * C, kernel_size=2 * r, stride=r, groups=2 * C, norm="weight_norm", causal=True,
+                                         pad_mode="constant", bias=True)).double()
+        sd = {}
+        for k, v in ds.state_dict().items():
+            a = rng.standard_normal(tuple(v.shape))
+            if k.endswith("original0"):
+                a = 0.5 + np.abs(a)
+            elif k.endswith("original1"):
+                a = a * (1.0 / np.sqrt(np.prod(v.shape[1:])))
+            elif k.endswith("bias"):
+                a = a * 0.1
+            else:
+                a = v.numpy()                       # the fixed Scale buffer / parameter
+            sd[k] = torch.from_numpy(np.asarray(a, dtype=np.float32)).double().reshape(v.shape)
+        ds.load_state_dict(sd)
+        x = torch.from_numpy(rng.standard_normal((B, C, T)).astype(np.float32)).double().requires_grad_(True)
+        y = ds(x * 1.0)
+        dy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).double()
+        y.backward(dy)
+        p = dict(ds.named_parameters())
+        out = dict(x=x.detach().numpy().astype(np.float32), dy=dy.numpy().astype(np.float32), y=y.detach().numpy().astype(np.float32),
+                   dx=x.grad.numpy().astype(np.float32), pre_scale=np.float32(sc), ratio=np.int32(r))
+        for name, short in (("2.conv.conv.parametrizations.weight.original0", "g_pw"), ("2.conv.conv.parametrizations.weight.original1", "v_pw"),
+                            ("3.conv.conv.parametrizations.weight.original0", "g_dw"), ("3.conv.conv.parametrizations.weight.original1", "v_dw"),
+                            ("3.conv.conv.bias", "b_dw")):
+            out[short] = p[name].detach().numpy().astype(np.float32)
+            out["d" + short] = p[name].grad.numpy().astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, f"grads_down_{tag}.npz"), **out)
+        print(f"wrote grads_down_{tag}.npz: B={B} C={C}->{2 * C} T={T}->{y.shape[-1]} r={r}")
+
     # ---- losses ----------------------------------------------------------------------------------------------------
     sys.modules["audiotools"] = types.ModuleType("audiotools")
     sys.modules["audiotools"].AudioSignal = type("AudioSignal", (), {})

@@ -167,3 +167,48 @@ def test_bce_at_training_size_vs_oracle_and_errors():
         bce_logits(_cu(z), _cu(mask[:, :, :100]), _cu(msg))
     with pytest.raises(ValueError, match="same shape"):
         bce_logits(_cu(z), _cu(mask), None)
+
+
+# ---- the strided unit (encoder Downsample) ---------------------------------------------------------------------------
+def run_unit(x, s, p, dy, ks, stride, elu=True, need_dx=True):
+    from waveverify_amd.train import TrainUnit
+    u = TrainUnit(x.shape[1], p["v_pw"].shape[0], ks, stride)
+    pt = {k: _cu(v) for k, v in p.items()}
+    y = u.forward(_cu(x), pt, s, elu)
+    g = u.backward(_cu(x), pt, s, _cu(dy), elu, need_dx)
+    g2 = u.backward(_cu(x), pt, s, _cu(dy), elu, need_dx)
+    for k in KEYS:
+        assert (g[k] is None and g2[k] is None) or torch.equal(g[k], g2[k]), k
+    return y, g
+
+
+@pytest.mark.parametrize("tag", ["r2", "r4", "r5", "r8"])
+def test_downsample_unit_gradients_vs_reference_autograd(golden_dir, tag):
+    f = np.load(os.path.join(golden_dir, f"grads_down_{tag}.npz"))
+    p = {k: f[k] for k in ("g_pw", "v_pw", "g_dw", "v_dw", "b_dw")}
+    r = int(f["ratio"])
+    y, g = run_unit(f["x"], float(f["pre_scale"]), p, f["dy"], 2 * r, r)
+    assert rel(y, f["y"]) <= 2e-5
+    for k in KEYS:
+        assert rel(g[k], f[k]) <= 1e-4, (k, rel(g[k], f[k]))
+
+
+@pytest.mark.parametrize("B,K,M,T,ks,stride,elu", [(4, 64, 128, 16000, 4, 2, True), (3, 128, 256, 8000, 8, 4, True), (2, 256, 512, 2000, 10, 5, True),
+                                                   (2, 512, 1024, 400, 16, 8, True), (3, 96, 64, 404, 5, 1, False), (2, 64, 128, 36, 7, 3, True)])
+def test_unit_gradients_vs_oracle(B, K, M, T, ks, stride, elu):
+    rng = np.random.default_rng(K + M + T)
+    x = rng.standard_normal((B, K, T)).astype(np.float32)
+    p = dict(g_pw=(0.5 + np.abs(rng.standard_normal((M, 1, 1)))).astype(np.float32),
+             v_pw=(rng.standard_normal((M, K, 1)) * K ** -0.5).astype(np.float32),
+             g_dw=(0.5 + np.abs(rng.standard_normal((M, 1, 1)))).astype(np.float32),
+             v_dw=(rng.standard_normal((M, 1, ks)) * ks ** -0.5).astype(np.float32),
+             b_dw=(rng.standard_normal(M) * 0.1).astype(np.float32))
+    dy = rng.standard_normal((B, M, -(-T // stride))).astype(np.float32)
+    s = 0.7071068
+    ref = OT.unit_backward(x, s, p["g_pw"], p["v_pw"], p["g_dw"], p["v_dw"], p["b_dw"], dy, stride=stride, elu=elu)
+    y, g = run_unit(x, s, p, dy, ks, stride, elu)
+    assert rel(y, ref["y"]) <= 2e-5
+    for k in KEYS:
+        assert rel(g[k], ref[k]) <= 1e-4, (k, rel(g[k], ref[k]))
+    _, g0 = run_unit(x, s, p, dy, ks, stride, elu, need_dx=False)                  # first layer: no input gradient
+    assert g0["dx"] is None and torch.equal(g0["dv_pw"], g["dv_pw"])

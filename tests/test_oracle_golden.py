@@ -247,3 +247,17 @@ def test_train_oracle_bce_vs_reference_losses(golden_dir):
         ll, dzl = OT.bce_logits(g[f"c{i}_zl"], g[f"c{i}_mask"], None)
         assert abs(ld - float(g[f"c{i}_dec"])) <= 2e-6 * abs(ld) and abs(ll - float(g[f"c{i}_loc"])) <= 2e-6 * abs(ll)
         assert np.abs(dz - g[f"c{i}_dz"]).max() <= 1e-6 / dz.size ** 0.5 and np.abs(dzl - g[f"c{i}_dzl"]).max() <= 1e-6 / dzl.size ** 0.5
+
+
+@pytest.mark.parametrize("tag", ["r2", "r4", "r5", "r8"])
+def test_train_oracle_downsample_unit_vs_reference_autograd(golden_dir, tag):
+    from oracle import wv_oracle_train as OT
+    g = np.load(os.path.join(golden_dir, f"grads_down_{tag}.npz"))
+    r = OT.unit_backward(g["x"], float(g["pre_scale"]), g["g_pw"], g["v_pw"], g["g_dw"], g["v_dw"], g["b_dw"], g["dy"], stride=int(g["ratio"]))
+    for k, ref in (("y", "y"), ("dx", "dx"), ("dg_pw", "dg_pw"), ("dv_pw", "dv_pw"), ("dg_dw", "dg_dw"), ("dv_dw", "dv_dw"), ("db_dw", "db_dw")):
+        b = g[ref]
+        assert float(np.abs(r[k].reshape(b.shape) - b).max() / max(np.abs(b).max(), 1e-30)) <= 2e-6, k
+    # stride 1 / k5 is the half
+    h = np.load(os.path.join(golden_dir, "grads_half_c64.npz"))
+    r = OT.unit_backward(h["x"], float(h["pre_scale"]), h["g_pw"], h["v_pw"], h["g_dw"], h["v_dw"], h["b_dw"], h["dy"])
+    assert float(np.abs(r["dx"] - h["dx"]).max() / np.abs(h["dx"]).max()) <= 2e-6

@@ -55,6 +55,12 @@ SIGNATURES = {
     "wv_encoder_forward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_int, _VP,
                                      C.c_size_t, _VP]),
     "wv_model_film": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP]),
+    "wv_train_unit_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "wv_train_unit_destroy": (None, [_VP]),
+    "wv_train_unit_workspace_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),
+    "wv_train_unit_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_int, _VP, C.c_int, C.c_int, _VP]),
+    "wv_train_unit_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                         C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     "wv_train_block_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "wv_train_block_destroy": (None, [_VP]),
     "wv_train_block_saved_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),

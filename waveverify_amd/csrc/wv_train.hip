@@ -73,41 +73,54 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ g
 }
 
 // ---- depth-wise stencil backward ---------------------------------------------------------------------------------
-// One workgroup per (channel m, clip b) row:  dh[t] = sum_i w[m][i] * dy[t + 4 - i]  (dy = 0 past T);
-// partial[b][m][0..4] = sum_t dy[t] * h[t - 4 + i]  (h = 0 before 0), partial[b][m][5] = sum_t dy[t].
+// y[n] = b + sum_i w[i] * h[n * stride + i - pad]  (h = 0 outside [0, Tin); SConv1d causal: pad = ks - stride,
+// Tout = ceil(Tin / stride), conv.py:715-763).  One workgroup per (channel m, clip b) row:
+//   dh[t] = sum_{i : (t + pad - i) = n * stride, 0 <= n < Tout} w[i] * dy[n]
+//   partial[b][m][i] = sum_n dy[n] * h[n * stride + i - pad]  (i < ks),  partial[b][m][ks] = sum_n dy[n].
+constexpr int TRAIN_MAX_KS = 16;
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ h,
                                                      const float* __restrict__ w, float* __restrict__ dh,
-                                                     float* __restrict__ partial, int M, int T) {
-    __shared__ float red[4][6];
+                                                     float* __restrict__ partial, int M, int Tin, int Tout, int ks, int stride, int pad) {
+    __shared__ float red[4][TRAIN_MAX_KS + 1];
     const int m = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const size_t row = ((size_t)b * M + m) * T;
-    const float* dyr = dy + row;
-    const float* hr = h + row;
-    float wt[5];
+    const size_t row_h = ((size_t)b * M + m) * Tin, row_y = ((size_t)b * M + m) * Tout;
+    const float* dyr = dy + row_y;
+    const float* hr = h + row_h;
+    float wt[TRAIN_MAX_KS];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) wt[i] = w[m * 5 + i];
-    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int t = tid; t < T; t += 256) {
-        const float d = dyr[t];
+    for (int i = 0; i < TRAIN_MAX_KS; ++i) wt[i] = i < ks ? w[m * ks + i] : 0.f;
+    for (int t = tid; t < Tin; t += 256) {
         float g = 0.f;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int tf = t + 4 - i;                              // dh[t] += w[i] * dy[t + 4 - i]
-            if (tf < T) g = fmaf(wt[i], dyr[tf], g);
-            const int tb = t - 4 + i;                              // dw[i] += dy[t] * h[t - 4 + i]
-            if (tb >= 0) acc[i] = fmaf(d, hr[tb], acc[i]);
+        for (int i = 0; i < TRAIN_MAX_KS; ++i) {
+            const int u = t + pad - i;
+            if (i < ks && u >= 0 && u % stride == 0 && u / stride < Tout) g = fmaf(wt[i], dyr[u / stride], g);
         }
-        acc[5] += d;
-        dh[row + t] = g;
+        dh[row_h + t] = g;
+    }
+    float acc[TRAIN_MAX_KS + 1];
+#pragma unroll
+    for (int i = 0; i <= TRAIN_MAX_KS; ++i) acc[i] = 0.f;
+    for (int n = tid; n < Tout; n += 256) {
+        const float d = dyr[n];
+#pragma unroll
+        for (int i = 0; i < TRAIN_MAX_KS; ++i) {
+            const int tb = n * stride + i - pad;
+            if (i < ks && tb >= 0 && tb < Tin) acc[i] = fmaf(d, hr[tb], acc[i]);
+        }
+        acc[TRAIN_MAX_KS] += d;
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        float s = acc[i];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if ((tid & 63) == 0) red[tid >> 6][i] = s;
+    for (int i = 0; i <= TRAIN_MAX_KS; ++i) {
+        float v = acc[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((tid & 63) == 0) red[tid >> 6][i] = v;
     }
     __syncthreads();
-    if (tid < 6) partial[((size_t)b * M + m) * 6 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid <= ks) {
+        const int src = tid < ks ? tid : TRAIN_MAX_KS;
+        partial[((size_t)b * M + m) * (ks + 1) + tid] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
+    }
 }
 
 // out[j] = sum_{s < S} part[s][j], fixed order (deterministic)
@@ -119,12 +132,12 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
     out[j] = s;
 }
 
-// tap / bias gradient rows: dwdb[m][0..5] -> dw_dw[m][5] and db[m]
-__global__ void split_dwdb_kernel(const float* __restrict__ dwdb, float* __restrict__ dw, float* __restrict__ db, int M) {
+// tap / bias gradient rows: dwdb[m][0..ks] -> dw_dw[m][ks] and db[m]
+__global__ void split_dwdb_kernel(const float* __restrict__ dwdb, float* __restrict__ dw, float* __restrict__ db, int M, int ks) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
-    for (int i = 0; i < 5; ++i) dw[m * 5 + i] = dwdb[m * 6 + i];
-    db[m] = dwdb[m * 6 + 5];
+    for (int i = 0; i < ks; ++i) dw[m * ks + i] = dwdb[m * (ks + 1) + i];
+    db[m] = dwdb[m * (ks + 1) + ks];
 }
 
 // dx = da * ELU'(s x) * s,  ELU'(z) = z > 0 ? 1 : exp(z)
@@ -152,7 +165,7 @@ __global__ void elu_bwd_tail_kernel(const float* da, const float* x, float* dx, 
 // 32 lanes of a fragment read -- same t, consecutive rows -- hit 32 banks), the ELU of the second operand is applied
 // on the way in.  part[split][M][K] partial sums; a fixed-order pass adds the splits.
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ dh, const float* __restrict__ x,
-                                                      float* __restrict__ part, float s, int B, int M, int K, int T) {
+                                                      float* __restrict__ part, float s, int elu, int B, int M, int K, int T) {
     constexpr int LD = 65;
     __shared__ float As[64 * LD], Bs[64 * LD];
     const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 64, split = blockIdx.z, S = gridDim.z;
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
                 As[lr * LD + lc + q] = (tv && m0 + lr < M) ? dhb[(size_t)(m0 + lr) * T + t] : 0.f;
                 float xv = (tv && k0 + lr < K) ? xb[(size_t)(k0 + lr) * T + t] : 0.f;
                 xv *= s;
-                Bs[lr * LD + lc + q] = xv > 0.f ? xv : (__expf(xv) - 1.f);     // ELU(0) = 0 keeps the padding neutral
+                Bs[lr * LD + lc + q] = (!elu || xv > 0.f) ? xv : (__expf(xv) - 1.f);     // ELU(0) = 0 keeps the padding neutral
             }
             __syncthreads();
 #pragma unroll
@@ -276,134 +289,159 @@ int tfail(int code, const std::string& msg) { g_terr = msg; return code; }
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
-struct wv_train_half {
-    int C = 0, Mp = 0;
+struct wv_train_unit {
+    int K = 0, M = 0, ks = 5, stride = 1, pad = 4, Mp = 0, KpT = 0;
     float *w_pw = nullptr, *inv_pw = nullptr, *wq = nullptr, *wqT = nullptr;      // folded 1x1 weight + packs
-    float *w_dw = nullptr, *inv_dw = nullptr, *id_taps = nullptr;                 // folded taps [C][5]
+    float *w_dw = nullptr, *inv_dw = nullptr, *id_taps = nullptr;                 // folded taps [M][ks]; identity stencil rows
     float *dW = nullptr, *dwdb = nullptr, *dw_taps = nullptr;                     // weight-gradient scratch
     std::vector<void*> owned;
-    ~wv_train_half() { for (void* p : owned) (void)hipFree(p); }
+    ~wv_train_unit() { for (void* p : owned) (void)hipFree(p); }
 };
 
 extern "C" {
 
 const char* wv_train_last_error(void) { return g_terr.c_str(); }
 
-int wv_train_half_create(int C, wv_train_half** out) {
-    if (!out || C < 1 || C > 4096) return tfail(WV_EINVAL, "bad channel count");
-    auto* h = new wv_train_half();
-    h->C = C; h->Mp = wv::round_up(C, wv::M_ALIGN);
-    const size_t kq = (size_t)wv::round_up(C, 32) * h->Mp;
+int wv_train_unit_create(int K, int M, int ks, int stride, wv_train_unit** out) {
+    if (!out || K < 1 || K > 4096 || M < 1 || M > 4096) return tfail(WV_EINVAL, "bad channel count");
+    if (ks < 1 || ks > wv::TRAIN_MAX_KS || stride < 1 || ks - stride < 0) return tfail(WV_EINVAL, "bad kernel size / stride");
+    auto* h = new wv_train_unit();
+    h->K = K; h->M = M; h->ks = ks; h->stride = stride; h->pad = ks - stride;
+    h->Mp = wv::round_up(M, wv::M_ALIGN); h->KpT = wv::round_up(K, wv::M_ALIGN);
+    const size_t nq = (size_t)wv::round_up(K, 32) * h->Mp, nqT = (size_t)wv::round_up(M, 32) * h->KpT;
     auto alloc = [&](float** p, size_t n, bool zero) {
         if (hipMalloc((void**)p, n * sizeof(float)) != hipSuccess) return false;
         h->owned.push_back(*p);
         return !zero || hipMemset(*p, 0, n * sizeof(float)) == hipSuccess;
     };
-    std::vector<float> taps((size_t)C * 5, 0.f);
-    for (int m = 0; m < C; ++m) taps[(size_t)m * 5 + 4] = 1.f;
-    bool ok = alloc(&h->w_pw, (size_t)C * C, false) && alloc(&h->inv_pw, C, false) && alloc(&h->wq, kq, true) &&
-              alloc(&h->wqT, kq, true) && alloc(&h->w_dw, (size_t)C * 5, false) && alloc(&h->inv_dw, C, false) &&
-              alloc(&h->id_taps, (size_t)C * 5, false) && alloc(&h->dW, (size_t)C * C, false) &&
-              alloc(&h->dwdb, (size_t)C * 6, false) && alloc(&h->dw_taps, (size_t)C * 5, false) &&
+    const int R = std::max(K, M);
+    std::vector<float> taps((size_t)R * 5, 0.f);
+    for (int m = 0; m < R; ++m) taps[(size_t)m * 5 + 4] = 1.f;
+    bool ok = alloc(&h->w_pw, (size_t)M * K, false) && alloc(&h->inv_pw, M, false) && alloc(&h->wq, nq, true) &&
+              alloc(&h->wqT, nqT, true) && alloc(&h->w_dw, (size_t)M * ks, false) && alloc(&h->inv_dw, M, false) &&
+              alloc(&h->id_taps, taps.size(), false) && alloc(&h->dW, (size_t)M * K, false) &&
+              alloc(&h->dwdb, (size_t)M * (ks + 1), false) && alloc(&h->dw_taps, (size_t)M * ks, false) &&
               hipMemcpy(h->id_taps, taps.data(), taps.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { delete h; return tfail(WV_EHIP, "device allocation failed"); }
     *out = h;
     return WV_OK;
 }
 
-void wv_train_half_destroy(wv_train_half* h) { delete h; }
+void wv_train_unit_destroy(wv_train_unit* h) { delete h; }
+int wv_train_half_create(int C, wv_train_unit** out) { return wv_train_unit_create(C, C, 5, 1, out); }
+void wv_train_half_destroy(wv_train_unit* h) { delete h; }
 
 static int nt_splits(int B) { return B < 32 ? B : 32; }
+static int t_out(const wv_train_unit* h, int Tin) { return (Tin + h->stride - 1) / h->stride; }
 
-size_t wv_train_half_workspace_bytes(const wv_train_half* h, int B, int T) {
-    if (!h || B < 1 || T < 1) return 0;
-    const size_t act = al256((size_t)B * h->C * T * 4);
-    return 3 * act + al256((size_t)B * h->C * 6 * 4) + al256((size_t)nt_splits(B) * h->C * h->C * 4);
+size_t wv_train_unit_workspace_bytes(const wv_train_unit* h, int B, int Tin) {
+    if (!h || B < 1 || Tin < 1) return 0;
+    const size_t am = al256((size_t)B * h->M * Tin * 4), ak = al256((size_t)B * h->K * Tin * 4);
+    return 2 * am + ak + al256((size_t)B * h->M * (h->ks + 1) * 4) + al256((size_t)nt_splits(B) * h->M * h->K * 4);
 }
+size_t wv_train_half_workspace_bytes(const wv_train_unit* h, int B, int T) { return wv_train_unit_workspace_bytes(h, B, T); }
 
 #define T_LAUNCH(expr)                                                                              \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) return tfail(WV_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
-// fold both weights of the half for this step (live weight norm)
-static int fold_step(wv_train_half* h, const float* g_pw, const float* v_pw, const float* g_dw, const float* v_dw, hipStream_t s) {
-    const int C = h->C;
-    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(C), dim3(256), 0, s, g_pw, v_pw, h->w_pw, h->inv_pw, h->wq, h->wqT, C, C, h->Mp, h->Mp);
-    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(C), dim3(256), 0, s, g_dw, v_dw, h->w_dw, h->inv_dw, (float*)nullptr, (float*)nullptr, C, 5, 0, 0);
+// fold both weights of the unit for this step (live weight norm)
+static int fold_step(wv_train_unit* h, const float* g_pw, const float* v_pw, const float* g_dw, const float* v_dw, hipStream_t s) {
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->M), dim3(256), 0, s, g_pw, v_pw, h->w_pw, h->inv_pw, h->wq, h->wqT, h->M, h->K, h->Mp, h->KpT);
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->M), dim3(256), 0, s, g_dw, v_dw, h->w_dw, h->inv_dw, (float*)nullptr, (float*)nullptr, h->M, h->ks, 0, 0);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }
 
-static wv::PwWeight pack_of(const wv_train_half* h, bool transposed) {
+static wv::PwWeight pack_of(const wv_train_unit* h, bool transposed) {
     wv::PwWeight p;
-    p.M = h->C; p.K = h->C; p.Mp = h->Mp; p.Kp = wv::round_up(h->C, wv::BK);
-    p.wq = transposed ? h->wqT : h->wq;
+    if (!transposed) { p.M = h->M; p.K = h->K; p.Mp = h->Mp; p.Kp = wv::round_up(h->K, wv::BK); p.wq = h->wq; }
+    else { p.M = h->K; p.K = h->M; p.Mp = h->KpT; p.Kp = wv::round_up(h->M, wv::BK); p.wq = h->wqT; }
     return p;
 }
 
-int wv_train_half_forward(wv_train_half* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
-                          const float* v_dw, const float* bias, float pre_scale, float* y, int B, int T, void* stream) {
-    if (!h || !x || !g_pw || !v_pw || !g_dw || !v_dw || !y || B < 1 || T < 1) return tfail(WV_EINVAL, "null / bad argument");
+static const char* SHAPE_MSG = "training unit: needs >= 33 channels on both sides, T % 4 == 0 and 16-byte aligned tensors";
+
+int wv_train_unit_forward(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
+                          const float* v_dw, const float* bias, float pre_scale, int pre_elu, float* y, int B, int Tin, void* stream) {
+    if (!h || !x || !g_pw || !v_pw || !g_dw || !v_dw || !y || B < 1 || Tin < 1) return tfail(WV_EINVAL, "null / bad argument");
     hipStream_t s = (hipStream_t)stream;
     int rc = fold_step(h, g_pw, v_pw, g_dw, v_dw, s);
     if (rc) return rc;
     wv::PwDwArgs a{};
     a.X = x; a.pw = pack_of(h, false); a.dw_w = h->w_dw; a.dw_b = bias; a.Y = y;
-    a.B = B; a.Tin = T; a.Tout = T; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
-    a.pre_scale = pre_scale; a.pre_elu = 1; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
-    if (!wv::k1_supported(a)) return tfail(WV_EINVAL, "training slice: needs C >= 33, T % 4 == 0 and 16-byte aligned tensors");
+    a.B = B; a.Tin = Tin; a.Tout = t_out(h, Tin); a.ks = h->ks; a.stride = h->stride; a.dil = 1; a.pad = h->pad;
+    a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
+    if (!wv::k1_supported(a)) return tfail(WV_EINVAL, SHAPE_MSG);
     T_LAUNCH(wv::launch_pw_dw(a, s));
     return WV_OK;
 }
 
-int wv_train_half_backward(wv_train_half* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
-                           const float* v_dw, float pre_scale, const float* dy, float* dx, float* dg_pw, float* dv_pw,
-                           float* dg_dw, float* dv_dw, float* db, int B, int T, void* ws, size_t ws_bytes, void* stream) {
-    if (!h || !x || !g_pw || !v_pw || !g_dw || !v_dw || !dy || !dx || !dg_pw || !dv_pw || !dg_dw || !dv_dw || !db)
+int wv_train_half_forward(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
+                          const float* v_dw, const float* bias, float pre_scale, float* y, int B, int T, void* stream) {
+    return wv_train_unit_forward(h, x, g_pw, v_pw, g_dw, v_dw, bias, pre_scale, 1, y, B, T, stream);
+}
+
+int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
+                           const float* v_dw, float pre_scale, int pre_elu, const float* dy, float* dx, float* dg_pw, float* dv_pw,
+                           float* dg_dw, float* dv_dw, float* db, int B, int Tin, void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !x || !g_pw || !v_pw || !g_dw || !v_dw || !dy || !dg_pw || !dv_pw || !dg_dw || !dv_dw || !db)
         return tfail(WV_EINVAL, "null argument");
-    if (B < 1 || T < 1 || !ws || ws_bytes < wv_train_half_workspace_bytes(h, B, T)) return tfail(WV_ENOMEM, "workspace too small");
+    if (B < 1 || Tin < 1 || !ws || ws_bytes < wv_train_unit_workspace_bytes(h, B, Tin)) return tfail(WV_ENOMEM, "workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const int C = h->C;
-    const size_t act = al256((size_t)B * C * T * 4);
+    const int M = h->M, K = h->K, ks = h->ks, Tout = t_out(h, Tin);
+    const size_t am = al256((size_t)B * M * Tin * 4), ak = al256((size_t)B * K * Tin * 4);
     char* w = (char*)ws;
-    float* H = (float*)w; float* DH = (float*)(w + act); float* DA = (float*)(w + 2 * act);
-    float* partial = (float*)(w + 3 * act);
-    float* parts = (float*)(w + 3 * act + al256((size_t)B * C * 6 * 4));
+    float* H = (float*)w; float* DH = (float*)(w + am); float* DA = (float*)(w + 2 * am);
+    float* partial = (float*)(w + 2 * am + ak);
+    float* parts = (float*)(w + 2 * am + ak + al256((size_t)B * M * (ks + 1) * 4));
     int rc = fold_step(h, g_pw, v_pw, g_dw, v_dw, s);                          // the step's weights (forward ran the same fold)
     if (rc) return rc;
-    // h = W @ ELU(s x), recomputed (forward keeps no activations): K1 with the identity stencil
+    // h = W @ act(s x), recomputed (forward keeps no activations): K1 with the identity stencil
     wv::PwDwArgs a{};
     a.X = x; a.pw = pack_of(h, false); a.dw_w = h->id_taps; a.dw_b = nullptr; a.Y = H;
-    a.B = B; a.Tin = T; a.Tout = T; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
-    a.pre_scale = pre_scale; a.pre_elu = 1; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
-    if (!wv::k1_supported(a)) return tfail(WV_EINVAL, "training slice: needs C >= 33, T % 4 == 0 and 16-byte aligned tensors");
+    a.B = B; a.Tin = Tin; a.Tout = Tin; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
+    a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
+    if (!wv::k1_supported(a)) return tfail(WV_EINVAL, SHAPE_MSG);
     T_LAUNCH(wv::launch_pw_dw(a, s));
     // dh, and the per-clip partial sums of the tap / bias gradients
-    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(C, B), dim3(256), 0, s, dy, H, h->w_dw, DH, partial, C, T);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((C * 6 + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)C * 6);
-    hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((C + 255) / 256), dim3(256), 0, s, h->dwdb, h->dw_taps, db, C);
-    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g_dw, v_dw, h->inv_dw, h->dw_taps, dg_dw, dv_dw, 5);
+    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(M, B), dim3(256), 0, s, dy, H, h->w_dw, DH, partial, M, Tin, Tout, ks, h->stride, h->pad);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((M * (ks + 1) + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)M * (ks + 1));
+    hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((M + 255) / 256), dim3(256), 0, s, h->dwdb, h->dw_taps, db, M, ks);
+    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(M), dim3(256), 0, s, g_dw, v_dw, h->inv_dw, h->dw_taps, dg_dw, dv_dw, ks);
     T_LAUNCH(hipGetLastError());
-    // da = W^T @ dh on the forward's GEMM kernel, then through the ELU
-    wv::PwDwArgs t{};
-    t.X = DH; t.pw = pack_of(h, true); t.dw_w = h->id_taps; t.dw_b = nullptr; t.Y = DA;
-    t.B = B; t.Tin = T; t.Tout = T; t.ks = 5; t.stride = 1; t.dil = 1; t.pad = 4;
-    t.pre_scale = 1.f; t.pre_elu = 0; t.out_scale = 1.f; t.bands = 1; t.film_stride = 2;
-    T_LAUNCH(wv::launch_pw_dw(t, s));
-    const size_t n = (size_t)B * C * T, n4 = n / 4;
-    if (n4) hipLaunchKernelGGL(wv::elu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, DA, x, dx, pre_scale, n4);
-    if (n % 4) hipLaunchKernelGGL(wv::elu_bwd_tail_kernel, dim3(1), dim3(256), 0, s, DA, x, dx, pre_scale, n4 * 4, n);
+    if (dx) {
+        // da = W^T @ dh on the forward's GEMM kernel, then through the activation
+        wv::PwDwArgs t{};
+        t.X = DH; t.pw = pack_of(h, true); t.dw_w = h->id_taps; t.dw_b = nullptr; t.Y = pre_elu ? DA : dx;
+        t.B = B; t.Tin = Tin; t.Tout = Tin; t.ks = 5; t.stride = 1; t.dil = 1; t.pad = 4;
+        t.pre_scale = pre_elu ? 1.f : pre_scale; t.pre_elu = 0; t.out_scale = 1.f; t.bands = 1; t.film_stride = 2;   // no ELU: dx = s W^T dh
+        if (!wv::k1_supported(t)) return tfail(WV_EINVAL, SHAPE_MSG);
+        T_LAUNCH(wv::launch_pw_dw(t, s));
+        if (pre_elu) {
+            const size_t n = (size_t)B * K * Tin, n4 = n / 4;
+            if (n4) hipLaunchKernelGGL(wv::elu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, DA, x, dx, pre_scale, n4);
+            if (n % 4) hipLaunchKernelGGL(wv::elu_bwd_tail_kernel, dim3(1), dim3(256), 0, s, DA, x, dx, pre_scale, n4 * 4, n);
+        }
+    }
     // dW = sum dh a^T, then the weight-norm backward
     const int S = nt_splits(B);
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((C + 63) / 64, (C + 63) / 64, S), dim3(256), 0, s, DH, x, parts, pre_scale, B, C, C, T);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)C * C + 255) / 256)), dim3(256), 0, s, parts, h->dW, S, (size_t)C * C);
-    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, C);
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((M + 63) / 64, (K + 63) / 64, S), dim3(256), 0, s, DH, x, parts, pre_scale, pre_elu, B, M, K, Tin);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)M * K + 255) / 256)), dim3(256), 0, s, parts, h->dW, S, (size_t)M * K);
+    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(M), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, K);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
+}
+
+int wv_train_half_backward(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
+                           const float* v_dw, float pre_scale, const float* dy, float* dx, float* dg_pw, float* dv_pw,
+                           float* dg_dw, float* dv_dw, float* db, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!dx) return tfail(WV_EINVAL, "null argument");
+    return wv_train_unit_backward(h, x, g_pw, v_pw, g_dw, v_dw, pre_scale, 1, dy, dx, dg_pw, dv_pw, dg_dw, dv_dw, db, B, T, ws, ws_bytes, stream);
 }
 
 // ---- whole SEANetResnetBlock: y = x + s * half2(half1(pre_scale * x)) (seanet.py:245-281) ------------------------------
 struct wv_train_block {
-    wv_train_half* h[2] = {nullptr, nullptr};
+    wv_train_unit* h[2] = {nullptr, nullptr};
     float* partial = nullptr;
     ~wv_train_block() { delete h[0]; delete h[1]; if (partial) (void)hipFree(partial); }
 };
@@ -422,12 +460,12 @@ int wv_train_block_create(int C, wv_train_block** out) {
 void wv_train_block_destroy(wv_train_block* b) { delete b; }
 
 size_t wv_train_block_saved_bytes(const wv_train_block* b, int B, int T) {
-    return (b && B > 0 && T > 0) ? 2 * al256((size_t)B * b->h[0]->C * T * 4) : 0;
+    return (b && B > 0 && T > 0) ? 2 * al256((size_t)B * b->h[0]->M * T * 4) : 0;
 }
 
 size_t wv_train_block_workspace_bytes(const wv_train_block* b, int B, int T) {
     if (!b || B < 1 || T < 1) return 0;
-    return wv_train_half_workspace_bytes(b->h[0], B, T) + 2 * al256((size_t)B * b->h[0]->C * T * 4);
+    return wv_train_half_workspace_bytes(b->h[0], B, T) + 2 * al256((size_t)B * b->h[0]->M * T * 4);
 }
 
 int wv_train_block_forward(wv_train_block* b, const float* x, const wv_half_params* p, const float* res_scale_param,
@@ -435,12 +473,12 @@ int wv_train_block_forward(wv_train_block* b, const float* x, const wv_half_para
     if (!b || !x || !p || !y || !saved) return tfail(WV_EINVAL, "null argument");
     if (B < 1 || T < 1 || (T & 3) || saved_bytes < wv_train_block_saved_bytes(b, B, T)) return tfail(WV_ENOMEM, "saved-activation buffer too small (or T % 4 != 0)");
     hipStream_t s = (hipStream_t)stream;
-    const size_t act = al256((size_t)B * b->h[0]->C * T * 4);
+    const size_t act = al256((size_t)B * b->h[0]->M * T * 4);
     float* u = (float*)saved; float* v = (float*)((char*)saved + act);
     int rc = wv_train_half_forward(b->h[0], x, p[0].g_pw, p[0].v_pw, p[0].g_dw, p[0].v_dw, p[0].bias, pre_scale, u, B, T, stream);
     if (!rc) rc = wv_train_half_forward(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, p[1].bias, 1.f, v, B, T, stream);
     if (rc) return rc;
-    const size_t n4 = (size_t)B * b->h[0]->C * T / 4;
+    const size_t n4 = (size_t)B * b->h[0]->M * T / 4;
     hipLaunchKernelGGL(wv::axpy_res_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float4*)x, (const float4*)v, (float4*)y,
                        res_scale_param, res_scale, n4);
     T_LAUNCH(hipGetLastError());
@@ -454,7 +492,7 @@ int wv_train_block_backward(wv_train_block* b, const float* x, const wv_half_par
     if (B < 1 || T < 1 || (T & 3) || !ws || ws_bytes < wv_train_block_workspace_bytes(b, B, T)) return tfail(WV_ENOMEM, "workspace too small (or T % 4 != 0)");
     if (res_scale_param && !d_res_scale_param) return tfail(WV_EINVAL, "res_scale_param without a gradient slot");
     hipStream_t s = (hipStream_t)stream;
-    const int C = b->h[0]->C;
+    const int C = b->h[0]->M;
     const size_t act = al256((size_t)B * C * T * 4), n4 = (size_t)B * C * T / 4;
     const float* u = (const float*)saved; const float* v = (const float*)((const char*)saved + act);
     float* DV = (float*)ws; float* DU = (float*)((char*)ws + act);

@@ -80,6 +80,57 @@ class TrainHalf:
             pass
 
 
+class TrainUnit:
+    """The general trunk unit with live weight norm (wv_train_unit_*): act(pre_scale x) -> 1x1 [M,K] -> causal
+    depth-wise conv (ks, stride) + bias.  ks = 2r, stride = r, M = 2K is the encoder's Downsample unit
+    (/root/reference/modules/seanet.py:733-772).  params: g_pw [M], v_pw [M,K], g_dw [M], v_dw [M,ks], b_dw [M]."""
+
+    def __init__(self, k_in: int, m_out: int, ks: int, stride: int):
+        self._lib = _lib.load()
+        self.K, self.M, self.ks, self.stride = int(k_in), int(m_out), int(ks), int(stride)
+        self._h = C.c_void_p()
+        if self._lib.wv_train_unit_create(self.K, self.M, self.ks, self.stride, C.byref(self._h)) != 0:
+            raise RuntimeError(f"wv_train_unit_create: {self._lib.wv_train_last_error().decode()}")
+
+    def _p(self, p):
+        return (_f(p["g_pw"]).reshape(self.M), _f(p["v_pw"]).reshape(self.M, self.K), _f(p["g_dw"]).reshape(self.M),
+                _f(p["v_dw"]).reshape(self.M, self.ks), _f(p["b_dw"]).reshape(self.M))
+
+    def forward(self, x, p, pre_scale: float, pre_elu: bool = True):
+        x = _f(x)
+        B, _, T = x.shape
+        g_pw, v_pw, g_dw, v_dw, b = self._p(p)
+        y = torch.empty(B, self.M, -(-T // self.stride), device=x.device)
+        rc = self._lib.wv_train_unit_forward(self._h, x.data_ptr(), g_pw.data_ptr(), v_pw.data_ptr(), g_dw.data_ptr(), v_dw.data_ptr(),
+                                             b.data_ptr(), float(pre_scale), int(pre_elu), y.data_ptr(), B, T, TrainHalf._stream())
+        if rc != 0:
+            raise RuntimeError(f"wv_train_unit_forward: {self._lib.wv_train_last_error().decode()}")
+        return y
+
+    def backward(self, x, p, pre_scale: float, dy, pre_elu: bool = True, need_dx: bool = True):
+        x, dy = _f(x), _f(dy)
+        B, _, T = x.shape
+        g_pw, v_pw, g_dw, v_dw, _ = self._p(p)
+        out = dict(dx=torch.empty_like(x) if need_dx else None, dg_pw=torch.empty_like(g_pw), dv_pw=torch.empty_like(v_pw),
+                   dg_dw=torch.empty_like(g_dw), dv_dw=torch.empty_like(v_dw), db_dw=torch.empty_like(g_dw))
+        ws = torch.empty(int(self._lib.wv_train_unit_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=x.device)
+        rc = self._lib.wv_train_unit_backward(
+            self._h, x.data_ptr(), g_pw.data_ptr(), v_pw.data_ptr(), g_dw.data_ptr(), v_dw.data_ptr(), float(pre_scale), int(pre_elu),
+            dy.data_ptr(), out["dx"].data_ptr() if need_dx else None, out["dg_pw"].data_ptr(), out["dv_pw"].data_ptr(),
+            out["dg_dw"].data_ptr(), out["dv_dw"].data_ptr(), out["db_dw"].data_ptr(), B, T, ws.data_ptr(), ws.numel(), TrainHalf._stream())
+        if rc != 0:
+            raise RuntimeError(f"wv_train_unit_backward: {self._lib.wv_train_last_error().decode()}")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._lib.wv_train_unit_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
 class _HalfParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("g_pw", "v_pw", "g_dw", "v_dw", "bias")]
 
