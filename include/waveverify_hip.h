@@ -261,6 +261,13 @@ int wv_train_block_backward(wv_train_block* b, const float* x, const wv_half_par
 size_t wv_train_bce_workspace_bytes(void);
 int wv_train_bce_logits(const float* logits, const float* mask, const float* msg, float* loss, float* dlogits, float grad_scale,
                         int B, int Cz, int T, void* workspace, size_t workspace_bytes, void* stream);
+/* Optimizer step over FLAT device arenas (a net's parameters / gradients / AdamW moments are contiguous; scripts/train.py:1346-1358,
+ * conf/base.yml:128-130): wv_train_sumsq = sum of squares of the gradient arena (fixed-order two-stage sum; device scalar `out`);
+ * wv_train_adamw = torch.nn.utils.clip_grad_norm_(max_norm) -- when grad_sumsq is given -- followed by torch.optim.AdamW's
+ * update at 1-based step `step`; the ExponentialLR schedule is the caller's lr. */
+int wv_train_sumsq(const float* g, size_t n, float* out, void* workspace, size_t workspace_bytes /* wv_train_bce_workspace_bytes() */, void* stream);
+int wv_train_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, const float* grad_sumsq, float max_norm, void* stream);
 const char* wv_train_last_error(void);
 
 /* ---- temporal augmentations of the training step ------------------------------------

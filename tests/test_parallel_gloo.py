@@ -110,3 +110,31 @@ def test_two_rank_bucketed_allreduce_is_the_mean(tmp_path):
         got = torch.load(tmp_path / f"g{r}.pt", weights_only=True)
         for a, b in zip(got, want):
             assert torch.allclose(a, b, atol=1e-6)
+
+
+def _flat_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from waveverify_amd.parallel import allreduce_mean_flat_
+    arena = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    n = allreduce_mean_flat_(arena, bucket_bytes=4 * 300)          # 300-float buckets -> 4 collectives, last one ragged
+    q.put((rank, n, arena.clone()))
+    dist.destroy_process_group()
+
+
+def test_flat_arena_allreduce_two_ranks():
+    """The training slices keep gradients in one flat arena: buckets are slices, reduced in place from the end."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 7
+    ps = [ctx.Process(target=_flat_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+    want = torch.arange(1000, dtype=torch.float32) * 1.5
+    for rank, n, arena in res:
+        assert n == 4 and torch.equal(arena, want)

@@ -17,6 +17,8 @@
 // Gradient parity against the reference's autograd: tests/test_gpu_train.py (fixtures tests/golden/grads_half_*).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include <string>
 #include <vector>
 
@@ -256,6 +258,35 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float4* __restrict__ d
     if (i >= n4) return;
     const float4 a = dx[i], b = dy[i];
     dx[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// ---- optimizer step over a FLAT parameter arena (scripts/train.py:1346-1358, conf/base.yml:128-130) ------------------
+// Parameters, gradients and both AdamW moments of a net live in contiguous arenas, so gradient clipping is one
+// two-stage sum of squares and the update one launch (and the DDP buckets are plain slices of the gradient arena).
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)RED_BLOCKS * 256) acc = fmaf(g[i], g[i], acc);
+    const float t = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// torch.nn.utils.clip_grad_norm_ (coef = min(1, max_norm / (norm + 1e-6))) followed by torch.optim.AdamW's update:
+//   p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                                                     float bc1, float bc2_sqrt, const float* __restrict__ sumsq, float max_norm) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float coef = 1.f;
+    if (sumsq) coef = fminf(max_norm / (sqrtf(sumsq[0]) + 1e-6f), 1.f);
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);                         // lerp, as torch does it
+    const float vi = v[i] * b2 + gi * gi * (1.f - b2);
+    m[i] = mi; v[i] = vi;
+    pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    p[i] = pi;
 }
 
 // ---- BCE-with-logits losses of the training step (scripts/loss.py:947-1099) -----------------------------------------
@@ -525,6 +556,29 @@ int wv_train_bce_logits(const float* logits, const float* mask, const float* msg
     hipLaunchKernelGGL(wv::bce_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, logits, mask, msg, dlogits, (float*)ws,
                        grad_scale / (float)n, Cz, T, n);
     hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, wv::RED_BLOCKS, 1.f / (float)n, loss);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+// ---- gradient norm + AdamW over flat arenas ---------------------------------------------------------------------------------
+int wv_train_sumsq(const float* g, size_t n, float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (!g || !out || !n) return tfail(WV_EINVAL, "null / bad argument");
+    if (!ws || ws_bytes < wv_train_bce_workspace_bytes()) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wv::sumsq_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, g, n, (float*)ws);
+    hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, wv::RED_BLOCKS, 1.f, out);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+int wv_train_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, const float* grad_sumsq, float max_norm, void* stream) {
+    if (!p || !g || !m || !v || !n || step < 1 || !(lr >= 0.f) || beta1 < 0.f || beta1 >= 1.f || beta2 < 0.f || beta2 >= 1.f)
+        return tfail(WV_EINVAL, "null / bad argument");
+    const float bc1 = (float)(1.0 - std::pow((double)beta1, step));
+    const float bc2s = (float)std::sqrt(1.0 - std::pow((double)beta2, step));
+    hipLaunchKernelGGL(wv::adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                       eps, weight_decay, bc1, bc2s, grad_sumsq, max_norm);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }

@@ -111,3 +111,25 @@ def allreduce_mean_(grads, buckets, group=None, async_op: bool = True):
             grads[i].copy_(flat[off:off + n].view_as(grads[i]))
             off += n
     return len(flats)
+
+
+def allreduce_mean_flat_(arena: torch.Tensor, bucket_bytes: int = DEFAULT_BUCKET_BYTES, group=None) -> int:
+    """In-place mean all-reduce of a FLAT gradient arena (waveverify_amd/train.py keeps a net's gradients contiguous):
+    buckets are plain slices -- no gather / scatter copies -- launched back to back from the END of the arena
+    (backward fills it last layer first) and waited for together.  Returns the number of collectives."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    if arena.dim() != 1 or not arena.is_contiguous():
+        raise ValueError("flat contiguous arena required")
+    world = dist.get_world_size(group)
+    per = max(1, bucket_bytes // arena.element_size())
+    works, hi = [], arena.numel()
+    while hi > 0:
+        lo = max(0, hi - per)
+        works.append(dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        hi = lo
+    for w in works:
+        w.wait()
+    arena.div_(world)
+    return len(works)

@@ -231,3 +231,93 @@ def bce_logits(logits: torch.Tensor, mask=None, msg=None, grad_scale: float = 1.
     if rc != 0:
         raise RuntimeError(f"wv_train_bce_logits: {lib.wv_train_last_error().decode()}")
     return loss, dz
+
+
+class FlatAdamW:
+    """AdamW over one flat parameter arena, with the reference's schedule and clipping (scripts/train.py:1346-1358:
+    clip_grad_norm_ -> AdamW step -> ExponentialLR step; conf/base.yml:128-130: betas (0.8, 0.99), lr 1e-4,
+    gamma 0.999996; torch defaults eps 1e-8, weight_decay 0.01).  `step(p, g, max_norm)` updates p in place and returns
+    the gradient norm before clipping (a [1] device tensor) when max_norm is given."""
+
+    def __init__(self, numel: int, lr: float = 1e-4, betas=(0.8, 0.99), eps: float = 1e-8, weight_decay: float = 0.01,
+                 gamma: float = 0.999996, device="cuda"):
+        self._lib = _lib.load()
+        self.lr0, self.betas, self.eps, self.weight_decay, self.gamma = float(lr), tuple(betas), float(eps), float(weight_decay), float(gamma)
+        self.m = torch.zeros(numel, device=device)
+        self.v = torch.zeros(numel, device=device)
+        self.t = 0
+        self._ws = torch.empty(int(self._lib.wv_train_bce_workspace_bytes()), dtype=torch.uint8, device=device)
+        self._ss = torch.zeros(1, device=device)
+
+    @property
+    def lr(self) -> float:
+        return self.lr0 * self.gamma ** self.t            # ExponentialLR: one decay per optimizer step
+
+    def step(self, p: torch.Tensor, g: torch.Tensor, max_norm=None):
+        if not (p.is_cuda and g.is_cuda and p.is_contiguous() and g.is_contiguous() and p.dtype == g.dtype == torch.float32):
+            raise RuntimeError("FlatAdamW: contiguous float32 CUDA arenas required")
+        if p.numel() != self.m.numel() or g.numel() != p.numel():
+            raise ValueError("FlatAdamW: arena size mismatch")
+        st = TrainHalf._stream()
+        norm = None
+        if max_norm is not None:
+            if self._lib.wv_train_sumsq(g.data_ptr(), g.numel(), self._ss.data_ptr(), self._ws.data_ptr(), self._ws.numel(), st) != 0:
+                raise RuntimeError(f"wv_train_sumsq: {self._lib.wv_train_last_error().decode()}")
+            norm = self._ss.sqrt()
+        lr = self.lr
+        self.t += 1
+        rc = self._lib.wv_train_adamw(p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), p.numel(), lr, self.betas[0],
+                                      self.betas[1], self.eps, self.weight_decay, self.t,
+                                      self._ss.data_ptr() if max_norm is not None else None, float(max_norm or 0.0), st)
+        if rc != 0:
+            raise RuntimeError(f"wv_train_adamw: {self._lib.wv_train_last_error().decode()}")
+        return norm
+
+
+class BlockTrainer:
+    """The closed loop of the training slices on ONE SEANetResnetBlock (scripts/train.py:1421-1480 in miniature):
+    live-weight-norm forward -> DecodingLoss on the block's output channels -> backward -> mean all-reduce of the flat
+    gradient arena across ranks (one process per GPU, RCCL) -> clip_grad_norm_ + AdamW + ExponentialLR.
+    Parameters, gradients and optimizer moments live in flat arenas; `self.params` are views into `self.arena`."""
+
+    SHAPES = (("g_pw", lambda c: (c,)), ("v_pw", lambda c: (c, c)), ("g_dw", lambda c: (c,)), ("v_dw", lambda c: (c, 5)), ("b_dw", lambda c: (c,)))
+
+    def __init__(self, channels: int, pre_scale: float = 1.0, res_scale: float = 0.5, seed: int = 0, lr: float = 1e-3,
+                 max_norm: float = 1000.0, device="cuda"):
+        C_ = int(channels)
+        self.block = TrainBlock(C_)
+        self.pre_scale, self.res_scale, self.max_norm = float(pre_scale), float(res_scale), float(max_norm)
+        n = 2 * sum(int(torch.Size(f(C_)).numel()) for _, f in self.SHAPES) + 1
+        gen = torch.Generator().manual_seed(seed)
+        self.arena = torch.empty(n, device=device)
+        self.grads = torch.zeros(n, device=device)
+        self.params, self._gviews, off = [], [], 0
+        for _ in range(2):
+            pv, gv = {}, {}
+            for name, f in self.SHAPES:
+                shape = f(C_)
+                k = int(torch.Size(shape).numel())
+                init = torch.randn(shape, generator=gen)
+                init = init.abs() + 0.5 if name.startswith("g_") else init * (0.1 if name == "b_dw" else shape[-1] ** -0.5)
+                self.arena[off:off + k] = init.reshape(-1).to(device)
+                pv[name], gv[name] = self.arena[off:off + k].view(shape), self.grads[off:off + k].view(shape)
+                off += k
+            self.params.append(pv)
+            self._gviews.append(gv)
+        self.arena[off] = 1.0
+        self.res_scale_param, self._g_rsp = self.arena[off:off + 1], self.grads[off:off + 1]
+        self.opt = FlatAdamW(n, lr=lr, device=device)
+
+    def step(self, x: torch.Tensor, mask: torch.Tensor, msg: torch.Tensor):
+        """One optimizer step on this rank's shard of the batch; returns (loss, gradient norm) as device tensors."""
+        from .parallel import allreduce_mean_flat_
+        y, saved = self.block.forward(x, self.params, self.res_scale_param, self.pre_scale, self.res_scale)
+        loss, dz = bce_logits(y, mask, msg)
+        g = self.block.backward(x, self.params, self.res_scale_param, self.pre_scale, self.res_scale, dz, saved)
+        for i in range(2):
+            for name, _ in self.SHAPES:
+                self._gviews[i][name].copy_(g["halves"][i]["d" + name if name != "b_dw" else "db_dw"].view_as(self._gviews[i][name]))
+        self._g_rsp.copy_(g["d_res_scale_param"])
+        allreduce_mean_flat_(self.grads)
+        norm = self.opt.step(self.arena, self.grads, self.max_norm)
+        return loss, norm
