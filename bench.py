@@ -232,6 +232,7 @@ def main():
     headline = a.workload == "embed_detect" and B == 256 and T == 16000
 
     def traffic_of(kernel):
+        kernel = kernel.replace(",flat", "")       # flat tiling is a launch-time property of the same kernel symbol
         if pmc and headline and kernel in pmc.get("kernels", {}):
             return round(pmc["kernels"][kernel]["traffic_bytes_per_launch"] / 1e9, 3)
         return None

@@ -26,6 +26,9 @@ def short(name: str) -> str:
         base = "convtr_pw" if ldr >= 2 else ("pw_dw_k5" if epi == 0 and res else "pw_dw_k5_nr" if epi == 0 else "pw_dw" if epi == 1 else "pw_dw_s")
         tag = "reg" if ldr else ("dma3" if ns == "3" else "dma")
         return f"{base}<{bm},{32 * int(nt)},{tag}>"          # spec_add launches share the pw_dw_k5 symbol
+    m = re.match(r"void wv::stft_k1_kernel<wv::K1<(\d+), (\d+), (\d+)>", name)
+    if m:
+        return f"stft_logmag<{m.group(3)},{32 * int(m.group(1))},k1>"
     m = re.match(r"void wv::resblock_kernel<wv::RB<(\d+), (\d+)>", name)
     if m:
         return f"resblock<{m.group(1)},{32 * int(m.group(2))}>"
