@@ -254,6 +254,31 @@ int wv_train_block_backward(wv_train_block* b, const float* x, const wv_half_par
                             const wv_half_grads* g /*[2]*/, float* d_res_scale_param, int B, int T,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* conv_pre with live weight norm (seanet.py:657-664): y[B,C,T] = causal conv1d(in_scale * x[B,1,T], g v/||v|| [C,1,ks]) + bias.
+ * backward: dg [C], dv [C,ks], db [C] and, optionally, dx [B,1,T] (the gradient towards the audio; NULL to skip). */
+typedef struct wv_train_convpre wv_train_convpre;
+int wv_train_convpre_create(int C, int ks, wv_train_convpre** out);
+void wv_train_convpre_destroy(wv_train_convpre* h);
+size_t wv_train_convpre_workspace_bytes(const wv_train_convpre* h, int B, int T);
+int wv_train_convpre_forward(wv_train_convpre* h, const float* x, const float* g, const float* v, const float* bias, float in_scale,
+                             float* y, int B, int T, void* stream);
+int wv_train_convpre_backward(wv_train_convpre* h, const float* x, const float* g, const float* v, float in_scale, const float* dy,
+                              float* dx, float* dg, float* dv, float* db, int B, int T, void* workspace, size_t workspace_bytes, void* stream);
+
+/* SpecBlock add with live weight norm (seanet.py:463-511): y[B,C,T] = x + s * ((g v/||v||)[C,F] @ P[B,F,T]),
+ * s = res_scale * scale_param[0] (scale_param: device scalar of zero_init blocks, or NULL).  P is the normalised
+ * log-magnitude STFT of the waveform (no parameters; wv_op_stft_logmag / the model's STFT kernel).  dx = dy (identity)
+ * is the caller's; backward returns dg [C], dv [C,F] and d(scale_param).  y may alias x. */
+typedef struct wv_train_spec wv_train_spec;
+int wv_train_spec_create(int C, int F, wv_train_spec** out);
+void wv_train_spec_destroy(wv_train_spec* h);
+size_t wv_train_spec_workspace_bytes(const wv_train_spec* h, int B, int T);
+int wv_train_spec_forward(wv_train_spec* h, const float* x, const float* P, const float* g, const float* v, const float* scale_param,
+                          float res_scale, float* y, int B, int T, void* stream);
+int wv_train_spec_backward(wv_train_spec* h, const float* P, const float* g, const float* v, const float* scale_param, float res_scale,
+                           const float* dy, float* dg, float* dv, float* d_scale_param, int B, int T,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* The two BCE-with-logits losses of the training step (scripts/loss.py:947-1099), forward + gradient in one pass:
  *   LocalizationLoss: msg = NULL, Cz = 1:  mean BCE(logits[B,1,T], mask[B,1,T])
  *   DecodingLoss:     mean BCE(logits[B,Cz,T], msg[B,Cz] * mask[B,1,T])        (mask NULL = all ones)

@@ -127,3 +127,30 @@ def unit_backward(x, s, g_pw, v_pw, g_dw, v_dw, b, dy, stride=1, elu=True):
     dg_pw, dv_pw = fold_backward(g_pw.astype(np.float64), v_pw.astype(np.float64), dW[:, :, None])
     dg_dw, dv_dw = fold_backward(g_dw.astype(np.float64), v_dw.astype(np.float64), dw[:, None, :])
     return dict(y=y, dx=dx, dg_pw=dg_pw, dv_pw=dv_pw, dg_dw=dg_dw, dv_dw=dv_dw, db_dw=dy.sum((0, 2)))
+
+
+def convpre_backward(x, in_scale, g, v, b, dy):
+    """conv_pre (seanet.py:657-664): y = causal conv1d(in_scale * x[B,1,T], fold(g, v)[C,1,ks]) + b -> dict(y, dx, dg, dv, db)."""
+    x = x.astype(np.float64)
+    dy = dy.astype(np.float64)
+    w = fold(g.astype(np.float64), v.astype(np.float64))[:, 0, :]          # [C, ks]
+    ks, T = w.shape[1], x.shape[2]
+    xp = np.pad(in_scale * x[:, 0, :], ((0, 0), (ks - 1, 0)))
+    y = b.astype(np.float64)[None, :, None] + sum(w[None, :, i, None] * xp[:, None, i:i + T] for i in range(ks))
+    dw = np.stack([(dy * xp[:, None, i:i + T]).sum((0, 2)) for i in range(ks)], 1)
+    dyp = np.pad(dy, ((0, 0), (0, 0), (0, ks - 1)))
+    dx = in_scale * sum((w[None, :, i, None] * dyp[:, :, ks - 1 - i:ks - 1 - i + T]).sum(1) for i in range(ks))
+    dg, dv = fold_backward(g.astype(np.float64), v.astype(np.float64), dw[:, None, :])
+    return dict(y=y, dx=dx[:, None, :], dg=dg, dv=dv, db=dy.sum((0, 2)))
+
+
+def spec_add_backward(x, P, g, v, scale_param, res_scale, dy):
+    """SpecBlock add (seanet.py:493-507): y = x + s * (fold(g, v)[C,F] @ P), s = res_scale * scale_param -> dict(y, dg, dv, d_scale_param)."""
+    P = P.astype(np.float64)
+    dy = dy.astype(np.float64)
+    W = fold(g.astype(np.float64), v.astype(np.float64))[:, :, 0]
+    sp = 1.0 if scale_param is None else float(np.asarray(scale_param).reshape(-1)[0])
+    z = np.einsum("cf,bft->bct", W, P)
+    G = np.einsum("bct,bft->cf", dy, P)
+    dg, dv = fold_backward(g.astype(np.float64), v.astype(np.float64), (res_scale * sp * G)[:, :, None])
+    return dict(y=x.astype(np.float64) + res_scale * sp * z, dg=dg, dv=dv, d_scale_param=res_scale * float((dy * z).sum()))

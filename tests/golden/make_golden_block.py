@@ -107,6 +107,63 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"grads_down_{tag}.npz"), **out)
         print(f"wrote grads_down_{tag}.npz: B={B} C={C}->{2 * C} T={T}->{y.shape[-1]} r={r}")
 
+    # ---- conv_pre (seanet.py:657-664) and the SpecBlock add (seanet.py:362-511) ------------------------------------------
+    from modules.seanet import SpecBlock
+    out = {}
+    for i, (B, C, T, ks) in enumerate(((2, 64, 400, 5), (3, 40, 37, 7))):
+        rng = np.random.default_rng(500 + i)
+        wav_std = 0.1122080159
+        cp = torch.nn.Sequential(Scale(1, value=1 / wav_std, learnable=False, inplace=False),
+                                 SConv1d(1, C, ks, norm="weight_norm", causal=True, pad_mode="constant", bias=True)).double()
+        sd = {}
+        for k, v in cp.state_dict().items():
+            a = rng.standard_normal(tuple(v.shape))
+            a = 0.5 + np.abs(a) if k.endswith("original0") else a * (0.45 if k.endswith("original1") else 0.1)
+            sd[k] = torch.from_numpy(a.astype(np.float32)).double()
+        cp.load_state_dict(sd)
+        x = torch.from_numpy((0.1 * rng.standard_normal((B, 1, T))).astype(np.float32)).double().requires_grad_(True)
+        y = cp(x)
+        dy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).double()
+        y.backward(dy)
+        p = dict(cp.named_parameters())
+        for k, t in dict(x=x, dy=dy, y=y, dx=x.grad, g=p["1.conv.conv.parametrizations.weight.original0"],
+                         v=p["1.conv.conv.parametrizations.weight.original1"], b=p["1.conv.conv.bias"],
+                         dg=p["1.conv.conv.parametrizations.weight.original0"].grad, dv=p["1.conv.conv.parametrizations.weight.original1"].grad,
+                         db=p["1.conv.conv.bias"].grad).items():
+            out[f"pre{i}_{k}"] = t.detach().numpy().astype(np.float32)
+        out[f"pre{i}_in_scale"] = np.float32(1 / wav_std)
+    for i, (B, C, T, n_fft, hop, zero_init) in enumerate(((2, 64, 64, 64, 1, True), (2, 48, 40, 128, 4, True), (1, 40, 24, 64, 2, False))):
+        rng = np.random.default_rng(600 + i)
+        sb = SpecBlock("stft", "log", n_fft, C, hop, "weight_norm", {}, False, "constant", False, causal=True, mean=-4.3, std=2.8,
+                       res_scale=0.5773503, zero_init=zero_init, inout_norm=True).double()
+        sd = dict(sb.state_dict())
+        for k, v in sd.items():
+            if k.endswith("original0"):
+                sd[k] = torch.from_numpy((0.5 + np.abs(rng.standard_normal(tuple(v.shape)))).astype(np.float32)).double()
+            elif k.endswith("original1"):
+                sd[k] = torch.from_numpy((rng.standard_normal(tuple(v.shape)) * v.shape[1] ** -0.5).astype(np.float32)).double()
+            elif k == "scale_param":
+                sd[k] = torch.tensor([0.8], dtype=torch.float64)
+        sb.load_state_dict(sd)
+        wav = torch.from_numpy((0.1 * rng.standard_normal((B, 1, T * hop))).astype(np.float32)).double()
+        x = torch.from_numpy(rng.standard_normal((B, C, T)).astype(np.float32)).double().requires_grad_(True)
+        with torch.no_grad():
+            P = sb.spec(wav).clamp_min(1e-5).log_().sub_(sb.mean).div_(sb.std)
+        y = sb(x * 1.0, wav)
+        dy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).double()
+        y.backward(dy)
+        p = dict(sb.named_parameters())
+        items = dict(x=x, wav=wav, P=P, dy=dy, y=y, dx=x.grad, g=p["layer.conv.conv.parametrizations.weight.original0"],
+                     v=p["layer.conv.conv.parametrizations.weight.original1"], dg=p["layer.conv.conv.parametrizations.weight.original0"].grad,
+                     dv=p["layer.conv.conv.parametrizations.weight.original1"].grad)
+        if zero_init:
+            items.update(scale_param=p["scale_param"], d_scale_param=p["scale_param"].grad)
+        for k, t in items.items():
+            out[f"spec{i}_{k}"] = t.detach().numpy().astype(np.float32)
+        out[f"spec{i}_meta"] = np.array([n_fft, hop, 0.5773503, -4.3, 2.8])
+    np.savez_compressed(os.path.join(HERE, "grads_pre_spec.npz"), **out)
+    print("wrote grads_pre_spec.npz", len(out), "arrays")
+
     # ---- losses ----------------------------------------------------------------------------------------------------
     sys.modules["audiotools"] = types.ModuleType("audiotools")
     sys.modules["audiotools"].AudioSignal = type("AudioSignal", (), {})

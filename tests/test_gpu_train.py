@@ -260,3 +260,67 @@ def test_block_trainer_closed_loop():
     assert la == lb and torch.equal(a.arena, b.arena)
     assert la[-1] < 0.8 * la[0] and all(np.isfinite(la)) and bool(torch.isfinite(a.arena).all())
     assert a.opt.t == 25 and abs(a.opt.lr - 5e-3 * 0.999996 ** 25) < 1e-12
+
+
+# ---- conv_pre and the SpecBlock add -----------------------------------------------------------------------------------
+def test_convpre_gradients_vs_reference_autograd_and_oracle(golden_dir):
+    from waveverify_amd.train import TrainConvPre
+    f = np.load(os.path.join(golden_dir, "grads_pre_spec.npz"))
+    for i in range(2):
+        x, dy, s = f[f"pre{i}_x"], f[f"pre{i}_dy"], float(f[f"pre{i}_in_scale"])
+        p = {k: _cu(f[f"pre{i}_{k}"]) for k in ("g", "v", "b")}
+        u = TrainConvPre(dy.shape[1], f[f"pre{i}_v"].shape[-1])
+        assert rel(u.forward(_cu(x), p, s), f[f"pre{i}_y"]) <= 2e-5
+        g = u.backward(_cu(x), p, s, _cu(dy), need_dx=True)
+        for k in ("dx", "dg", "dv", "db"):
+            assert rel(g[k], f[f"pre{i}_{k}"]) <= 1e-4, (i, k)
+        assert u.backward(_cu(x), p, s, _cu(dy))["dx"] is None
+    # the detector's first layer at the training batch: 64 clips x 1 s, C = 64
+    rng = np.random.default_rng(1)
+    B, C, T, ks = 64, 64, 16000, 5
+    x = (0.1 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    dy = rng.standard_normal((B, C, T)).astype(np.float32)
+    p = dict(g=(0.5 + np.abs(rng.standard_normal((C, 1, 1)))).astype(np.float32), v=(0.45 * rng.standard_normal((C, 1, ks))).astype(np.float32),
+             b=(0.1 * rng.standard_normal(C)).astype(np.float32))
+    ref = OT.convpre_backward(x, 8.912, p["g"], p["v"], p["b"], dy)
+    u = TrainConvPre(C, ks)
+    pt = {k: _cu(v) for k, v in p.items()}
+    assert rel(u.forward(_cu(x), pt, 8.912), ref["y"]) <= 2e-5
+    g = u.backward(_cu(x), pt, 8.912, _cu(dy), need_dx=True)
+    g2 = u.backward(_cu(x), pt, 8.912, _cu(dy), need_dx=True)
+    for k in ("dx", "dg", "dv", "db"):
+        assert rel(g[k], ref[k]) <= 1e-4 and torch.equal(g[k], g2[k]), k
+
+
+def test_spec_add_gradients_vs_reference_autograd_and_oracle(golden_dir):
+    from waveverify_amd import ops
+    from waveverify_amd.train import TrainSpecAdd
+    f = np.load(os.path.join(golden_dir, "grads_pre_spec.npz"))
+    for i in range(3):
+        n_fft, hop, rs, mean, std = f[f"spec{i}_meta"]
+        sp = _cu(f[f"spec{i}_scale_param"]) if f"spec{i}_scale_param" in f else None
+        # features from OUR STFT kernel on the fixture's waveform, as the training step would produce them
+        P = ops.stft_logmag(_cu(f[f"spec{i}_wav"]), int(n_fft), int(hop), mean=float(mean), std=float(std))
+        p = {k: _cu(f[f"spec{i}_{k}"]) for k in ("g", "v")}
+        u = TrainSpecAdd(f[f"spec{i}_x"].shape[1], int(n_fft) // 2 + 1)
+        y = u.forward(_cu(f[f"spec{i}_x"]), P, p, sp, float(rs))
+        assert rel(y, f[f"spec{i}_y"]) <= 5e-5
+        g = u.backward(P, p, sp, float(rs), _cu(f[f"spec{i}_dy"]))
+        for k in ("dg", "dv"):
+            assert rel(g[k], f[f"spec{i}_{k}"]) <= 2e-4, (i, k)
+        if sp is not None:
+            ref = float(f[f"spec{i}_d_scale_param"][0])
+            assert abs(float(g["d_scale_param"].item()) - ref) <= 2e-4 * max(1.0, abs(ref))
+    # a detector scale at the training batch against the oracle: C = 256, F = 129, T = 2000
+    rng = np.random.default_rng(2)
+    B, C, F, T = 16, 256, 129, 2000
+    x, P, dy = (rng.standard_normal(s).astype(np.float32) for s in ((B, C, T), (B, F, T), (B, C, T)))
+    p = dict(g=(0.5 + np.abs(rng.standard_normal((C, 1, 1)))).astype(np.float32), v=(rng.standard_normal((C, F, 1)) * F ** -0.5).astype(np.float32))
+    spn = np.array([0.7], np.float32)
+    ref = OT.spec_add_backward(x, P, p["g"], p["v"], spn, 0.5773503, dy)
+    u = TrainSpecAdd(C, F)
+    pt = {k: _cu(v) for k, v in p.items()}
+    assert rel(u.forward(_cu(x), _cu(P), pt, _cu(spn), 0.5773503), ref["y"]) <= 2e-5
+    g = u.backward(_cu(P), pt, _cu(spn), 0.5773503, _cu(dy))
+    assert rel(g["dg"], ref["dg"]) <= 1e-4 and rel(g["dv"], ref["dv"]) <= 1e-4
+    assert abs(float(g["d_scale_param"].item()) - ref["d_scale_param"]) <= 1e-4 * abs(ref["d_scale_param"])

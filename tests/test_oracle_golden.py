@@ -261,3 +261,28 @@ def test_train_oracle_downsample_unit_vs_reference_autograd(golden_dir, tag):
     h = np.load(os.path.join(golden_dir, "grads_half_c64.npz"))
     r = OT.unit_backward(h["x"], float(h["pre_scale"]), h["g_pw"], h["v_pw"], h["g_dw"], h["v_dw"], h["b_dw"], h["dy"])
     assert float(np.abs(r["dx"] - h["dx"]).max() / np.abs(h["dx"]).max()) <= 2e-6
+
+
+def test_train_oracle_convpre_and_spec_add_vs_reference_autograd(golden_dir):
+    from oracle import wv_oracle_train as OT
+    g = np.load(os.path.join(golden_dir, "grads_pre_spec.npz"))
+
+    def rel(a, b):
+        return float(np.abs(np.asarray(a).reshape(b.shape) - b).max() / max(np.abs(b).max(), 1e-30))
+    for i in range(2):
+        r = OT.convpre_backward(g[f"pre{i}_x"], float(g[f"pre{i}_in_scale"]), g[f"pre{i}_g"], g[f"pre{i}_v"], g[f"pre{i}_b"], g[f"pre{i}_dy"])
+        for k in ("y", "dx", "dg", "dv", "db"):
+            assert rel(r[k], g[f"pre{i}_{k}"]) <= 2e-6, (i, k)
+    for i in range(3):
+        n_fft, hop, rs, mean, std = g[f"spec{i}_meta"]
+        sp = g[f"spec{i}_scale_param"] if f"spec{i}_scale_param" in g else None
+        # the features the unit consumes are the reference's own (CausalSTFT -> log -> normalise); the oracle's STFT matches them
+        mag = O.causal_stft_mag(g[f"spec{i}_wav"], int(n_fft), int(hop))
+        P = ((np.log(np.maximum(mag, np.float32(1e-5))) - np.float32(mean)) / np.float32(std)).astype(np.float32)
+        assert np.abs(P - g[f"spec{i}_P"]).max() <= 5e-3 and np.abs(P - g[f"spec{i}_P"])[mag > 1e-3].max() <= 2e-5
+        r = OT.spec_add_backward(g[f"spec{i}_x"], g[f"spec{i}_P"], g[f"spec{i}_g"], g[f"spec{i}_v"], sp, float(rs), g[f"spec{i}_dy"])
+        for k in ("y", "dg", "dv"):
+            assert rel(r[k], g[f"spec{i}_{k}"]) <= 2e-6, (i, k)
+        assert np.array_equal(g[f"spec{i}_dx"], g[f"spec{i}_dy"])                    # identity path
+        if sp is not None:
+            assert rel(r["d_scale_param"], g[f"spec{i}_d_scale_param"]) <= 2e-6

@@ -61,6 +61,16 @@ SIGNATURES = {
     "wv_train_unit_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_int, _VP, C.c_int, C.c_int, _VP]),
     "wv_train_unit_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                          C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_train_convpre_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_VP)]),
+    "wv_train_convpre_destroy": (None, [_VP]),
+    "wv_train_convpre_workspace_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),
+    "wv_train_convpre_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_float, _VP, C.c_int, C.c_int, _VP]),
+    "wv_train_convpre_backward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_train_spec_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_VP)]),
+    "wv_train_spec_destroy": (None, [_VP]),
+    "wv_train_spec_workspace_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),
+    "wv_train_spec_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, C.c_int, C.c_int, _VP]),
+    "wv_train_spec_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     "wv_train_block_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "wv_train_block_destroy": (None, [_VP]),
     "wv_train_block_saved_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),

@@ -33,7 +33,8 @@ namespace wv {
 __global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ g, const float* __restrict__ v,
                                                       float* __restrict__ w, float* __restrict__ inv_norm,
                                                       float* __restrict__ wq, float* __restrict__ wqT,
-                                                      int M, int K, int Mp, int KpT) {
+                                                      int M, int K, int Mp, int KpT,
+                                                      const float* __restrict__ pack_param = nullptr, float pack_scale = 1.f) {
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x;
     const float* vr = v + (size_t)m * K;
@@ -49,8 +50,9 @@ __global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ 
     for (int k = tid; k < K; k += 256) {
         const float x = vr[k] * sc;
         w[(size_t)m * K + k] = x;
-        if (wq) wq[((size_t)(k >> 2) * Mp + m) * 4 + (k & 3)] = x;
-        if (wqT) wqT[((size_t)(m >> 2) * KpT + k) * 4 + (m & 3)] = x;
+        const float xs = x * (pack_param ? pack_scale * pack_param[0] : pack_scale);   // a scalar folded into the GEMM operand only
+        if (wq) wq[((size_t)(k >> 2) * Mp + m) * 4 + (k & 3)] = xs;
+        if (wqT) wqT[((size_t)(m >> 2) * KpT + k) * 4 + (m & 3)] = xs;
     }
 }
 
@@ -82,23 +84,25 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ g
 constexpr int TRAIN_MAX_KS = 16;
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ h,
                                                      const float* __restrict__ w, float* __restrict__ dh,
-                                                     float* __restrict__ partial, int M, int Tin, int Tout, int ks, int stride, int pad) {
+                                                     float* __restrict__ partial, int M, int Tin, int Tout, int ks, int stride, int pad,
+                                                     int h_shared = 0) {
     __shared__ float red[4][TRAIN_MAX_KS + 1];
     const int m = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const size_t row_h = ((size_t)b * M + m) * Tin, row_y = ((size_t)b * M + m) * Tout;
+    // h_shared: one input row per clip feeds every channel (conv_pre: h = the waveform); dh may be null
+    const size_t row_h = h_shared ? (size_t)b * Tin : ((size_t)b * M + m) * Tin, row_y = ((size_t)b * M + m) * Tout;
     const float* dyr = dy + row_y;
     const float* hr = h + row_h;
     float wt[TRAIN_MAX_KS];
 #pragma unroll
     for (int i = 0; i < TRAIN_MAX_KS; ++i) wt[i] = i < ks ? w[m * ks + i] : 0.f;
-    for (int t = tid; t < Tin; t += 256) {
+    for (int t = tid; dh && t < Tin; t += 256) {
         float g = 0.f;
 #pragma unroll
         for (int i = 0; i < TRAIN_MAX_KS; ++i) {
             const int u = t + pad - i;
             if (i < ks && u >= 0 && u % stride == 0 && u / stride < Tout) g = fmaf(wt[i], dyr[u / stride], g);
         }
-        dh[row_h + t] = g;
+        dh[((size_t)b * M + m) * Tin + t] = g;
     }
     float acc[TRAIN_MAX_KS + 1];
 #pragma unroll
@@ -135,10 +139,11 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
 }
 
 // tap / bias gradient rows: dwdb[m][0..ks] -> dw_dw[m][ks] and db[m]
-__global__ void split_dwdb_kernel(const float* __restrict__ dwdb, float* __restrict__ dw, float* __restrict__ db, int M, int ks) {
+__global__ void split_dwdb_kernel(const float* __restrict__ dwdb, float* __restrict__ dw, float* __restrict__ db, int M, int ks,
+                                  float tap_scale = 1.f) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
-    for (int i = 0; i < ks; ++i) dw[m * ks + i] = dwdb[m * (ks + 1) + i];
+    for (int i = 0; i < ks; ++i) dw[m * ks + i] = dwdb[m * (ks + 1) + i] * tap_scale;
     db[m] = dwdb[m * (ks + 1) + ks];
 }
 
@@ -258,6 +263,38 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float4* __restrict__ d
     if (i >= n4) return;
     const float4 a = dx[i], b = dy[i];
     dx[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// ---- conv_pre backward towards the waveform: dx[b,t] = in_scale * sum_c sum_i w[c][i] * dy[b,c,t + (ks-1) - i] ----------
+__global__ __launch_bounds__(256) void convpre_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                          int C, int T, int ks, float in_scale) {
+    extern __shared__ float wl[];                                   // [C][ks]
+    for (int i = threadIdx.x; i < C * ks; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (t >= T) return;
+    const float* dyb = dy + (size_t)b * C * T;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c)
+        for (int i = 0; i < ks; ++i) {
+            const int u = t + (ks - 1) - i;
+            if (u < T) acc = fmaf(wl[c * ks + i], dyb[(size_t)c * T + u], acc);
+        }
+    dx[(size_t)b * T + t] = acc * in_scale;
+}
+
+// out[0] = scale * sum_i a[i] * b[i]  (one workgroup, fixed order);  buf *= res_s(param, res_scale)
+__global__ __launch_bounds__(256) void dot_small_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, float scale,
+                                                         float* __restrict__ out) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 256) acc = fmaf(a[i], b[i], acc);
+    const float t = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[0] = t * scale;
+}
+__global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ buf, size_t n, const float* __restrict__ param, float res_scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) buf[i] *= res_s(param, res_scale);
 }
 
 // ---- optimizer step over a FLAT parameter arena (scripts/train.py:1346-1358, conf/base.yml:128-130) ------------------
@@ -556,6 +593,133 @@ int wv_train_bce_logits(const float* logits, const float* mask, const float* msg
     hipLaunchKernelGGL(wv::bce_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, logits, mask, msg, dlogits, (float*)ws,
                        grad_scale / (float)n, Cz, T, n);
     hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, wv::RED_BLOCKS, 1.f / (float)n, loss);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+// ---- conv_pre: y = conv1d(in_scale * x[B,1,T], W(g,v)[C,1,ks]) + b, causal (seanet.py:657-664) ------------------------------
+struct wv_train_convpre {
+    int C = 0, ks = 0;
+    float *w = nullptr, *inv = nullptr, *dwdb = nullptr, *taps = nullptr;
+    std::vector<void*> owned;
+    ~wv_train_convpre() { for (void* p : owned) (void)hipFree(p); }
+};
+
+int wv_train_convpre_create(int C, int ks, wv_train_convpre** out) {
+    if (!out || C < 1 || C > 4096 || ks < 1 || ks > wv::TRAIN_MAX_KS) return tfail(WV_EINVAL, "bad channel count / kernel size");
+    auto* h = new wv_train_convpre();
+    h->C = C; h->ks = ks;
+    auto alloc = [&](float** p, size_t n) {
+        if (hipMalloc((void**)p, n * sizeof(float)) != hipSuccess) return false;
+        h->owned.push_back(*p);
+        return true;
+    };
+    if (!(alloc(&h->w, (size_t)C * ks) && alloc(&h->inv, C) && alloc(&h->dwdb, (size_t)C * (ks + 1)) && alloc(&h->taps, (size_t)C * ks))) {
+        delete h;
+        return tfail(WV_EHIP, "device allocation failed");
+    }
+    *out = h;
+    return WV_OK;
+}
+void wv_train_convpre_destroy(wv_train_convpre* h) { delete h; }
+size_t wv_train_convpre_workspace_bytes(const wv_train_convpre* h, int B, int T) {
+    return (h && B > 0 && T > 0) ? al256((size_t)B * h->C * (h->ks + 1) * 4) : 0;
+}
+
+int wv_train_convpre_forward(wv_train_convpre* h, const float* x, const float* g, const float* v, const float* bias, float in_scale,
+                             float* y, int B, int T, void* stream) {
+    if (!h || !x || !g || !v || !y || B < 1 || T < 1) return tfail(WV_EINVAL, "null / bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->C), dim3(256), 0, s, g, v, h->w, h->inv, (float*)nullptr, (float*)nullptr, h->C, h->ks, 0, 0,
+                       (const float*)nullptr, 1.f);
+    T_LAUNCH(hipGetLastError());
+    T_LAUNCH(wv::launch_conv_pre(x, h->w, bias, y, nullptr, 0.f, B, h->C, T, h->ks, in_scale, s));
+    return WV_OK;
+}
+
+int wv_train_convpre_backward(wv_train_convpre* h, const float* x, const float* g, const float* v, float in_scale, const float* dy,
+                              float* dx, float* dg, float* dv, float* db, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !x || !g || !v || !dy || !dg || !dv || !db) return tfail(WV_EINVAL, "null argument");
+    if (B < 1 || T < 1 || !ws || ws_bytes < wv_train_convpre_workspace_bytes(h, B, T)) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = h->C, ks = h->ks;
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(C), dim3(256), 0, s, g, v, h->w, h->inv, (float*)nullptr, (float*)nullptr, C, ks, 0, 0,
+                       (const float*)nullptr, 1.f);
+    // per-clip partial sums of dW[c][i] = sum_t dy[c][t] x[t - (ks-1) + i] and of db, then the fixed-order sum over clips
+    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(C, B), dim3(256), 0, s, dy, x, h->w, (float*)nullptr, (float*)ws, C, T, T, ks, 1, ks - 1, 1);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((C * (ks + 1) + 255) / 256), dim3(256), 0, s, (const float*)ws, h->dwdb, B, (size_t)C * (ks + 1));
+    hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((C + 255) / 256), dim3(256), 0, s, h->dwdb, h->taps, db, C, ks, in_scale);
+    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g, v, h->inv, h->taps, dg, dv, ks);
+    if (dx) hipLaunchKernelGGL(wv::convpre_dx_kernel, dim3((T + 255) / 256, B), dim3(256), (size_t)C * ks * 4, s, dy, h->w, dx, C, T, ks, in_scale);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+// ---- SpecBlock add: y = x + s * (W(g,v)[C,F] @ P[B,F,T]),  s = res_scale * scale_param[0] (seanet.py:463-511) ----------------
+struct wv_train_spec {
+    int C = 0, F = 0, Mp = 0;
+    float *w = nullptr, *inv = nullptr, *wq = nullptr, *dW = nullptr, *id_taps = nullptr;
+    std::vector<void*> owned;
+    ~wv_train_spec() { for (void* p : owned) (void)hipFree(p); }
+};
+
+int wv_train_spec_create(int C, int F, wv_train_spec** out) {
+    if (!out || C < 1 || C > 4096 || F < 1 || F > 4096) return tfail(WV_EINVAL, "bad channel count");
+    auto* h = new wv_train_spec();
+    h->C = C; h->F = F; h->Mp = wv::round_up(C, wv::M_ALIGN);
+    auto alloc = [&](float** p, size_t n, bool zero) {
+        if (hipMalloc((void**)p, n * sizeof(float)) != hipSuccess) return false;
+        h->owned.push_back(*p);
+        return !zero || hipMemset(*p, 0, n * sizeof(float)) == hipSuccess;
+    };
+    std::vector<float> taps((size_t)C * 5, 0.f);
+    for (int m = 0; m < C; ++m) taps[(size_t)m * 5 + 4] = 1.f;
+    bool ok = alloc(&h->w, (size_t)C * F, false) && alloc(&h->inv, C, false) && alloc(&h->wq, (size_t)wv::round_up(F, 32) * h->Mp, true) &&
+              alloc(&h->dW, (size_t)C * F, false) && alloc(&h->id_taps, taps.size(), false) &&
+              hipMemcpy(h->id_taps, taps.data(), taps.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { delete h; return tfail(WV_EHIP, "device allocation failed"); }
+    *out = h;
+    return WV_OK;
+}
+void wv_train_spec_destroy(wv_train_spec* h) { delete h; }
+size_t wv_train_spec_workspace_bytes(const wv_train_spec* h, int B, int T) {
+    return (h && B > 0 && T > 0) ? al256((size_t)nt_splits(B) * h->C * h->F * 4) : 0;
+}
+
+int wv_train_spec_forward(wv_train_spec* h, const float* x, const float* P, const float* g, const float* v, const float* scale_param,
+                          float res_scale, float* y, int B, int T, void* stream) {
+    if (!h || !x || !P || !g || !v || !y || B < 1 || T < 1) return tfail(WV_EINVAL, "null / bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    // the scalar s rides in the GEMM operand: wq = s * W
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->C), dim3(256), 0, s, g, v, h->w, h->inv, h->wq, (float*)nullptr, h->C, h->F, h->Mp, 0,
+                       scale_param, res_scale);
+    T_LAUNCH(hipGetLastError());
+    wv::PwDwArgs a{};
+    a.X = P; a.pw.M = h->C; a.pw.K = h->F; a.pw.Mp = h->Mp; a.pw.Kp = wv::round_up(h->F, wv::BK); a.pw.wq = h->wq;
+    a.dw_w = h->id_taps; a.dw_b = nullptr; a.resid = x; a.Y = y;
+    a.B = B; a.Tin = T; a.Tout = T; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
+    a.pre_scale = 1.f; a.pre_elu = 0; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
+    if (!wv::k1_supported(a)) return tfail(WV_EINVAL, SHAPE_MSG);
+    T_LAUNCH(wv::launch_pw_dw(a, s));
+    return WV_OK;
+}
+
+int wv_train_spec_backward(wv_train_spec* h, const float* P, const float* g, const float* v, const float* scale_param, float res_scale,
+                           const float* dy, float* dg, float* dv, float* d_scale_param, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !P || !g || !v || !dy || !dg || !dv) return tfail(WV_EINVAL, "null argument");
+    if (scale_param && !d_scale_param) return tfail(WV_EINVAL, "scale_param without a gradient slot");
+    if (B < 1 || T < 1 || !ws || ws_bytes < wv_train_spec_workspace_bytes(h, B, T)) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = h->C, F = h->F, S = nt_splits(B);
+    const size_t n = (size_t)C * F;
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(C), dim3(256), 0, s, g, v, h->w, h->inv, (float*)nullptr, (float*)nullptr, C, F, 0, 0,
+                       (const float*)nullptr, 1.f);
+    // G = sum_{b,t} dy P^T;  d scale_param = res_scale * <W, G>  (= res_scale * sum dy . (W @ P));  dW = s * G
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((C + 63) / 64, (F + 63) / 64, S), dim3(256), 0, s, dy, P, (float*)ws, 1.f, 0, B, C, F, T);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws, h->dW, S, n);
+    if (d_scale_param) hipLaunchKernelGGL(wv::dot_small_kernel, dim3(1), dim3(256), 0, s, h->w, h->dW, n, res_scale, d_scale_param);
+    hipLaunchKernelGGL(wv::scale_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dW, n, scale_param, res_scale);
+    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g, v, h->inv, h->dW, dg, dv, F);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }

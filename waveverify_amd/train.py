@@ -131,6 +131,94 @@ class TrainUnit:
             pass
 
 
+class _Handle:
+    """Owner of one wv_train_* handle."""
+    _create = _destroy = ""
+
+    def _open(self, *args):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        if getattr(self._lib, self._create)(*args, C.byref(self._h)) != 0:
+            raise RuntimeError(f"{self._create}: {self._lib.wv_train_last_error().decode()}")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self._lib.wv_train_last_error().decode()}")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                getattr(self._lib, self._destroy)(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+class TrainConvPre(_Handle):
+    """conv_pre with live weight norm (/root/reference/modules/seanet.py:657-664): Scale(1/wav_std) -> causal SConv1d(1, C, ks).
+    params: g [C], v [C,ks], b [C]."""
+    _create, _destroy = "wv_train_convpre_create", "wv_train_convpre_destroy"
+
+    def __init__(self, channels: int, ks: int):
+        self.C, self.ks = int(channels), int(ks)
+        self._open(self.C, self.ks)
+
+    def forward(self, x, p, in_scale: float):
+        x = _f(x)
+        B, _, T = x.shape
+        g, v, b = _f(p["g"]).reshape(self.C), _f(p["v"]).reshape(self.C, self.ks), _f(p["b"]).reshape(self.C)
+        y = torch.empty(B, self.C, T, device=x.device)
+        self._check(self._lib.wv_train_convpre_forward(self._h, x.data_ptr(), g.data_ptr(), v.data_ptr(), b.data_ptr(), float(in_scale),
+                                                       y.data_ptr(), B, T, TrainHalf._stream()), "wv_train_convpre_forward")
+        return y
+
+    def backward(self, x, p, in_scale: float, dy, need_dx: bool = False):
+        x, dy = _f(x), _f(dy)
+        B, _, T = x.shape
+        g, v = _f(p["g"]).reshape(self.C), _f(p["v"]).reshape(self.C, self.ks)
+        out = dict(dx=torch.empty_like(x) if need_dx else None, dg=torch.empty_like(g), dv=torch.empty_like(v), db=torch.empty_like(g))
+        ws = torch.empty(int(self._lib.wv_train_convpre_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=x.device)
+        self._check(self._lib.wv_train_convpre_backward(
+            self._h, x.data_ptr(), g.data_ptr(), v.data_ptr(), float(in_scale), dy.data_ptr(), out["dx"].data_ptr() if need_dx else None,
+            out["dg"].data_ptr(), out["dv"].data_ptr(), out["db"].data_ptr(), B, T, ws.data_ptr(), ws.numel(), TrainHalf._stream()),
+            "wv_train_convpre_backward")
+        return out
+
+
+class TrainSpecAdd(_Handle):
+    """SpecBlock add with live weight norm (/root/reference/modules/seanet.py:463-511): y = x + res_scale * scale_param *
+    (W(g,v)[C,F] @ P), P = the normalised log-magnitude STFT features [B,F,T].  params: g [C], v [C,F]; scale_param [1] or None."""
+    _create, _destroy = "wv_train_spec_create", "wv_train_spec_destroy"
+
+    def __init__(self, channels: int, bins: int):
+        self.C, self.F = int(channels), int(bins)
+        self._open(self.C, self.F)
+
+    def forward(self, x, P, p, scale_param, res_scale: float):
+        x, P = _f(x), _f(P)
+        B, _, T = x.shape
+        g, v = _f(p["g"]).reshape(self.C), _f(p["v"]).reshape(self.C, self.F)
+        sp = None if scale_param is None else _f(scale_param).reshape(1)
+        y = torch.empty_like(x)
+        self._check(self._lib.wv_train_spec_forward(self._h, x.data_ptr(), P.data_ptr(), g.data_ptr(), v.data_ptr(),
+                                                    None if sp is None else sp.data_ptr(), float(res_scale), y.data_ptr(), B, T,
+                                                    TrainHalf._stream()), "wv_train_spec_forward")
+        return y
+
+    def backward(self, P, p, scale_param, res_scale: float, dy):
+        P, dy = _f(P), _f(dy)
+        B, _, T = dy.shape
+        g, v = _f(p["g"]).reshape(self.C), _f(p["v"]).reshape(self.C, self.F)
+        sp = None if scale_param is None else _f(scale_param).reshape(1)
+        out = dict(dg=torch.empty_like(g), dv=torch.empty_like(v), d_scale_param=None if sp is None else torch.empty(1, device=dy.device))
+        ws = torch.empty(int(self._lib.wv_train_spec_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=dy.device)
+        self._check(self._lib.wv_train_spec_backward(
+            self._h, P.data_ptr(), g.data_ptr(), v.data_ptr(), None if sp is None else sp.data_ptr(), float(res_scale), dy.data_ptr(),
+            out["dg"].data_ptr(), out["dv"].data_ptr(), None if sp is None else out["d_scale_param"].data_ptr(), B, T, ws.data_ptr(),
+            ws.numel(), TrainHalf._stream()), "wv_train_spec_backward")
+        return out
+
+
 class _HalfParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("g_pw", "v_pw", "g_dw", "v_dw", "bias")]
 
