@@ -207,7 +207,7 @@ int wv_model_film(wv_model* m, const float* msg, int msg_rows, float* film, int 
  *     y = DW5( (g_pw v_pw/||v_pw||) @ ELU(pre_scale * x) ; g_dw v_dw/||v_dw|| ) + bias
  * ALL pointers are DEVICE pointers (parameters live on the GPU while training): x, y, dy, dx [B,C,T];
  * g_pw [C], v_pw [C,C] (the 1x1), g_dw [C], v_dw [C,5] (the depth-wise conv), bias [C]; gradients have the
- * shapes of what they differentiate.  Needs C >= 33, T % 4 == 0, 16-byte aligned tensors.
+ * shapes of what they differentiate.  Any C and T: shapes off the LDS-DMA core's grid (C <= 32, T % 4 != 0) run on the round-1 core.
  * The weight-norm fold runs on the device in every call (wv_train_half_forward and _backward both fold). */
 typedef struct wv_train_unit wv_train_unit;
 typedef wv_train_unit wv_train_half;

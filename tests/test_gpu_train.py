@@ -61,14 +61,22 @@ def test_half_block_gradients_vs_oracle(B, C, T):
         assert rel(g[k], ref[k]) <= 1e-4, (k, rel(g[k], ref[k]))
 
 
-def test_training_slice_rejects_unsupported_shapes():
-    from waveverify_amd.train import TrainHalf
+def test_training_slice_errors_are_loud():
+    """Ragged lengths are served by the round-1 core (covered by test_unit_gradients_vs_oracle); what is rejected:
+    CPU tensors, bad geometry, and whole blocks at T % 4 != 0 (their glue kernels are 16-byte vectorised)."""
+    from waveverify_amd.train import TrainBlock, TrainHalf, TrainUnit
     half = TrainHalf(64)
-    x = torch.randn(1, 64, 10, device="cuda")                     # T % 4 != 0
     p = dict(g_pw=torch.ones(64, device="cuda"), v_pw=torch.randn(64, 64, device="cuda"), g_dw=torch.ones(64, device="cuda"),
              v_dw=torch.randn(64, 5, device="cuda"), b_dw=torch.zeros(64, device="cuda"))
+    assert half.forward(torch.randn(1, 64, 10, device="cuda"), p, 1.0).shape == (1, 64, 10)
+    with pytest.raises(RuntimeError, match="GPU"):
+        half.forward(torch.randn(1, 64, 16), p, 1.0)
+    with pytest.raises(RuntimeError, match="kernel size"):
+        TrainUnit(64, 64, 17, 1)
+    with pytest.raises(RuntimeError, match="kernel size"):
+        TrainUnit(64, 64, 2, 4)
     with pytest.raises(RuntimeError, match="T % 4"):
-        half.forward(x, p, 1.0)
+        TrainBlock(64).forward(torch.randn(1, 64, 10, device="cuda"), [p, p], None, 1.0, 0.5)
 
 
 # ---- whole SEANetResnetBlock ----------------------------------------------------------------------------------------
@@ -194,7 +202,9 @@ def test_downsample_unit_gradients_vs_reference_autograd(golden_dir, tag):
 
 
 @pytest.mark.parametrize("B,K,M,T,ks,stride,elu", [(4, 64, 128, 16000, 4, 2, True), (3, 128, 256, 8000, 8, 4, True), (2, 256, 512, 2000, 10, 5, True),
-                                                   (2, 512, 1024, 400, 16, 8, True), (3, 96, 64, 404, 5, 1, False), (2, 64, 128, 36, 7, 3, True)])
+                                                   (2, 512, 1024, 400, 16, 8, True), (3, 96, 64, 404, 5, 1, False), (2, 64, 128, 36, 7, 3, True),
+                                                   # ragged lengths and narrow layers leave the LDS-DMA core: the locator's first stage (C = 32), T = 50
+                                                   (3, 32, 32, 50, 5, 1, True), (2, 32, 64, 1001, 16, 8, True), (2, 512, 1024, 50, 4, 2, True), (2, 24, 40, 7, 5, 1, False)])
 def test_unit_gradients_vs_oracle(B, K, M, T, ks, stride, elu):
     rng = np.random.default_rng(K + M + T)
     x = rng.standard_normal((B, K, T)).astype(np.float32)
@@ -311,9 +321,14 @@ def test_spec_add_gradients_vs_reference_autograd_and_oracle(golden_dir):
         if sp is not None:
             ref = float(f[f"spec{i}_d_scale_param"][0])
             assert abs(float(g["d_scale_param"].item()) - ref) <= 2e-4 * max(1.0, abs(ref))
-    # a detector scale at the training batch against the oracle: C = 256, F = 129, T = 2000
+    # a detector scale at the training batch against the oracle (C = 256, F = 129, T = 2000) and spec_post's shape (T = 50)
+    for B, C, F, T in ((16, 256, 129, 2000), (4, 1024, 513, 50)):
+        _spec_vs_oracle(B, C, F, T)
+
+
+def _spec_vs_oracle(B, C, F, T):
+    from waveverify_amd.train import TrainSpecAdd
     rng = np.random.default_rng(2)
-    B, C, F, T = 16, 256, 129, 2000
     x, P, dy = (rng.standard_normal(s).astype(np.float32) for s in ((B, C, T), (B, F, T), (B, C, T)))
     p = dict(g=(0.5 + np.abs(rng.standard_normal((C, 1, 1)))).astype(np.float32), v=(rng.standard_normal((C, F, 1)) * F ** -0.5).astype(np.float32))
     spn = np.array([0.7], np.float32)

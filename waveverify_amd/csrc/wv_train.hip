@@ -29,12 +29,14 @@ namespace wv {
 
 // ---- weight-norm fold (conv.py:73-74: norm over all dims but 0) ------------------------------------------------
 // v [M][K], g [M] -> w [M][K] (plain), inv_norm [M]; optional packs: wq[k/4][Mp][4] (A operand of W @ X) and
-// wqT[m/4][Kp'][4] (A operand of W^T @ X, Kp' = padded K as the row count).  Padding is zeroed once by the host.
+// wqT[m/4][Kp'][4] (A operand of W^T @ X, Kp' = padded K as the row count), and their K-major twins wt[k][Mp] /
+// wtT[m][Kp'] for the round-1 core that takes over at ragged lengths.  Padding is zeroed once by the host.
 __global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ g, const float* __restrict__ v,
                                                       float* __restrict__ w, float* __restrict__ inv_norm,
                                                       float* __restrict__ wq, float* __restrict__ wqT,
                                                       int M, int K, int Mp, int KpT,
-                                                      const float* __restrict__ pack_param = nullptr, float pack_scale = 1.f) {
+                                                      const float* __restrict__ pack_param = nullptr, float pack_scale = 1.f,
+                                                      float* __restrict__ wt = nullptr, float* __restrict__ wtT = nullptr) {
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x;
     const float* vr = v + (size_t)m * K;
@@ -53,6 +55,8 @@ __global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ 
         const float xs = x * (pack_param ? pack_scale * pack_param[0] : pack_scale);   // a scalar folded into the GEMM operand only
         if (wq) wq[((size_t)(k >> 2) * Mp + m) * 4 + (k & 3)] = xs;
         if (wqT) wqT[((size_t)(m >> 2) * KpT + k) * 4 + (m & 3)] = xs;
+        if (wt) wt[(size_t)k * Mp + m] = xs;                       // K-major packs of the round-1 core (ragged T, M <= 32)
+        if (wtT) wtT[(size_t)m * KpT + k] = xs;
     }
 }
 
@@ -359,7 +363,7 @@ size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct wv_train_unit {
     int K = 0, M = 0, ks = 5, stride = 1, pad = 4, Mp = 0, KpT = 0;
-    float *w_pw = nullptr, *inv_pw = nullptr, *wq = nullptr, *wqT = nullptr;      // folded 1x1 weight + packs
+    float *w_pw = nullptr, *inv_pw = nullptr, *wq = nullptr, *wqT = nullptr, *wt = nullptr, *wtT = nullptr;   // folded 1x1 weight + packs
     float *w_dw = nullptr, *inv_dw = nullptr, *id_taps = nullptr;                 // folded taps [M][ks]; identity stencil rows
     float *dW = nullptr, *dwdb = nullptr, *dw_taps = nullptr;                     // weight-gradient scratch
     std::vector<void*> owned;
@@ -386,7 +390,8 @@ int wv_train_unit_create(int K, int M, int ks, int stride, wv_train_unit** out) 
     std::vector<float> taps((size_t)R * 5, 0.f);
     for (int m = 0; m < R; ++m) taps[(size_t)m * 5 + 4] = 1.f;
     bool ok = alloc(&h->w_pw, (size_t)M * K, false) && alloc(&h->inv_pw, M, false) && alloc(&h->wq, nq, true) &&
-              alloc(&h->wqT, nqT, true) && alloc(&h->w_dw, (size_t)M * ks, false) && alloc(&h->inv_dw, M, false) &&
+              alloc(&h->wqT, nqT, true) && alloc(&h->wt, (size_t)wv::round_up(K, wv::BK) * h->Mp, true) &&
+              alloc(&h->wtT, (size_t)wv::round_up(M, wv::BK) * h->KpT, true) && alloc(&h->w_dw, (size_t)M * ks, false) && alloc(&h->inv_dw, M, false) &&
               alloc(&h->id_taps, taps.size(), false) && alloc(&h->dW, (size_t)M * K, false) &&
               alloc(&h->dwdb, (size_t)M * (ks + 1), false) && alloc(&h->dw_taps, (size_t)M * ks, false) &&
               hipMemcpy(h->id_taps, taps.data(), taps.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
@@ -414,20 +419,20 @@ size_t wv_train_half_workspace_bytes(const wv_train_unit* h, int B, int T) { ret
 
 // fold both weights of the unit for this step (live weight norm)
 static int fold_step(wv_train_unit* h, const float* g_pw, const float* v_pw, const float* g_dw, const float* v_dw, hipStream_t s) {
-    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->M), dim3(256), 0, s, g_pw, v_pw, h->w_pw, h->inv_pw, h->wq, h->wqT, h->M, h->K, h->Mp, h->KpT);
-    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->M), dim3(256), 0, s, g_dw, v_dw, h->w_dw, h->inv_dw, (float*)nullptr, (float*)nullptr, h->M, h->ks, 0, 0);
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->M), dim3(256), 0, s, g_pw, v_pw, h->w_pw, h->inv_pw, h->wq, h->wqT, h->M, h->K, h->Mp, h->KpT,
+                       (const float*)nullptr, 1.f, h->wt, h->wtT);
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->M), dim3(256), 0, s, g_dw, v_dw, h->w_dw, h->inv_dw, (float*)nullptr, (float*)nullptr, h->M, h->ks, 0, 0,
+                       (const float*)nullptr, 1.f, (float*)nullptr, (float*)nullptr);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }
 
 static wv::PwWeight pack_of(const wv_train_unit* h, bool transposed) {
     wv::PwWeight p;
-    if (!transposed) { p.M = h->M; p.K = h->K; p.Mp = h->Mp; p.Kp = wv::round_up(h->K, wv::BK); p.wq = h->wq; }
-    else { p.M = h->K; p.K = h->M; p.Mp = h->KpT; p.Kp = wv::round_up(h->M, wv::BK); p.wq = h->wqT; }
+    if (!transposed) { p.M = h->M; p.K = h->K; p.Mp = h->Mp; p.Kp = wv::round_up(h->K, wv::BK); p.wq = h->wq; p.wt = h->wt; }
+    else { p.M = h->K; p.K = h->M; p.Mp = h->KpT; p.Kp = wv::round_up(h->M, wv::BK); p.wq = h->wqT; p.wt = h->wtT; }
     return p;
 }
-
-static const char* SHAPE_MSG = "training unit: needs >= 33 channels on both sides, T % 4 == 0 and 16-byte aligned tensors";
 
 int wv_train_unit_forward(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
                           const float* v_dw, const float* bias, float pre_scale, int pre_elu, float* y, int B, int Tin, void* stream) {
@@ -439,7 +444,6 @@ int wv_train_unit_forward(wv_train_unit* h, const float* x, const float* g_pw, c
     a.X = x; a.pw = pack_of(h, false); a.dw_w = h->w_dw; a.dw_b = bias; a.Y = y;
     a.B = B; a.Tin = Tin; a.Tout = t_out(h, Tin); a.ks = h->ks; a.stride = h->stride; a.dil = 1; a.pad = h->pad;
     a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
-    if (!wv::k1_supported(a)) return tfail(WV_EINVAL, SHAPE_MSG);
     T_LAUNCH(wv::launch_pw_dw(a, s));
     return WV_OK;
 }
@@ -469,7 +473,6 @@ int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, 
     a.X = x; a.pw = pack_of(h, false); a.dw_w = h->id_taps; a.dw_b = nullptr; a.Y = H;
     a.B = B; a.Tin = Tin; a.Tout = Tin; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
     a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
-    if (!wv::k1_supported(a)) return tfail(WV_EINVAL, SHAPE_MSG);
     T_LAUNCH(wv::launch_pw_dw(a, s));
     // dh, and the per-clip partial sums of the tap / bias gradients
     hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(M, B), dim3(256), 0, s, dy, H, h->w_dw, DH, partial, M, Tin, Tout, ks, h->stride, h->pad);
@@ -483,7 +486,6 @@ int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, 
         t.X = DH; t.pw = pack_of(h, true); t.dw_w = h->id_taps; t.dw_b = nullptr; t.Y = pre_elu ? DA : dx;
         t.B = B; t.Tin = Tin; t.Tout = Tin; t.ks = 5; t.stride = 1; t.dil = 1; t.pad = 4;
         t.pre_scale = pre_elu ? 1.f : pre_scale; t.pre_elu = 0; t.out_scale = 1.f; t.bands = 1; t.film_stride = 2;   // no ELU: dx = s W^T dh
-        if (!wv::k1_supported(t)) return tfail(WV_EINVAL, SHAPE_MSG);
         T_LAUNCH(wv::launch_pw_dw(t, s));
         if (pre_elu) {
             const size_t n = (size_t)B * K * Tin, n4 = n / 4;
@@ -658,7 +660,7 @@ int wv_train_convpre_backward(wv_train_convpre* h, const float* x, const float* 
 // ---- SpecBlock add: y = x + s * (W(g,v)[C,F] @ P[B,F,T]),  s = res_scale * scale_param[0] (seanet.py:463-511) ----------------
 struct wv_train_spec {
     int C = 0, F = 0, Mp = 0;
-    float *w = nullptr, *inv = nullptr, *wq = nullptr, *dW = nullptr, *id_taps = nullptr;
+    float *w = nullptr, *inv = nullptr, *wq = nullptr, *wt = nullptr, *dW = nullptr, *id_taps = nullptr;
     std::vector<void*> owned;
     ~wv_train_spec() { for (void* p : owned) (void)hipFree(p); }
 };
@@ -675,7 +677,7 @@ int wv_train_spec_create(int C, int F, wv_train_spec** out) {
     std::vector<float> taps((size_t)C * 5, 0.f);
     for (int m = 0; m < C; ++m) taps[(size_t)m * 5 + 4] = 1.f;
     bool ok = alloc(&h->w, (size_t)C * F, false) && alloc(&h->inv, C, false) && alloc(&h->wq, (size_t)wv::round_up(F, 32) * h->Mp, true) &&
-              alloc(&h->dW, (size_t)C * F, false) && alloc(&h->id_taps, taps.size(), false) &&
+              alloc(&h->wt, (size_t)wv::round_up(F, wv::BK) * h->Mp, true) && alloc(&h->dW, (size_t)C * F, false) && alloc(&h->id_taps, taps.size(), false) &&
               hipMemcpy(h->id_taps, taps.data(), taps.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { delete h; return tfail(WV_EHIP, "device allocation failed"); }
     *out = h;
@@ -692,14 +694,13 @@ int wv_train_spec_forward(wv_train_spec* h, const float* x, const float* P, cons
     hipStream_t s = (hipStream_t)stream;
     // the scalar s rides in the GEMM operand: wq = s * W
     hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->C), dim3(256), 0, s, g, v, h->w, h->inv, h->wq, (float*)nullptr, h->C, h->F, h->Mp, 0,
-                       scale_param, res_scale);
+                       scale_param, res_scale, h->wt, (float*)nullptr);
     T_LAUNCH(hipGetLastError());
     wv::PwDwArgs a{};
-    a.X = P; a.pw.M = h->C; a.pw.K = h->F; a.pw.Mp = h->Mp; a.pw.Kp = wv::round_up(h->F, wv::BK); a.pw.wq = h->wq;
+    a.X = P; a.pw.M = h->C; a.pw.K = h->F; a.pw.Mp = h->Mp; a.pw.Kp = wv::round_up(h->F, wv::BK); a.pw.wq = h->wq; a.pw.wt = h->wt;
     a.dw_w = h->id_taps; a.dw_b = nullptr; a.resid = x; a.Y = y;
     a.B = B; a.Tin = T; a.Tout = T; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
     a.pre_scale = 1.f; a.pre_elu = 0; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
-    if (!wv::k1_supported(a)) return tfail(WV_EINVAL, SHAPE_MSG);
     T_LAUNCH(wv::launch_pw_dw(a, s));
     return WV_OK;
 }
