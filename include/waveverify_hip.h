@@ -279,6 +279,19 @@ int wv_train_spec_backward(wv_train_spec* h, const float* P, const float* g, con
                            const float* dy, float* dg, float* dv, float* d_scale_param, int B, int T,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* conv_post with live weight norm (seanet.py:795-822): y[B,D,T] = L2Norm( (g_pw v_pw/||v_pw||)[D,C] @ DW_ks( ELU(x[B,C,T]) ; g_dw v_dw/||v_dw|| ) + bias )
+ * L2Norm = x / max(||x||_2 over channels, 1e-12) * sqrt(D) (seanet.py:288-318; l2norm = 0 skips it).  D <= 128.
+ * v_dw [C,ks] (no bias on the depth-wise conv), v_pw [D,C], bias [D]. */
+typedef struct wv_train_convpost wv_train_convpost;
+int wv_train_convpost_create(int C, int D, int ks, wv_train_convpost** out);
+void wv_train_convpost_destroy(wv_train_convpost* h);
+size_t wv_train_convpost_workspace_bytes(const wv_train_convpost* h, int B, int T);
+int wv_train_convpost_forward(wv_train_convpost* h, const float* x, const float* g_dw, const float* v_dw, const float* g_pw, const float* v_pw,
+                              const float* bias, int l2norm, float* y, int B, int T, void* stream);
+int wv_train_convpost_backward(wv_train_convpost* h, const float* x, const float* g_dw, const float* v_dw, const float* g_pw, const float* v_pw,
+                               const float* bias, int l2norm, const float* dy, float* dx, float* dg_dw, float* dv_dw, float* dg_pw, float* dv_pw,
+                               float* db, int B, int T, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The two BCE-with-logits losses of the training step (scripts/loss.py:947-1099), forward + gradient in one pass:
  *   LocalizationLoss: msg = NULL, Cz = 1:  mean BCE(logits[B,1,T], mask[B,1,T])
  *   DecodingLoss:     mean BCE(logits[B,Cz,T], msg[B,Cz] * mask[B,1,T])        (mask NULL = all ones)

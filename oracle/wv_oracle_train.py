@@ -154,3 +154,33 @@ def spec_add_backward(x, P, g, v, scale_param, res_scale, dy):
     G = np.einsum("bct,bft->cf", dy, P)
     dg, dv = fold_backward(g.astype(np.float64), v.astype(np.float64), (res_scale * sp * G)[:, :, None])
     return dict(y=x.astype(np.float64) + res_scale * sp * z, dg=dg, dv=dv, d_scale_param=res_scale * float((dy * z).sum()))
+
+
+def convpost_backward(x, g_dw, v_dw, g_pw, v_pw, b, dy, l2norm=True, eps=1e-12):
+    """conv_post (seanet.py:795-822): ELU -> causal depth-wise conv (no bias) -> 1x1 + bias -> L2Norm * sqrt(D)
+    -> dict(y, dx, dg_dw, dv_dw, dg_pw, dv_pw, db)."""
+    x = x.astype(np.float64)
+    dy = dy.astype(np.float64)
+    w = fold(g_dw.astype(np.float64), v_dw.astype(np.float64))[:, 0, :]
+    W = fold(g_pw.astype(np.float64), v_pw.astype(np.float64))[:, :, 0]
+    ks, T, D = w.shape[1], x.shape[2], W.shape[0]
+    a = np.where(x > 0, x, np.expm1(x))
+    ap = np.pad(a, ((0, 0), (0, 0), (ks - 1, 0)))
+    h = sum(w[None, :, i, None] * ap[:, :, i:i + T] for i in range(ks))
+    z = np.einsum("dc,bct->bdt", W, h) + b.astype(np.float64)[None, :, None]
+    if l2norm:
+        n = np.sqrt((z ** 2).sum(1, keepdims=True))
+        nc = np.maximum(n, eps)
+        y = z / nc * np.sqrt(D)
+        dz = np.where(n > eps, np.sqrt(D) / nc * (dy - z * (dy * z).sum(1, keepdims=True) / nc ** 2), np.sqrt(D) / eps * dy)
+    else:
+        y, dz = z, dy
+    dW = np.einsum("bdt,bct->dc", dz, h)
+    dh = np.einsum("dc,bdt->bct", W, dz)
+    dw = np.stack([(dh * ap[:, :, i:i + T]).sum((0, 2)) for i in range(ks)], 1)
+    dhp = np.pad(dh, ((0, 0), (0, 0), (0, ks - 1)))
+    da = sum(w[None, :, i, None] * dhp[:, :, ks - 1 - i:ks - 1 - i + T] for i in range(ks))
+    dx = da * np.where(x > 0, 1.0, np.exp(x))
+    dg_dw, dv_dw = fold_backward(g_dw.astype(np.float64), v_dw.astype(np.float64), dw[:, None, :])
+    dg_pw, dv_pw = fold_backward(g_pw.astype(np.float64), v_pw.astype(np.float64), dW[:, :, None])
+    return dict(y=y, dx=dx, dg_dw=dg_dw, dv_dw=dv_dw, dg_pw=dg_pw, dv_pw=dv_pw, db=dz.sum((0, 2)))

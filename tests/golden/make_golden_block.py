@@ -161,6 +161,30 @@ def main():
         for k, t in items.items():
             out[f"spec{i}_{k}"] = t.detach().numpy().astype(np.float32)
         out[f"spec{i}_meta"] = np.array([n_fft, hop, 0.5773503, -4.3, 2.8])
+    from modules.seanet import L2Norm
+    for i, (B, C, D, T, ks) in enumerate(((2, 64, 128, 50, 5), (3, 40, 16, 37, 7))):
+        rng = np.random.default_rng(700 + i)
+        cpo = torch.nn.Sequential(torch.nn.ELU(inplace=False),
+                                  SConv1d(C, C, ks, groups=C, norm="weight_norm", causal=True, pad_mode="constant", bias=False, nonlinearity="relu"),
+                                  SConv1d(C, D, 1, norm="weight_norm", bias=True), L2Norm(D, inout_norm=True)).double()
+        sd = {}
+        for k, v in cpo.state_dict().items():
+            a = rng.standard_normal(tuple(v.shape))
+            a = 0.5 + np.abs(a) if k.endswith("original0") else a * (np.prod(v.shape[1:]) ** -0.5 if k.endswith("original1") else 1.0)
+            sd[k] = torch.from_numpy(a.astype(np.float32)).double()
+        cpo.load_state_dict(sd)
+        x = torch.from_numpy(rng.standard_normal((B, C, T)).astype(np.float32)).double().requires_grad_(True)
+        y = cpo(x)
+        dy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).double()
+        y.backward(dy)
+        p = dict(cpo.named_parameters())
+        names = dict(g_dw="1.conv.conv.parametrizations.weight.original0", v_dw="1.conv.conv.parametrizations.weight.original1",
+                     g_pw="2.conv.conv.parametrizations.weight.original0", v_pw="2.conv.conv.parametrizations.weight.original1", b="2.conv.conv.bias")
+        for k, t in dict(x=x, dy=dy, y=y, dx=x.grad).items():
+            out[f"post{i}_{k}"] = t.detach().numpy().astype(np.float32)
+        for k, nm in names.items():
+            out[f"post{i}_{k}"] = p[nm].detach().numpy().astype(np.float32)
+            out[f"post{i}_d{k}"] = p[nm].grad.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "grads_pre_spec.npz"), **out)
     print("wrote grads_pre_spec.npz", len(out), "arrays")
 

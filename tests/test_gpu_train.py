@@ -339,3 +339,33 @@ def _spec_vs_oracle(B, C, F, T):
     g = u.backward(_cu(P), pt, _cu(spn), 0.5773503, _cu(dy))
     assert rel(g["dg"], ref["dg"]) <= 1e-4 and rel(g["dv"], ref["dv"]) <= 1e-4
     assert abs(float(g["d_scale_param"].item()) - ref["d_scale_param"]) <= 1e-4 * abs(ref["d_scale_param"])
+
+
+def test_convpost_gradients_vs_reference_autograd_and_oracle(golden_dir):
+    from waveverify_amd.train import TrainConvPost
+    f = np.load(os.path.join(golden_dir, "grads_pre_spec.npz"))
+    names = ("g_dw", "v_dw", "g_pw", "v_pw", "b")
+    for i in range(2):
+        x, dy = f[f"post{i}_x"], f[f"post{i}_dy"]
+        u = TrainConvPost(x.shape[1], dy.shape[1], f[f"post{i}_v_dw"].shape[-1])
+        p = {k: _cu(f[f"post{i}_{k}"]) for k in names}
+        assert rel(u.forward(_cu(x), p), f[f"post{i}_y"]) <= 2e-5
+        g = u.backward(_cu(x), p, _cu(dy))
+        for k, ref in (("dx", "dx"), ("dg_dw", "dg_dw"), ("dv_dw", "dv_dw"), ("dg_pw", "dg_pw"), ("dv_pw", "dv_pw"), ("db", "db")):
+            assert rel(g[k], f[f"post{i}_{ref}"]) <= 1e-4, (i, k, rel(g[k], f[f"post{i}_{ref}"]))
+    # the detector's shape at the training batch (C = 1024 -> D = 128, 50 frames), with and without the norm; a silent column
+    rng = np.random.default_rng(4)
+    B, C, D, T, ks = 64, 1024, 128, 50, 5
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    dy = rng.standard_normal((B, D, T)).astype(np.float32)
+    p = dict(g_dw=(0.5 + np.abs(rng.standard_normal((C, 1, 1)))).astype(np.float32), v_dw=(0.45 * rng.standard_normal((C, 1, ks))).astype(np.float32),
+             g_pw=(0.5 + np.abs(rng.standard_normal((D, 1, 1)))).astype(np.float32), v_pw=(rng.standard_normal((D, C, 1)) * C ** -0.5).astype(np.float32),
+             b=rng.standard_normal(D).astype(np.float32))
+    pt = {k: _cu(v) for k, v in p.items()}
+    for l2 in (True, False):
+        ref = OT.convpost_backward(x, p["g_dw"], p["v_dw"], p["g_pw"], p["v_pw"], p["b"], dy, l2norm=l2)
+        u = TrainConvPost(C, D, ks, l2norm=l2)
+        assert rel(u.forward(_cu(x), pt), ref["y"]) <= 2e-5
+        g, g2 = u.backward(_cu(x), pt, _cu(dy)), u.backward(_cu(x), pt, _cu(dy))
+        for k in ("dx", "dg_dw", "dv_dw", "dg_pw", "dv_pw", "db"):
+            assert rel(g[k], ref[k]) <= 1e-4 and torch.equal(g[k], g2[k]), (l2, k, rel(g[k], ref[k]))

@@ -286,3 +286,13 @@ def test_train_oracle_convpre_and_spec_add_vs_reference_autograd(golden_dir):
         assert np.array_equal(g[f"spec{i}_dx"], g[f"spec{i}_dy"])                    # identity path
         if sp is not None:
             assert rel(r["d_scale_param"], g[f"spec{i}_d_scale_param"]) <= 2e-6
+
+
+def test_train_oracle_convpost_vs_reference_autograd(golden_dir):
+    from oracle import wv_oracle_train as OT
+    g = np.load(os.path.join(golden_dir, "grads_pre_spec.npz"))
+    for i in range(2):
+        r = OT.convpost_backward(*(g[f"post{i}_{k}"] for k in ("x", "g_dw", "v_dw", "g_pw", "v_pw", "b", "dy")))
+        for k, ref in (("y", "y"), ("dx", "dx"), ("dg_dw", "dg_dw"), ("dv_dw", "dv_dw"), ("dg_pw", "dg_pw"), ("dv_pw", "dv_pw"), ("db", "db")):
+            b = g[f"post{i}_{ref}"]
+            assert float(np.abs(r[k].reshape(b.shape) - b).max() / max(np.abs(b).max(), 1e-30)) <= 2e-6, (i, k)

@@ -301,6 +301,44 @@ __global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ 
     if (i < n) buf[i] *= res_s(param, res_scale);
 }
 
+// ---- conv_post pieces (seanet.py:795-822): a = ELU(x), h = causal depth-wise conv(a);  L2Norm backward ----------------------
+__global__ __launch_bounds__(256) void elu_dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ a,
+                                                          float* __restrict__ h, int C, int T, int ks) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const size_t row = ((size_t)b * C + c) * T;
+    float wt[TRAIN_MAX_KS];
+#pragma unroll
+    for (int i = 0; i < TRAIN_MAX_KS; ++i) wt[i] = i < ks ? w[c * ks + i] : 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TRAIN_MAX_KS; ++i) {
+            const int u = t - (ks - 1) + i;
+            if (i < ks && u >= 0) { const float v = x[row + u]; acc = fmaf(wt[i], v > 0.f ? v : (__expf(v) - 1.f), acc); }
+        }
+        const float v = x[row + t];
+        a[row + t] = v > 0.f ? v : (__expf(v) - 1.f);
+        h[row + t] = acc;
+    }
+}
+
+// y = z / max(||z||_2 over channels, eps) * sqrt(D)  (seanet.py:288-318, F.normalize).  In place: z <- dL/dz.
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(float* __restrict__ z, const float* __restrict__ dy, int D, int T, float eps) {
+    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (t >= T) return;
+    float* zb = z + (size_t)b * D * T + t;
+    const float* db = dy + (size_t)b * D * T + t;
+    float ss = 0.f, dot = 0.f;
+    for (int d = 0; d < D; ++d) { const float v = zb[(size_t)d * T]; ss = fmaf(v, v, ss); dot = fmaf(v, db[(size_t)d * T], dot); }
+    const float n = sqrtf(ss), sc = sqrtf((float)D);
+    if (n > eps) {
+        const float inv = 1.f / n, k = dot * inv * inv;
+        for (int d = 0; d < D; ++d) zb[(size_t)d * T] = sc * inv * (db[(size_t)d * T] - zb[(size_t)d * T] * k);
+    } else {
+        for (int d = 0; d < D; ++d) zb[(size_t)d * T] = sc / eps * db[(size_t)d * T];
+    }
+}
+
 // ---- optimizer step over a FLAT parameter arena (scripts/train.py:1346-1358, conf/base.yml:128-130) ------------------
 // Parameters, gradients and both AdamW moments of a net live in contiguous arenas, so gradient clipping is one
 // two-stage sum of squares and the update one launch (and the DDP buckets are plain slices of the gradient arena).
@@ -721,6 +759,125 @@ int wv_train_spec_backward(wv_train_spec* h, const float* P, const float* g, con
     if (d_scale_param) hipLaunchKernelGGL(wv::dot_small_kernel, dim3(1), dim3(256), 0, s, h->w, h->dW, n, res_scale, d_scale_param);
     hipLaunchKernelGGL(wv::scale_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dW, n, scale_param, res_scale);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g, v, h->inv, h->dW, dg, dv, F);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+// ---- conv_post: ELU -> causal depth-wise conv (ks, no bias) -> 1x1 (C -> D, bias) -> L2Norm * sqrt(D) (seanet.py:795-822) --------
+struct wv_train_convpost {
+    int C = 0, D = 0, ks = 0, Mp = 0, KpT = 0;
+    float *w_dw = nullptr, *inv_dw = nullptr, *w_pw = nullptr, *inv_pw = nullptr, *wt = nullptr, *wtT = nullptr, *wq = nullptr, *wqT = nullptr;
+    float *dW = nullptr, *dwdb = nullptr, *taps = nullptr, *dbsum = nullptr, *junk = nullptr, *id_taps = nullptr;
+    std::vector<void*> owned;
+    ~wv_train_convpost() { for (void* p : owned) (void)hipFree(p); }
+};
+
+int wv_train_convpost_create(int C, int D, int ks, wv_train_convpost** out) {
+    if (!out || C < 1 || C > 4096 || D < 1 || D > 128 || ks < 1 || ks > wv::TRAIN_MAX_KS) return tfail(WV_EINVAL, "bad channel count / kernel size (D <= 128)");
+    auto* h = new wv_train_convpost();
+    h->C = C; h->D = D; h->ks = ks; h->Mp = wv::round_up(D, wv::M_ALIGN); h->KpT = wv::round_up(C, wv::M_ALIGN);
+    auto alloc = [&](float** p, size_t n, bool zero) {
+        if (hipMalloc((void**)p, n * sizeof(float)) != hipSuccess) return false;
+        h->owned.push_back(*p);
+        return !zero || hipMemset(*p, 0, n * sizeof(float)) == hipSuccess;
+    };
+    std::vector<float> taps((size_t)C * 5, 0.f);
+    for (int m = 0; m < C; ++m) taps[(size_t)m * 5 + 4] = 1.f;
+    bool ok = alloc(&h->w_dw, (size_t)C * ks, false) && alloc(&h->inv_dw, C, false) && alloc(&h->w_pw, (size_t)D * C, false) && alloc(&h->inv_pw, D, false) &&
+              alloc(&h->wt, (size_t)wv::round_up(C, wv::BK) * h->Mp, true) && alloc(&h->wtT, (size_t)wv::round_up(D, wv::BK) * h->KpT, true) &&
+              alloc(&h->wq, (size_t)wv::round_up(C, 32) * h->Mp, true) && alloc(&h->wqT, (size_t)wv::round_up(D, 32) * h->KpT, true) &&
+              alloc(&h->dW, (size_t)D * C, false) && alloc(&h->dwdb, (size_t)std::max(C * (ks + 1), D * 2), false) && alloc(&h->taps, (size_t)C * ks, false) &&
+              alloc(&h->dbsum, (size_t)D, false) && alloc(&h->junk, (size_t)std::max(C, D), false) && alloc(&h->id_taps, taps.size(), false) &&
+              hipMemcpy(h->id_taps, taps.data(), taps.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { delete h; return tfail(WV_EHIP, "device allocation failed"); }
+    *out = h;
+    return WV_OK;
+}
+void wv_train_convpost_destroy(wv_train_convpost* h) { delete h; }
+
+size_t wv_train_convpost_workspace_bytes(const wv_train_convpost* h, int B, int T) {
+    if (!h || B < 1 || T < 1) return 0;
+    const size_t ac = al256((size_t)B * h->C * T * 4), ad = al256((size_t)B * h->D * T * 4);
+    return 3 * ac + ad + al256((size_t)B * std::max(h->C * (h->ks + 1), h->D * 2) * 4) + al256((size_t)nt_splits(B) * h->D * h->C * 4);
+}
+
+static int convpost_fold(wv_train_convpost* h, const float* g_dw, const float* v_dw, const float* g_pw, const float* v_pw, hipStream_t s) {
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->C), dim3(256), 0, s, g_dw, v_dw, h->w_dw, h->inv_dw, (float*)nullptr, (float*)nullptr, h->C, h->ks, 0, 0,
+                       (const float*)nullptr, 1.f, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->D), dim3(256), 0, s, g_pw, v_pw, h->w_pw, h->inv_pw, h->wq, h->wqT, h->D, h->C, h->Mp, h->KpT,
+                       (const float*)nullptr, 1.f, h->wt, h->wtT);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+static wv::PwWeight convpost_pack(const wv_train_convpost* h, bool transposed) {
+    wv::PwWeight p;
+    if (!transposed) { p.M = h->D; p.K = h->C; p.Mp = h->Mp; p.Kp = wv::round_up(h->C, wv::BK); p.wq = h->wq; p.wt = h->wt; }
+    else { p.M = h->C; p.K = h->D; p.Mp = h->KpT; p.Kp = wv::round_up(h->D, wv::BK); p.wq = h->wqT; p.wt = h->wtT; }
+    return p;
+}
+
+int wv_train_convpost_forward(wv_train_convpost* h, const float* x, const float* g_dw, const float* v_dw, const float* g_pw, const float* v_pw,
+                              const float* bias, int l2norm, float* y, int B, int T, void* stream) {
+    if (!h || !x || !g_dw || !v_dw || !g_pw || !v_pw || !y || B < 1 || T < 1) return tfail(WV_EINVAL, "null / bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = convpost_fold(h, g_dw, v_dw, g_pw, v_pw, s);
+    if (rc) return rc;
+    wv::DwPwArgs a{};
+    a.X = x; a.dw_w = h->w_dw; a.pw = convpost_pack(h, false); a.bias = bias; a.Y = y;
+    a.B = B; a.Tin = T; a.Tout = T; a.mode = 1; a.ks = h->ks; a.pre_scale = 1.f; a.pre_elu = 1; a.l2norm = l2norm; a.out_scale = 1.f;
+    T_LAUNCH(wv::launch_dw_pw(a, s));
+    return WV_OK;
+}
+
+int wv_train_convpost_backward(wv_train_convpost* h, const float* x, const float* g_dw, const float* v_dw, const float* g_pw, const float* v_pw,
+                               const float* bias, int l2norm, const float* dy, float* dx, float* dg_dw, float* dv_dw, float* dg_pw, float* dv_pw,
+                               float* db, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !x || !g_dw || !v_dw || !g_pw || !v_pw || !dy || !dx || !dg_dw || !dv_dw || !dg_pw || !dv_pw || !db) return tfail(WV_EINVAL, "null argument");
+    if (B < 1 || T < 1 || !ws || ws_bytes < wv_train_convpost_workspace_bytes(h, B, T)) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = h->C, D = h->D, ks = h->ks, S = nt_splits(B);
+    const size_t ac = al256((size_t)B * C * T * 4), ad = al256((size_t)B * D * T * 4);
+    char* w = (char*)ws;
+    float* A = (float*)w; float* H = (float*)(w + ac); float* DH = (float*)(w + 2 * ac); float* Z = (float*)(w + 3 * ac);
+    float* partial = (float*)(w + 3 * ac + ad);
+    float* parts = (float*)(w + 3 * ac + ad + al256((size_t)B * std::max(C * (ks + 1), D * 2) * 4));
+    int rc = convpost_fold(h, g_dw, v_dw, g_pw, v_pw, s);
+    if (rc) return rc;
+    // recompute a = ELU(x), h = DW(a), z = W h + b
+    hipLaunchKernelGGL(wv::elu_dw_fwd_kernel, dim3(C, B), dim3(256), 0, s, x, h->w_dw, A, H, C, T, ks);
+    T_LAUNCH(hipGetLastError());
+    const float* dZ = dy;
+    if (l2norm) {
+        wv::DwPwArgs a{};
+        a.X = H; a.pw = convpost_pack(h, false); a.bias = bias; a.Y = Z;
+        a.B = B; a.Tin = T; a.Tout = T; a.mode = 0; a.ks = 1; a.pre_scale = 1.f; a.pre_elu = 0; a.l2norm = 0; a.out_scale = 1.f;
+        T_LAUNCH(wv::launch_dw_pw(a, s));
+        hipLaunchKernelGGL(wv::l2norm_bwd_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, Z, dy, D, T, 1e-12f);
+        dZ = Z;
+    }
+    // db = sum dz (the bias slot of the row-sum kernel with one tap), dW = sum dz h^T
+    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(D, B), dim3(256), 0, s, dZ, dZ, h->junk, (float*)nullptr, partial, D, T, T, 1, 1, 0, 0);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((D * 2 + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)D * 2);
+    hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((D + 255) / 256), dim3(256), 0, s, h->dwdb, h->junk, db, D, 1, 1.f);
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((D + 63) / 64, (C + 63) / 64, S), dim3(256), 0, s, dZ, H, parts, 1.f, 0, B, D, C, T);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)D * C + 255) / 256)), dim3(256), 0, s, parts, h->dW, S, (size_t)D * C);
+    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(D), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, C);
+    T_LAUNCH(hipGetLastError());
+    // dh = W^T dz
+    wv::PwDwArgs t{};
+    t.X = dZ; t.pw = convpost_pack(h, true); t.dw_w = h->id_taps; t.dw_b = nullptr; t.Y = DH;
+    t.B = B; t.Tin = T; t.Tout = T; t.ks = 5; t.stride = 1; t.dil = 1; t.pad = 4;
+    t.pre_scale = 1.f; t.pre_elu = 0; t.out_scale = 1.f; t.bands = 1; t.film_stride = 2;
+    T_LAUNCH(wv::launch_pw_dw(t, s));
+    // through the depth-wise conv (da into the H buffer) and the ELU
+    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(C, B), dim3(256), 0, s, DH, A, h->w_dw, H, partial, C, T, T, ks, 1, ks - 1, 0);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((C * (ks + 1) + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)C * (ks + 1));
+    hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((C + 255) / 256), dim3(256), 0, s, h->dwdb, h->taps, h->junk, C, ks, 1.f);
+    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g_dw, v_dw, h->inv_dw, h->taps, dg_dw, dv_dw, ks);
+    const size_t n = (size_t)B * C * T, n4 = n / 4;
+    if (n4) hipLaunchKernelGGL(wv::elu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, H, x, dx, 1.f, n4);
+    if (n % 4) hipLaunchKernelGGL(wv::elu_bwd_tail_kernel, dim3(1), dim3(256), 0, s, H, x, dx, 1.f, n4 * 4, n);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }

@@ -219,6 +219,43 @@ class TrainSpecAdd(_Handle):
         return out
 
 
+class TrainConvPost(_Handle):
+    """conv_post with live weight norm (/root/reference/modules/seanet.py:795-822): ELU -> causal depth-wise SConv1d(C, C, ks, no
+    bias) -> SConv1d(C, D, 1, bias) -> L2Norm * sqrt(D).  params: g_dw [C], v_dw [C,ks], g_pw [D], v_pw [D,C], b [D]."""
+    _create, _destroy = "wv_train_convpost_create", "wv_train_convpost_destroy"
+
+    def __init__(self, channels: int, dimension: int, ks: int, l2norm: bool = True):
+        self.C, self.D, self.ks, self.l2norm = int(channels), int(dimension), int(ks), bool(l2norm)
+        self._open(self.C, self.D, self.ks)
+
+    def _p(self, p):
+        return (_f(p["g_dw"]).reshape(self.C), _f(p["v_dw"]).reshape(self.C, self.ks), _f(p["g_pw"]).reshape(self.D),
+                _f(p["v_pw"]).reshape(self.D, self.C), _f(p["b"]).reshape(self.D))
+
+    def forward(self, x, p):
+        x = _f(x)
+        B, _, T = x.shape
+        g_dw, v_dw, g_pw, v_pw, b = self._p(p)
+        y = torch.empty(B, self.D, T, device=x.device)
+        self._check(self._lib.wv_train_convpost_forward(self._h, x.data_ptr(), g_dw.data_ptr(), v_dw.data_ptr(), g_pw.data_ptr(), v_pw.data_ptr(),
+                                                        b.data_ptr(), int(self.l2norm), y.data_ptr(), B, T, TrainHalf._stream()),
+                    "wv_train_convpost_forward")
+        return y
+
+    def backward(self, x, p, dy):
+        x, dy = _f(x), _f(dy)
+        B, _, T = x.shape
+        g_dw, v_dw, g_pw, v_pw, b = self._p(p)
+        out = dict(dx=torch.empty_like(x), dg_dw=torch.empty_like(g_dw), dv_dw=torch.empty_like(v_dw), dg_pw=torch.empty_like(g_pw),
+                   dv_pw=torch.empty_like(v_pw), db=torch.empty_like(b))
+        ws = torch.empty(int(self._lib.wv_train_convpost_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=x.device)
+        self._check(self._lib.wv_train_convpost_backward(
+            self._h, x.data_ptr(), g_dw.data_ptr(), v_dw.data_ptr(), g_pw.data_ptr(), v_pw.data_ptr(), b.data_ptr(), int(self.l2norm), dy.data_ptr(),
+            out["dx"].data_ptr(), out["dg_dw"].data_ptr(), out["dv_dw"].data_ptr(), out["dg_pw"].data_ptr(), out["dv_pw"].data_ptr(),
+            out["db"].data_ptr(), B, T, ws.data_ptr(), ws.numel(), TrainHalf._stream()), "wv_train_convpost_backward")
+        return out
+
+
 class _HalfParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("g_pw", "v_pw", "g_dw", "v_dw", "bias")]
 
