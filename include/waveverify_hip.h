@@ -292,6 +292,20 @@ int wv_train_convpost_backward(wv_train_convpost* h, const float* x, const float
                                const float* bias, int l2norm, const float* dy, float* dx, float* dg_dw, float* dv_dw, float* dg_pw, float* dv_pw,
                                float* db, int B, int T, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Detector / locator head (model/detector.py:209-218,278-318; locator.py likewise): plain (not weight-normed) parameters
+ *   logits[B,nb,T] = Conv1d(O, nb, 1)( ConvTranspose1d(D, O, k = s = hop)(z[B,D,N])[:, :, :T] ),  T <= N * hop
+ * w_rev [D,O,hop], b_rev [O], w_last [nb,O], b_last [nb].  (Inference composes the two layers into one weight; training keeps
+ * them apart so that each gets its gradient.) */
+typedef struct wv_train_head wv_train_head;
+int wv_train_head_create(int D, int O, int nb, int hop, wv_train_head** out);
+void wv_train_head_destroy(wv_train_head* h);
+size_t wv_train_head_workspace_bytes(const wv_train_head* h, int B, int N);
+int wv_train_head_forward(wv_train_head* h, const float* z, const float* w_rev, const float* b_rev, const float* w_last, const float* b_last,
+                          float* logits, int B, int N, int T, void* workspace, size_t workspace_bytes, void* stream);
+int wv_train_head_backward(wv_train_head* h, const float* z, const float* w_rev, const float* b_rev, const float* w_last, const float* dlogits,
+                           float* dz, float* dw_rev, float* db_rev, float* dw_last, float* db_last, int B, int N, int T,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* The two BCE-with-logits losses of the training step (scripts/loss.py:947-1099), forward + gradient in one pass:
  *   LocalizationLoss: msg = NULL, Cz = 1:  mean BCE(logits[B,1,T], mask[B,1,T])
  *   DecodingLoss:     mean BCE(logits[B,Cz,T], msg[B,Cz] * mask[B,1,T])        (mask NULL = all ones)

@@ -369,3 +369,28 @@ def test_convpost_gradients_vs_reference_autograd_and_oracle(golden_dir):
         g, g2 = u.backward(_cu(x), pt, _cu(dy)), u.backward(_cu(x), pt, _cu(dy))
         for k in ("dx", "dg_dw", "dv_dw", "dg_pw", "dv_pw", "db"):
             assert rel(g[k], ref[k]) <= 1e-4 and torch.equal(g[k], g2[k]), (l2, k, rel(g[k], ref[k]))
+
+
+@pytest.mark.parametrize("B,D,O,nb,hop,N,T", [(4, 128, 32, 16, 320, 50, 16000), (3, 64, 32, 1, 32, 500, 16000), (2, 128, 32, 16, 320, 51, 16001),
+                                              (2, 16, 8, 3, 5, 7, 33)])
+def test_head_forward_backward_vs_torch_modules(B, D, O, nb, hop, N, T):
+    """The reference's head IS torch.nn.ConvTranspose1d(D, O, hop, hop) -> [:, :, :T] -> nn.Conv1d(O, nb, 1) (detector.py:209-218,
+    304-310): its CPU autograd in float64 is the oracle.  Detector, locator, a ragged length and a tiny case."""
+    from waveverify_amd.train import TrainHead
+    torch.manual_seed(D + hop)
+    rev = torch.nn.ConvTranspose1d(D, O, hop, hop).double()
+    last = torch.nn.Conv1d(O, nb, 1).double()
+    z = torch.randn(B, D, N, dtype=torch.float64, requires_grad=True)
+    logits = last(rev(z)[:, :, :T])
+    dl = torch.randn_like(logits)
+    logits.backward(dl)
+    p = dict(w_rev=rev.weight.detach().float().cuda(), b_rev=rev.bias.detach().float().cuda(), w_last=last.weight.detach().float().cuda(),
+             b_last=last.bias.detach().float().cuda())
+    h = TrainHead(D, O, nb, hop)
+    got = h.forward(z.detach().float().cuda(), p, T)
+    assert rel(got, logits.detach().numpy()) <= 2e-5
+    g = h.backward(z.detach().float().cuda(), p, dl.float().cuda())
+    g2 = h.backward(z.detach().float().cuda(), p, dl.float().cuda())
+    for k, ref in (("dz", z.grad), ("dw_rev", rev.weight.grad), ("db_rev", rev.bias.grad), ("dw_last", last.weight.grad[:, :, 0]), ("db_last", last.bias.grad)):
+        assert rel(g[k], ref.numpy()) <= 1e-4, (k, rel(g[k], ref.numpy()))
+        assert torch.equal(g[k], g2[k]), k

@@ -339,6 +339,35 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(float* __restrict__ z, 
     }
 }
 
+// ---- detector / locator head (detector.py:209-218,278-318): ConvTranspose1d(D, O, k = s = hop) -> trim -> Conv1d(O, nb, 1) ------
+// Everything runs in FRAME layout q[B][rows][hop][N] (row-major over (j, n)): the transposed conv is then a plain GEMM over the
+// latent frames and the 1x1 a GEMM over the hop*N axis; two transposes move logits / their gradient between [B][nb][T] and frames.
+__global__ __launch_bounds__(256) void time_to_frames_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int hop, int N) {
+    const size_t row = blockIdx.y;                                  // (b, r)
+    const int i = blockIdx.x * 256 + threadIdx.x;                   // index into [hop][N]
+    if (i >= hop * N) return;
+    const int j = i / N, n = i - j * N, t = n * hop + j;
+    out[row * hop * N + i] = t < T ? in[row * T + t] : 0.f;         // positions past T were trimmed: no gradient
+}
+__global__ __launch_bounds__(256) void frames_to_time_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int hop, int N) {
+    const size_t row = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int n = t / hop, j = t - n * hop;
+    out[row * T + t] = in[row * hop * N + (size_t)j * N + n];
+}
+// dst wt[k][Mp] (K-major pack of an [M][K] matrix); src is [M][K] (transposed = 0) or [K][M] (transposed = 1); padding pre-zeroed
+__global__ __launch_bounds__(256) void pack_wt_kernel(const float* __restrict__ src, float* __restrict__ dst, int M, int K, int Mp, int transposed) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * K) return;
+    const int m = (int)(i % M), k = (int)(i / M);
+    dst[(size_t)k * Mp + m] = transposed ? src[(size_t)k * M + m] : src[(size_t)m * K + k];
+}
+__global__ void expand_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int O, int hop) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < O * hop) out[i] = b[i / hop];
+}
+
 // ---- optimizer step over a FLAT parameter arena (scripts/train.py:1346-1358, conf/base.yml:128-130) ------------------
 // Parameters, gradients and both AdamW moments of a net live in contiguous arenas, so gradient clipping is one
 // two-stage sum of squares and the update one launch (and the DDP buckets are plain slices of the gradient arena).
@@ -879,6 +908,124 @@ int wv_train_convpost_backward(wv_train_convpost* h, const float* x, const float
     if (n4) hipLaunchKernelGGL(wv::elu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, H, x, dx, 1.f, n4);
     if (n % 4) hipLaunchKernelGGL(wv::elu_bwd_tail_kernel, dim3(1), dim3(256), 0, s, H, x, dx, 1.f, n4 * 4, n);
     T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+// ---- head ------------------------------------------------------------------------------------------------------------------------
+struct wv_train_head {
+    int D = 0, O = 0, nb = 0, hop = 0;
+    float *wt_q = nullptr, *wt_dz = nullptr, *wt_l = nullptr, *wt_lT = nullptr, *bias_q = nullptr, *scr = nullptr, *junk = nullptr;
+    std::vector<void*> owned;
+    ~wv_train_head() { for (void* p : owned) (void)hipFree(p); }
+};
+
+int wv_train_head_create(int D, int O, int nb, int hop, wv_train_head** out) {
+    if (!out || D < 1 || D > 4096 || O < 1 || O > 4096 || nb < 1 || nb > 4096 || hop < 1 || (long long)O * hop > (1 << 20)) return tfail(WV_EINVAL, "bad head shape");
+    auto* h = new wv_train_head();
+    h->D = D; h->O = O; h->nb = nb; h->hop = hop;
+    const int OH = O * hop;
+    auto alloc = [&](float** p, size_t n) {
+        if (hipMalloc((void**)p, n * sizeof(float)) != hipSuccess) return false;
+        h->owned.push_back(*p);
+        return hipMemset(*p, 0, n * sizeof(float)) == hipSuccess;
+    };
+    const size_t big = std::max<size_t>((size_t)std::max(nb, O) * 2, 64);
+    bool ok = alloc(&h->wt_q, (size_t)wv::round_up(D, wv::BK) * wv::round_up(OH, wv::M_ALIGN)) &&
+              alloc(&h->wt_dz, (size_t)wv::round_up(OH, wv::BK) * wv::round_up(D, wv::M_ALIGN)) &&
+              alloc(&h->wt_l, (size_t)wv::round_up(O, wv::BK) * wv::round_up(nb, wv::M_ALIGN)) &&
+              alloc(&h->wt_lT, (size_t)wv::round_up(nb, wv::BK) * wv::round_up(O, wv::M_ALIGN)) && alloc(&h->bias_q, (size_t)OH) &&
+              alloc(&h->scr, big) && alloc(&h->junk, big);
+    if (!ok) { delete h; return tfail(WV_EHIP, "device allocation failed"); }
+    *out = h;
+    return WV_OK;
+}
+void wv_train_head_destroy(wv_train_head* h) { delete h; }
+
+static int head_splits(int B, size_t mk) { return (int)std::max<size_t>(1, std::min<size_t>(nt_splits(B), ((size_t)16 << 20) / std::max<size_t>(mk, 1))); }
+
+size_t wv_train_head_workspace_bytes(const wv_train_head* h, int B, int N) {
+    if (!h || B < 1 || N < 1) return 0;
+    const size_t hn = (size_t)h->hop * N;
+    const size_t aq = al256((size_t)B * h->O * hn * 4), al = al256((size_t)B * h->nb * hn * 4);
+    const size_t p1 = (size_t)head_splits(B, (size_t)h->D * h->O * h->hop) * h->D * h->O * h->hop, p2 = (size_t)head_splits(B, (size_t)h->nb * h->O) * h->nb * h->O;
+    return 2 * aq + al + al256(std::max(p1, p2) * 4) + al256((size_t)B * std::max(h->nb, h->O) * 2 * 4);
+}
+
+static wv::PwWeight head_pw(int M, int K, const float* wt) {
+    wv::PwWeight p; p.M = M; p.K = K; p.Mp = wv::round_up(M, wv::M_ALIGN); p.Kp = wv::round_up(K, wv::BK); p.wt = wt; p.wq = nullptr;
+    return p;
+}
+static hipError_t head_gemm(const float* X, const wv::PwWeight& pw, const float* bias, float* Y, int B, int T, hipStream_t s) {
+    wv::DwPwArgs a{};
+    a.X = X; a.pw = pw; a.bias = bias; a.Y = Y; a.B = B; a.Tin = T; a.Tout = T; a.mode = 0; a.ks = 1;
+    a.pre_scale = 1.f; a.pre_elu = 0; a.l2norm = 0; a.out_scale = 1.f;
+    return wv::launch_dw_pw(a, s);
+}
+// q[B][O*hop][N] = ConvTranspose frames of z
+static int head_q(wv_train_head* h, const float* z, const float* w_rev, const float* b_rev, float* q, int B, int N, hipStream_t s) {
+    const int OH = h->O * h->hop;
+    hipLaunchKernelGGL(wv::pack_wt_kernel, dim3((unsigned)(((size_t)OH * h->D + 255) / 256)), dim3(256), 0, s, w_rev, h->wt_q, OH, h->D, wv::round_up(OH, wv::M_ALIGN), 1);
+    hipLaunchKernelGGL(wv::expand_bias_kernel, dim3((OH + 255) / 256), dim3(256), 0, s, b_rev, h->bias_q, h->O, h->hop);
+    T_LAUNCH(hipGetLastError());
+    T_LAUNCH(head_gemm(z, head_pw(OH, h->D, h->wt_q), b_rev ? h->bias_q : nullptr, q, B, N, s));
+    return WV_OK;
+}
+
+int wv_train_head_forward(wv_train_head* h, const float* z, const float* w_rev, const float* b_rev, const float* w_last, const float* b_last,
+                          float* logits, int B, int N, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !z || !w_rev || !w_last || !logits || B < 1 || N < 1 || T < 1 || T > N * h->hop) return tfail(WV_EINVAL, "null / bad argument");
+    if (!ws || ws_bytes < wv_train_head_workspace_bytes(h, B, N)) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t hn = (size_t)h->hop * N, aq = al256((size_t)B * h->O * hn * 4);
+    float* q = (float*)ws; float* lq = (float*)((char*)ws + 2 * aq);
+    int rc = head_q(h, z, w_rev, b_rev, q, B, N, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wv::pack_wt_kernel, dim3((unsigned)(((size_t)h->nb * h->O + 255) / 256)), dim3(256), 0, s, w_last, h->wt_l, h->nb, h->O, wv::round_up(h->nb, wv::M_ALIGN), 0);
+    T_LAUNCH(hipGetLastError());
+    T_LAUNCH(head_gemm(q, head_pw(h->nb, h->O, h->wt_l), b_last, lq, B, (int)hn, s));
+    hipLaunchKernelGGL(wv::frames_to_time_kernel, dim3((T + 255) / 256, B * h->nb), dim3(256), 0, s, lq, logits, T, h->hop, N);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+int wv_train_head_backward(wv_train_head* h, const float* z, const float* w_rev, const float* b_rev, const float* w_last, const float* dlogits,
+                           float* dz, float* dw_rev, float* db_rev, float* dw_last, float* db_last, int B, int N, int T,
+                           void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !z || !w_rev || !w_last || !dlogits || !dz || !dw_rev || !db_rev || !dw_last || !db_last || B < 1 || N < 1 || T < 1 || T > N * h->hop)
+        return tfail(WV_EINVAL, "null / bad argument");
+    if (!ws || ws_bytes < wv_train_head_workspace_bytes(h, B, N)) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = h->D, O = h->O, nb = h->nb, hop = h->hop, OH = O * hop;
+    const size_t hn = (size_t)hop * N, aq = al256((size_t)B * O * hn * 4), al = al256((size_t)B * nb * hn * 4);
+    const size_t p1 = (size_t)head_splits(B, (size_t)D * OH) * D * OH, p2 = (size_t)head_splits(B, (size_t)nb * O) * nb * O;
+    char* w = (char*)ws;
+    float* q = (float*)w; float* dq = (float*)(w + aq); float* dlq = (float*)(w + 2 * aq);
+    float* parts = (float*)(w + 2 * aq + al);
+    float* partial = (float*)(w + 2 * aq + al + al256(std::max(p1, p2) * 4));
+    int rc = head_q(h, z, w_rev, b_rev, q, B, N, s);                               // recomputed (forward keeps nothing)
+    if (rc) return rc;
+    hipLaunchKernelGGL(wv::time_to_frames_kernel, dim3((unsigned)((hn + 255) / 256), B * nb), dim3(256), 0, s, dlogits, dlq, T, hop, N);
+    // last layer: dw_last[k][o] = sum dlq[k] . q[o] over (b, j, n);  db_last[k] = sum dlogits
+    const int S2 = head_splits(B, (size_t)nb * O);
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((nb + 63) / 64, (O + 63) / 64, S2), dim3(256), 0, s, dlq, q, parts, 1.f, 0, B, nb, O, (int)hn);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)nb * O + 255) / 256)), dim3(256), 0, s, parts, dw_last, S2, (size_t)nb * O);
+    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(nb, B), dim3(256), 0, s, dlq, dlq, h->junk, (float*)nullptr, partial, nb, (int)hn, (int)hn, 1, 1, 0, 0);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((nb * 2 + 255) / 256), dim3(256), 0, s, partial, h->scr, B, (size_t)nb * 2);
+    hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, h->scr, h->junk, db_last, nb, 1, 1.f);
+    // dq = w_last^T @ dlq
+    hipLaunchKernelGGL(wv::pack_wt_kernel, dim3((unsigned)(((size_t)O * nb + 255) / 256)), dim3(256), 0, s, w_last, h->wt_lT, O, nb, wv::round_up(O, wv::M_ALIGN), 1);
+    T_LAUNCH(hipGetLastError());
+    T_LAUNCH(head_gemm(dlq, head_pw(O, nb, h->wt_lT), nullptr, dq, B, (int)hn, s));
+    // db_rev[o] = sum dq[o];  dw_rev[d][(o,j)] = sum_{b,n} z[d][n] dq[(o,j)][n];  dz = w_rev @ dq
+    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(O, B), dim3(256), 0, s, dq, dq, h->junk, (float*)nullptr, partial, O, (int)hn, (int)hn, 1, 1, 0, 0);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((O * 2 + 255) / 256), dim3(256), 0, s, partial, h->scr, B, (size_t)O * 2);
+    hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((O + 255) / 256), dim3(256), 0, s, h->scr, h->junk, db_rev, O, 1, 1.f);
+    const int S1 = head_splits(B, (size_t)D * OH);
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((D + 63) / 64, (OH + 63) / 64, S1), dim3(256), 0, s, z, dq, parts, 1.f, 0, B, D, OH, N);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)D * OH + 255) / 256)), dim3(256), 0, s, parts, dw_rev, S1, (size_t)D * OH);
+    hipLaunchKernelGGL(wv::pack_wt_kernel, dim3((unsigned)(((size_t)D * OH + 255) / 256)), dim3(256), 0, s, w_rev, h->wt_dz, D, OH, wv::round_up(D, wv::M_ALIGN), 0);
+    T_LAUNCH(hipGetLastError());
+    T_LAUNCH(head_gemm(dq, head_pw(D, OH, h->wt_dz), nullptr, dz, B, N, s));
     return WV_OK;
 }
 

@@ -256,6 +256,47 @@ class TrainConvPost(_Handle):
         return out
 
 
+class TrainHead(_Handle):
+    """Detector / locator head (/root/reference/model/detector.py:209-218,278-318): ConvTranspose1d(D, O, k = s = hop) -> trim to T
+    -> Conv1d(O, nb, 1), plain parameters w_rev [D,O,hop], b_rev [O], w_last [nb,O(,1)], b_last [nb]."""
+    _create, _destroy = "wv_train_head_create", "wv_train_head_destroy"
+
+    def __init__(self, dimension: int, output_dim: int, nbits: int, hop: int):
+        self.D, self.O, self.nb, self.hop = int(dimension), int(output_dim), int(nbits), int(hop)
+        self._open(self.D, self.O, self.nb, self.hop)
+
+    def _p(self, p):
+        return (_f(p["w_rev"]).reshape(self.D, self.O, self.hop), _f(p["b_rev"]).reshape(self.O), _f(p["w_last"]).reshape(self.nb, self.O),
+                _f(p["b_last"]).reshape(self.nb))
+
+    def _ws(self, B, N, dev):
+        return torch.empty(int(self._lib.wv_train_head_workspace_bytes(self._h, B, N)), dtype=torch.uint8, device=dev)
+
+    def forward(self, z, p, T: int):
+        z = _f(z)
+        B, _, N = z.shape
+        w_rev, b_rev, w_last, b_last = self._p(p)
+        logits = torch.empty(B, self.nb, T, device=z.device)
+        ws = self._ws(B, N, z.device)
+        self._check(self._lib.wv_train_head_forward(self._h, z.data_ptr(), w_rev.data_ptr(), b_rev.data_ptr(), w_last.data_ptr(), b_last.data_ptr(),
+                                                    logits.data_ptr(), B, N, int(T), ws.data_ptr(), ws.numel(), TrainHalf._stream()),
+                    "wv_train_head_forward")
+        return logits
+
+    def backward(self, z, p, dlogits):
+        z, dl = _f(z), _f(dlogits)
+        B, _, N = z.shape
+        w_rev, b_rev, w_last, _ = self._p(p)
+        out = dict(dz=torch.empty_like(z), dw_rev=torch.empty_like(w_rev), db_rev=torch.empty_like(b_rev), dw_last=torch.empty_like(w_last),
+                   db_last=torch.empty(self.nb, device=z.device))
+        ws = self._ws(B, N, z.device)
+        self._check(self._lib.wv_train_head_backward(
+            self._h, z.data_ptr(), w_rev.data_ptr(), b_rev.data_ptr(), w_last.data_ptr(), dl.data_ptr(), out["dz"].data_ptr(),
+            out["dw_rev"].data_ptr(), out["db_rev"].data_ptr(), out["dw_last"].data_ptr(), out["db_last"].data_ptr(), B, N, dl.shape[2],
+            ws.data_ptr(), ws.numel(), TrainHalf._stream()), "wv_train_head_backward")
+        return out
+
+
 class _HalfParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("g_pw", "v_pw", "g_dw", "v_dw", "bias")]
 
