@@ -52,20 +52,20 @@ def resnet_block(net, pre, x, idx, rs, dil):
         wd = net.w(f"{pre}.block.{dw}.conv.conv.weight")
         y = sconv1d(y, wd, net.w(f"{pre}.block.{dw}.conv.conv.bias"), dilation=d, groups=wd.shape[0])
     p = net.opt(f"{pre}.res_scale_param")
-    scale = rs * (float(p.reshape(-1)[0]) if p is not None else 1.0)
+    scale = rs * (p.reshape(-1)[0] if p is not None else 1.0)               # a tensor: differentiable for the training oracle
     return y * scale + x                                                     # seanet.py:272-277
 
 
 def spec_block(net, pre, x, wav, n_fft, hop, mean, std, rs):
     basis = net.opt(f"{pre}.spec.weight")
-    basis = _t(dft_basis(n_fft))[:, None, :] if basis is None else basis
+    basis = (_t(dft_basis(n_fft))[:, None, :] if basis is None else basis).to(wav.dtype)
     c = F.conv1d(F.pad(wav, (n_fft - 1, 0)), basis, None, stride=hop)        # conv.py:1055-1068
     Fq = n_fft // 2 + 1
     y = (c[:, :Fq] ** 2 + c[:, Fq:] ** 2).clamp_min(1e-12).sqrt()
     y = (y.clamp_min(1e-5).log() - mean) / std                               # seanet.py:484,494
     y = sconv1d(y, net.w(f"{pre}.layer.conv.conv.weight"), None)
     p = net.opt(f"{pre}.scale_param")
-    return x + y * (rs * (float(p.reshape(-1)[0]) if p is not None else 1.0))
+    return x + y * (rs * (p.reshape(-1)[0] if p is not None else 1.0))
 
 
 def encoder_forward(net, x, msg):

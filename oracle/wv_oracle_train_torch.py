@@ -1,0 +1,62 @@
+"""Gradient oracle for the detector / locator training step -- TEST INFRASTRUCTURE ONLY (tests/ import it; the product
+never does).  The same torch restatement of the forward path as oracle/wv_oracle_torch.py (pinned to the reference's
+outputs), made differentiable: the leaves are the reference's PARAMETRIZED state dict (weight norm g = original0,
+v = original1, folded inside the graph as conv.py:47-88 does on every training forward), everything in float64, and
+torch's CPU autograd supplies the gradients.  Pinned to the reference's own autograd on whole (shrunk) Detector / Locator
+modules by tests/golden/netgrads_*.npz (tests/golden/make_golden_netgrads.py).
+
+    Detector.forward / Locator.forward   /root/reference/model/detector.py:278-318,366-391, locator.py:228-299
+    LocalizationLoss / DecodingLoss      /root/reference/scripts/loss.py:947-1099"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import wv_oracle_torch as OTc
+
+_W = "weight"
+
+
+class LiveNet:
+    """Accessor over float64 leaf tensors: w(key) folds weight norm inside the autograd graph."""
+
+    def __init__(self, cfg, sd: Dict[str, np.ndarray]):
+        self.cfg = cfg
+        self.leaf = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in sd.items()
+                     if not k.endswith("spec.weight")}
+
+    def w(self, k: str) -> torch.Tensor:
+        if k in self.leaf:
+            return self.leaf[k]
+        base = k[: -len(_W)] + "parametrizations.weight."
+        g, v = self.leaf[base + "original0"], self.leaf[base + "original1"]
+        n = v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))        # norm over all dims but 0 (conv.py:73-74)
+        return g * v / n
+
+    def opt(self, k: str) -> Optional[torch.Tensor]:
+        return self.leaf.get(k)
+
+
+def logits_of(net: LiveNet, x: torch.Tensor) -> torch.Tensor:
+    z = OTc.encoder_forward(net, x, None)
+    wr = net.w("reverse_convolution.weight")
+    up = F.conv_transpose1d(z, wr, net.w("reverse_convolution.bias"), stride=wr.shape[-1])[..., : x.shape[-1]]
+    return F.conv1d(up, net.w("last_layer.weight"), net.w("last_layer.bias"))
+
+
+def loss_and_grads(cfg, sd, x, mask, msg=None, need_dx=False):
+    """-> (loss float, logits ndarray, {key: grad ndarray} for every leaf that received one, dx or None).
+    msg None: LocalizationLoss(logits[B,1,T], mask); else DecodingLoss(logits[B,nb,T], mask, msg)."""
+    net = LiveNet(cfg, sd)
+    xt = torch.tensor(np.asarray(x), dtype=torch.float64, requires_grad=need_dx)
+    logits = logits_of(net, xt)
+    target = torch.tensor(np.asarray(mask), dtype=torch.float64)
+    if msg is not None:
+        target = torch.tensor(np.asarray(msg), dtype=torch.float64).unsqueeze(2) * target
+    loss = F.binary_cross_entropy_with_logits(logits, target.expand_as(logits), reduction="mean")
+    loss.backward()
+    grads = {k: t.grad.numpy() for k, t in net.leaf.items() if t.grad is not None}
+    return float(loss.detach()), logits.detach().numpy(), grads, (xt.grad.numpy() if need_dx else None)

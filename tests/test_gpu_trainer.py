@@ -1,0 +1,93 @@
+"""The detector / locator training step on the GPU (waveverify_amd.train.EncoderNetTrainer): loss and EVERY
+parameter gradient of the whole net against (a) the reference's own autograd through whole (shrunk) Locator / Detector modules
+(tests/golden/netgrads_*.npz) and (b) the differentiable float64 oracle (oracle/wv_oracle_train_torch.py, pinned to (a)) on the
+full-size nets at 16000-sample clips; then optimizer steps against torch's AdamW driven by the oracle's gradients."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wv_oracle_train_torch as OTT
+from waveverify_amd.config import default_config
+from waveverify_amd.init import random_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def check_grads(tr, ref_grads, tol=2e-4):
+    assert sorted(tr.gviews) == sorted(ref_grads)
+    worst = ("", 0.0)
+    for k, r in ref_grads.items():
+        got = tr.gviews[k].detach().cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), k
+        e = float(np.abs(got - r.reshape(got.shape)).max() / max(np.abs(r).max(), 1e-30))
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] <= tol, worst
+    return worst
+
+
+@pytest.mark.parametrize("name", ["locator", "detector"])
+def test_whole_net_gradients_vs_reference_autograd(golden_dir, name):
+    from waveverify_amd.train import EncoderNetTrainer, bce_logits
+    g = np.load(os.path.join(golden_dir, f"netgrads_{name}.npz"))
+    c = ast.literal_eval(str(g["cfg"][0]))
+    seed, kind = c.pop("seed"), c.pop("kind")
+    cfg = default_config(kind, **c)
+    tr = EncoderNetTrainer(cfg, random_state_dict(cfg, seed, parametrized=True))
+    logits = tr.forward(_cu(g["x"]))
+    assert float(np.abs(logits.cpu().numpy() - g["logits"]).max()) <= 5e-5 * max(1.0, float(np.abs(g["logits"]).max()))
+    loss, dz = bce_logits(logits, _cu(g["mask"]), _cu(g["msg"]) if "msg" in g else None)
+    assert abs(float(loss.item()) - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    tr.backward(dz)
+    check_grads(tr, {k[2:]: g[k] for k in g.files if k.startswith("g:")})
+
+
+@pytest.mark.parametrize("kind,B", [("locator", 3), ("detector", 2)])
+def test_full_size_net_gradients_vs_oracle_and_training_steps(kind, B):
+    """Default (full-size) nets, 1 s clips: every gradient vs the float64 oracle; then three optimizer steps tracked against
+    torch.optim.AdamW fed with the oracle's gradients of the evolving parameters (clip_grad_norm_ included)."""
+    from waveverify_amd.train import EncoderNetTrainer
+    cfg = default_config(kind)
+    sd = random_state_dict(cfg, 0, parametrized=True)
+    rng = np.random.default_rng(11)
+    T = 16000
+    x = (0.1 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    mask = (rng.random((B, 1, T)) < 0.7).astype(np.float32)
+    msg = rng.integers(0, 2, (B, cfg.nbits)).astype(np.float32) if kind == "detector" else None
+    tr = EncoderNetTrainer(cfg, sd, lr=1e-3, max_norm=1.0)
+    keys = list(tr.params)
+    ref_p = {k: torch.nn.Parameter(torch.from_numpy(np.asarray(sd[k], dtype=np.float32).copy())) for k in keys}
+    opt = torch.optim.AdamW(list(ref_p.values()), lr=1e-3, betas=(0.8, 0.99))
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, 0.999996)
+    losses = []
+    for it in range(3):
+        cur = dict(sd)
+        cur.update({k: p.detach().numpy() for k, p in ref_p.items()})
+        ref_loss, _, ref_grads, _ = OTT.loss_and_grads(cfg, cur, x, mask, msg)
+        # gradients of the CURRENT parameters, before the step
+        logits = tr.forward(_cu(x))
+        from waveverify_amd.train import bce_logits
+        loss, dz = bce_logits(logits, _cu(mask), None if msg is None else _cu(msg))
+        tr.backward(dz)
+        assert abs(float(loss.item()) - ref_loss) <= 2e-5 * ref_loss, (it, float(loss.item()), ref_loss)
+        worst = check_grads(tr, ref_grads, tol=5e-4)
+        # the step itself (forward + backward again inside; deterministic kernels -> the same gradients)
+        loss2, norm = tr.step(_cu(x), _cu(mask), None if msg is None else _cu(msg))
+        assert float(loss2.item()) == float(loss.item())
+        for k, p in ref_p.items():
+            p.grad = torch.from_numpy(ref_grads[k].astype(np.float32)).view_as(p)
+        ref_norm = torch.nn.utils.clip_grad_norm_(list(ref_p.values()), 1.0)
+        opt.step(); sched.step()
+        assert abs(float(norm.item()) - float(ref_norm)) <= 5e-4 * float(ref_norm), (it, worst)
+        for k, p in ref_p.items():
+            d = float((tr.params[k].detach().cpu() - p.detach()).abs().max())
+            assert d <= 2e-5 + 5e-3 * 1e-3, (it, k, d)                       # AdamW normalises: a step is <= lr per element
+        losses.append(float(loss.item()))
+    assert all(np.isfinite(losses))

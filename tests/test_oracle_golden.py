@@ -296,3 +296,27 @@ def test_train_oracle_convpost_vs_reference_autograd(golden_dir):
         for k, ref in (("y", "y"), ("dx", "dx"), ("dg_dw", "dg_dw"), ("dv_dw", "dv_dw"), ("dg_pw", "dg_pw"), ("dv_pw", "dv_pw"), ("db", "db")):
             b = g[f"post{i}_{ref}"]
             assert float(np.abs(r[k].reshape(b.shape) - b).max() / max(np.abs(b).max(), 1e-30)) <= 2e-6, (i, k)
+
+
+@pytest.mark.parametrize("name", ["locator", "detector"])
+def test_training_gradient_oracle_vs_whole_reference_nets(golden_dir, name):
+    """oracle/wv_oracle_train_torch.py (differentiable restatement, live weight norm) against the reference's own autograd
+    through whole Locator / Detector modules and its loss classes: loss, logits, every parameter gradient, dL/dx."""
+    import ast
+    from oracle import wv_oracle_train_torch as OTT
+    from waveverify_amd.config import default_config
+    from waveverify_amd.init import random_state_dict
+    g = np.load(os.path.join(golden_dir, f"netgrads_{name}.npz"))
+    c = ast.literal_eval(str(g["cfg"][0]))
+    seed, kind = c.pop("seed"), c.pop("kind")
+    cfg = default_config(kind, **c)
+    sd = random_state_dict(cfg, seed, parametrized=True)
+    loss, logits, grads, dx = OTT.loss_and_grads(cfg, sd, g["x"], g["mask"], g["msg"] if "msg" in g else None, need_dx=True)
+    assert abs(loss - float(g["loss"])) <= 1e-8 * abs(loss)
+    assert np.abs(logits - g["logits"]).max() <= 2e-6 * max(1.0, np.abs(g["logits"]).max())
+    assert np.abs(dx - g["dx"]).max() <= 1e-4 * np.abs(g["dx"]).max()    # through log|STFT| near its clamps: amplified rounding of the float32 fixture
+    ref_keys = [k[2:] for k in g.files if k.startswith("g:")]
+    assert sorted(ref_keys) == sorted(grads)                       # the same parameters receive gradients (msg MLP / FiLM do not)
+    for k in ref_keys:
+        r = g["g:" + k]
+        assert np.abs(grads[k] - r).max() <= 5e-6 * max(np.abs(r).max(), 1e-12) + 1e-14, k

@@ -14,7 +14,9 @@ back to torch autograd."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict
+from typing import Dict, Optional
+
+import numpy as np
 
 import torch
 
@@ -487,3 +489,170 @@ class BlockTrainer:
         allreduce_mean_flat_(self.grads)
         norm = self.opt.step(self.arena, self.grads, self.max_norm)
         return loss, norm
+
+
+class EncoderNetTrainer:
+    """The training step of the Detector or the Locator on the HIP units: SEANetEncoder (msg = None) + head under the reference's
+    BCE loss (/root/reference/model/detector.py:278-318, locator.py:228-299, modules/seanet.py:883-976, scripts/loss.py:947-1099,
+    scripts/train.py:1346-1358).  `state_dict` is the reference's PARAMETRIZED layout (weight norm original0 / original1); every
+    tensor that receives a gradient in the reference lives in one flat arena (`self.arena`, views in `self.params`), its gradient
+    in `self.grads`; the message MLP and FiLM layers of the encoder are unused without a message and stay out, as they stay
+    untouched in the reference (grad None).  One process per GPU: `step` all-reduces the gradient arena over RCCL.
+    Clip lengths must keep every ResnetBlock stage a multiple of 4 samples (T = 16000 does for both nets)."""
+
+    def __init__(self, cfg, state_dict, lr: float = 1e-4, max_norm: float = 1000.0, device="cuda"):
+        from . import ops as _ops
+        if cfg.kind not in ("detector", "locator"):
+            raise ValueError("EncoderNetTrainer: detector or locator")
+        if cfg.dilation_base != 1:
+            raise NotImplementedError("training units: dilation_base = 1 only")
+        self.cfg, self._ops, self.max_norm = cfg, _ops, float(max_norm)
+        skip = ("encoder.msg_embedding.", "encoder.film_layers.")
+        items = [(k, np.asarray(v, dtype=np.float32)) for k, v in state_dict.items()
+                 if not k.startswith(skip) and not k.endswith("spec.weight")]
+        n = sum(v.size for _, v in items)
+        self.arena, self.grads = torch.empty(n, device=device), torch.zeros(n, device=device)
+        self.params, self.gviews, off = {}, {}, 0
+        for k, v in items:
+            self.arena[off:off + v.size] = torch.from_numpy(v.reshape(-1)).to(device)
+            self.params[k], self.gviews[k] = self.arena[off:off + v.size].view(v.shape), self.grads[off:off + v.size].view(v.shape)
+            off += v.size
+        rs, C = cfg.res_scale_enc, cfg.channels_enc
+        self.conv_pre = TrainConvPre(C, cfg.kernel_size)
+        self.scales = []
+        for s, r in enumerate(cfg.ratios_enc):
+            F_ = (2 ** s) * cfg.n_fft_base // 2 + 1
+            self.scales.append(dict(C=C, r=r, blocks=[TrainBlock(C) for _ in range(cfg.n_residual_enc)], spec=TrainSpecAdd(C, F_),
+                                    down=TrainUnit(C, 2 * C, 2 * r, r)))
+            C *= 2
+        self.spec_post = TrainSpecAdd(C, (2 ** len(cfg.ratios_enc)) * cfg.n_fft_base // 2 + 1)
+        self.conv_post = TrainConvPost(C, cfg.dimension, cfg.last_kernel_size)
+        self.nb = cfg.nbits if cfg.kind == "detector" else 1
+        self.head = TrainHead(cfg.dimension, cfg.output_dim, self.nb, cfg.hop_length)
+        self.down_scale = (1 + cfg.n_residual_enc * rs ** 2) ** -0.5
+        self.opt = FlatAdamW(n, lr=lr, device=device)
+        self._saved = None
+
+    # ---- parameter access by the reference's keys ------------------------------------------------------------------------------
+    def _wn(self, conv):          # weight-normed SConv1d "<conv>.conv.conv"
+        b = conv + ".conv.conv.parametrizations.weight."
+        return self.params[b + "original0"], self.params[b + "original1"]
+
+    def _half(self, pre, pw, dw):
+        g_pw, v_pw = self._wn(f"{pre}.{pw}")
+        g_dw, v_dw = self._wn(f"{pre}.{dw}")
+        return dict(g_pw=g_pw, v_pw=v_pw, g_dw=g_dw, v_dw=v_dw, b_dw=self.params[f"{pre}.{dw}.conv.conv.bias"])
+
+    def _put(self, conv, dg, dv):
+        b = conv + ".conv.conv.parametrizations.weight."
+        self.gviews[b + "original0"].copy_(dg.view_as(self.gviews[b + "original0"]))
+        self.gviews[b + "original1"].copy_(dv.view_as(self.gviews[b + "original1"]))
+
+    def _put_half(self, pre, pw, dw, g):
+        self._put(f"{pre}.{pw}", g["dg_pw"], g["dv_pw"])
+        self._put(f"{pre}.{dw}", g["dg_dw"], g["dv_dw"])
+        self.gviews[f"{pre}.{dw}.conv.conv.bias"].copy_(g["db_dw"])
+
+    def _spec_p(self, pre):
+        g, v = self._wn(pre + ".layer")
+        return dict(g=g, v=v), self.params.get(pre + ".scale_param")
+
+    def _head_p(self):
+        return dict(w_rev=self.params["reverse_convolution.weight"], b_rev=self.params["reverse_convolution.bias"],
+                    w_last=self.params["last_layer.weight"], b_last=self.params["last_layer.bias"])
+
+    # ---- forward / backward ----------------------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        cfg, rs = self.cfg, self.cfg.res_scale_enc
+        x = _f(x)
+        sv = dict(x=x, scales=[])
+        g, v = self._wn("encoder.conv_pre.1")
+        h = self.conv_pre.forward(x, dict(g=g, v=v, b=self.params["encoder.conv_pre.1.conv.conv.bias"]), 1.0 / cfg.wav_std)
+        stride = 1
+        for s, sc in enumerate(self.scales):
+            rec = dict(blocks=[])
+            for j, blk in enumerate(sc["blocks"]):
+                pre = f"encoder.blocks.{s}.{j}"
+                ps = [self._half(pre + ".block", 1, 2), self._half(pre + ".block", 4, 5)]
+                pre_scale = (1 + (j + 1) * rs ** 2) ** -0.5                         # idx = j + 1 (seanet.py:183,684)
+                y, saved = blk.forward(h, ps, self.params.get(pre + ".res_scale_param"), pre_scale, rs)
+                rec["blocks"].append((h, saved, pre_scale))
+                h = y
+            P = self._ops.stft_logmag(x, (2 ** s) * cfg.n_fft_base, stride, mean=cfg.spec_means[s], std=cfg.spec_stds[s])
+            sp, scp = self._spec_p(f"encoder.spec_blocks.{s}")
+            h = sc["spec"].forward(h, P, sp, scp, rs)
+            rec["P"], rec["down_in"] = P, h
+            h = sc["down"].forward(h, self._half(f"encoder.downsample.{s}", 2, 3), self.down_scale, True)
+            stride *= sc["r"]
+            sv["scales"].append(rec)
+        P = self._ops.stft_logmag(x, (2 ** len(self.scales)) * cfg.n_fft_base, stride, mean=cfg.spec_means[-1], std=cfg.spec_stds[-1])
+        sp, scp = self._spec_p("encoder.spec_post")
+        h = self.spec_post.forward(h, P, sp, scp, rs)
+        sv["P_post"], sv["post_in"] = P, h
+        z = self.conv_post.forward(h, self._post_p())
+        sv["z"] = z
+        self._saved = sv
+        return self.head.forward(z, self._head_p(), x.shape[-1])
+
+    def _post_p(self):
+        g_dw, v_dw = self._wn("encoder.conv_post.1")
+        g_pw, v_pw = self._wn("encoder.conv_post.2")
+        return dict(g_dw=g_dw, v_dw=v_dw, g_pw=g_pw, v_pw=v_pw, b=self.params["encoder.conv_post.2.conv.conv.bias"])
+
+    def backward(self, dlogits: torch.Tensor, need_dx: bool = False):
+        """Fills `self.grads` (every view of `self.gviews`); returns dL/dx through conv_pre when asked.  (The spectrogram
+        branches' gradient towards the audio is not part of it yet: the STFT has no backward here.)"""
+        cfg, rs, sv = self.cfg, self.cfg.res_scale_enc, self._saved
+        if sv is None:
+            raise RuntimeError("backward before forward")
+        g = self.head.backward(sv["z"], self._head_p(), dlogits)
+        for k, name in (("dw_rev", "reverse_convolution.weight"), ("db_rev", "reverse_convolution.bias"), ("dw_last", "last_layer.weight"),
+                        ("db_last", "last_layer.bias")):
+            self.gviews[name].copy_(g[k].view_as(self.gviews[name]))
+        g = self.conv_post.backward(sv["post_in"], self._post_p(), g["dz"])
+        self._put("encoder.conv_post.1", g["dg_dw"], g["dv_dw"])
+        self._put("encoder.conv_post.2", g["dg_pw"], g["dv_pw"])
+        self.gviews["encoder.conv_post.2.conv.conv.bias"].copy_(g["db"])
+        dh = g["dx"]
+
+        def spec_back(unit, pre, P, dy):
+            sp, scp = self._spec_p(pre)
+            gs = unit.backward(P, sp, scp, rs, dy)
+            self._put(pre + ".layer", gs["dg"], gs["dv"])
+            if scp is not None:
+                self.gviews[pre + ".scale_param"].copy_(gs["d_scale_param"])
+        spec_back(self.spec_post, "encoder.spec_post", sv["P_post"], dh)
+        for s in reversed(range(len(self.scales))):
+            sc, rec = self.scales[s], sv["scales"][s]
+            gd = sc["down"].backward(rec["down_in"], self._half(f"encoder.downsample.{s}", 2, 3), self.down_scale, dh, True, True)
+            self._put_half(f"encoder.downsample.{s}", 2, 3, gd)
+            dh = gd["dx"]
+            spec_back(sc["spec"], f"encoder.spec_blocks.{s}", rec["P"], dh)          # the add passes dh through unchanged
+            for j in reversed(range(len(sc["blocks"]))):
+                pre = f"encoder.blocks.{s}.{j}"
+                h_in, saved, pre_scale = rec["blocks"][j]
+                ps = [self._half(pre + ".block", 1, 2), self._half(pre + ".block", 4, 5)]
+                rsp = self.params.get(pre + ".res_scale_param")
+                gb = sc["blocks"][j].backward(h_in, ps, rsp, pre_scale, rs, dh, saved)
+                self._put_half(pre + ".block", 1, 2, gb["halves"][0])
+                self._put_half(pre + ".block", 4, 5, gb["halves"][1])
+                if rsp is not None:
+                    self.gviews[pre + ".res_scale_param"].copy_(gb["d_res_scale_param"])
+                dh = gb["dx"]
+        gv = self._wn("encoder.conv_pre.1")
+        gp = self.conv_pre.backward(sv["x"], dict(g=gv[0], v=gv[1], b=self.params["encoder.conv_pre.1.conv.conv.bias"]), 1.0 / cfg.wav_std,
+                                    dh, need_dx)
+        self._put("encoder.conv_pre.1", gp["dg"], gp["dv"])
+        self.gviews["encoder.conv_pre.1.conv.conv.bias"].copy_(gp["db"])
+        self._saved = None
+        return gp["dx"]
+
+    def step(self, x: torch.Tensor, mask: torch.Tensor, msg: Optional[torch.Tensor] = None):
+        """One optimizer step on this rank's clips: LocalizationLoss (locator: msg None) or DecodingLoss (detector) ->
+        backward -> mean all-reduce of the gradient arena -> clip + AdamW + ExponentialLR.  Returns (loss, gradient norm)."""
+        from .parallel import allreduce_mean_flat_
+        logits = self.forward(x)
+        loss, dz = bce_logits(logits, mask, msg)
+        self.backward(dz)
+        allreduce_mean_flat_(self.grads)
+        return loss, self.opt.step(self.arena, self.grads, self.max_norm)
