@@ -49,10 +49,11 @@ def parse():
     ap.add_argument("--cpu-clips", type=int, default=16, help="clips of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="embed_detect",
-                    choices=["embed_detect", "longform", "detector_stress", "grad_allreduce"],
+                    choices=["embed_detect", "longform", "detector_stress", "grad_allreduce", "train_det_loc"],
                     help="embed_detect = BASELINE configs[1] (the headline); longform = configs[3] "
                          "(32 x 30 s, embed+locate+detect); detector_stress = configs[4] (1024 clips, detector "
-                         "only); grad_allreduce = configs[2]'s gradient exchange (no model compute)")
+                         "only); grad_allreduce = configs[2]'s gradient exchange (no model compute); train_det_loc = the "
+                         "detector + locator part of configs[2]'s training step (64 clips per GPU) on the HIP training units")
     ap.add_argument("--bucket-mb", type=float, default=25.0, help="grad_allreduce: bucket size")
     return ap.parse_args()
 
@@ -130,6 +131,60 @@ def grad_allreduce(a, dev, dist, world, rank):
             note="bus GB/s = 2(N-1)/N * bytes / time (ring); xGMI gives one ~153 GB/s link per peer")), flush=True)
 
 
+def train_det_loc(a, dev, dist, world, rank):
+    """The detector and locator training steps of BASELINE configs[2] (64 clips x 1 s per GPU): live weight norm, forward,
+    DecodingLoss / LocalizationLoss, backward, mean all-reduce of the flat gradient arenas (RCCL when N > 1), clip + AdamW.
+    The generator / discriminator part of the reference's step is not built yet, so this is NOT the headline metric."""
+    from waveverify_amd.config import default_config
+    from waveverify_amd.init import random_state_dict, synthetic_clips
+    from waveverify_amd.train import EncoderNetTrainer
+    B = 64 if a.batch == 256 else a.batch
+    T = int(round(a.seconds * 16000))
+    x_np, msg_np = synthetic_clips(B, T, seed=1234 + rank)
+    rng = np.random.default_rng(99 + rank)
+    x, msg = torch.from_numpy(x_np).to(dev), torch.from_numpy(msg_np.astype(np.float32)).to(dev)
+    mask = torch.from_numpy((rng.random((B, 1, T)) < 0.8).astype(np.float32)).to(dev)
+    cfgD, cfgL = default_config("detector"), default_config("locator")
+    trD = EncoderNetTrainer(cfgD, random_state_dict(cfgD, 0, parametrized=True), device=dev)
+    trL = EncoderNetTrainer(cfgL, random_state_dict(cfgL, 0, parametrized=True), device=dev)
+    losses = []
+
+    def step():
+        ld, _ = trD.step(x, mask, msg)
+        ll, _ = trL.step(x, mask, None)
+        losses.append((ld, ll))
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        first, last = losses[0], losses[-1]
+        print(json.dumps(dict(
+            metric="clips/sec detector+locator training step, 1s@16kHz bs=64 per GPU", value=round(world * B * a.steps / elapsed, 2),
+            unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
+            vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload=f"train_det_loc: detector + locator training steps of BASELINE.json configs[2] ({B} clips x {a.seconds:g} s per GPU); "
+                                 "generator / discriminator steps not built", batch_per_gpu=B, global_batch=B * world, clip_samples=T,
+                        parallelism=f"dp{world} (flat gradient arenas, bucketed mean all-reduce)",
+                        parameters=dict(detector=int(trD.arena.numel()), locator=int(trL.arena.numel()))),
+            loss_first=[round(float(v.item()), 5) for v in first], loss_last=[round(float(v.item()), 5) for v in last],
+            note="first correct version of the backward path (recompute-based, unfused); no roofline claim")), flush=True)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,8 +199,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)          # RCCL; used for barrier + MAX only (embed/detect)
         world = dist.get_world_size()                            # n_gpus is what RCCL reports
-    if a.workload == "grad_allreduce":
-        grad_allreduce(a, dev, dist, world, rank)
+    if a.workload in ("grad_allreduce", "train_det_loc"):
+        (grad_allreduce if a.workload == "grad_allreduce" else train_det_loc)(a, dev, dist, world, rank)
         if dist:
             dist.destroy_process_group()
         return

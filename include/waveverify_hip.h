@@ -181,6 +181,13 @@ int wv_op_stft_logmag(const float* wav, const float* host_basis, float* P, int B
                       int n_fft, int hop, float mean, float std, void* stream);
 
 /* conv_pre: Y = Conv1d(1->C,k)(x * in_scale) + bias  (seanet.py:657-664). x [B,1,T], w [C,1,k]. */
+
+/* The same op with the basis packed and uploaded ONCE (a training step computes these features for every scale at every step):
+ * basis_or_null as in wv_op_stft_logmag (NULL = the reference's windowed DFT basis). */
+typedef struct wv_stft_plan wv_stft_plan;
+int wv_stft_plan_create(int n_fft, const float* basis_or_null, wv_stft_plan** out);
+void wv_stft_plan_destroy(wv_stft_plan* p);
+int wv_stft_plan_logmag(const wv_stft_plan* p, const float* wav, float* P, int B, int T, int hop, float mean, float std, void* stream);
 int wv_op_conv_pre(const float* x, const float* w, const float* bias, float* Y, int B, int C,
                    int T, int ks, float in_scale, void* stream);
 

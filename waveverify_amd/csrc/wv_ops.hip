@@ -128,14 +128,14 @@ int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const floa
     return done(t, wv::launch_dw_pw(a, (hipStream_t)stream), (hipStream_t)stream);
 }
 
-int wv_op_stft_logmag(const float* wav, const float* host_basis, float* P, int B, int T, int n_fft,
-                      int hop, float mean, float std, void* stream) {
-    if (!wav || !P || B < 1 || T < 1 || n_fft < 2 || hop < 1) return WV_EINVAL;
+// host: the reference's windowed DFT basis [2F][n_fft] (conv.py:1003-1026), or the caller's
+static std::vector<float> stft_basis_host(const float* basis_or_null, int n_fft) {
     const int F = n_fft / 2 + 1;
-    std::vector<float> basis;
-    if (host_basis) basis.assign(host_basis, host_basis + (size_t)2 * F * n_fft);
-    else {
-        basis.resize((size_t)2 * F * n_fft);
+    std::vector<float> basis((size_t)2 * F * n_fft);
+    if (basis_or_null) {
+        std::memcpy(basis.data(), basis_or_null, basis.size() * sizeof(float));
+    } else {
+        // float32 arithmetic in the reference's order (bit-identical to its buffer: tests/golden/dft_basis.npz)
         const float c = (float)(-2.0 * M_PI / n_fft), wc = (float)(2.0 * M_PI / n_fft);
         for (int k = 0; k < F; ++k) {
             volatile float ck = c * (float)k;
@@ -148,7 +148,15 @@ int wv_op_stft_logmag(const float* wav, const float* host_basis, float* P, int B
             }
         }
     }
+    return basis;
+}
+
+int wv_op_stft_logmag(const float* wav, const float* basis_or_null, float* P, int B, int T, int n_fft,
+                      int hop, float mean, float std, void* stream) {
+    if (!wav || !P || B < 1 || T < 1 || hop < 1) return WV_EINVAL;
     if (n_fft < 4 || (n_fft & 1)) return WV_EINVAL;
+    const int F = n_fft / 2 + 1;
+    const std::vector<float> basis = stft_basis_host(basis_or_null, n_fft);
     std::vector<float> bt, side;
     int Mp = 0;
     wv::pack_stft_basis(basis.data(), n_fft, bt, side, &Mp);
@@ -157,6 +165,45 @@ int wv_op_stft_logmag(const float* wav, const float* host_basis, float* P, int B
     a.wav = wav; a.basis_t = t.upv(bt); a.basis_q = t.upv(wv::pack_stft_q(bt, n_fft, Mp)); a.side = t.upv(side); a.P = P; a.B = B; a.T = T; a.Tf = (T + hop - 1) / hop;
     a.n_fft = n_fft; a.hop = hop; a.F = F; a.Mp = Mp; a.mean = mean; a.inv_std = 1.f / std;
     return done(t, wv::launch_stft_logmag(a, (hipStream_t)stream), (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// A resident plan of the same op (the basis packed and uploaded once): what a training step calls once per scale and step.
+struct wv_stft_plan {
+    int n_fft = 0, Mp = 0;
+    float *basis_t = nullptr, *basis_q = nullptr, *side = nullptr;
+    ~wv_stft_plan() { (void)hipFree(basis_t); (void)hipFree(basis_q); (void)hipFree(side); }
+};
+
+extern "C" {
+
+int wv_stft_plan_create(int n_fft, const float* basis_or_null, wv_stft_plan** out) {
+    if (!out || n_fft < 4 || (n_fft & 1)) return WV_EINVAL;
+    const std::vector<float> basis = stft_basis_host(basis_or_null, n_fft);
+    std::vector<float> bt, side;
+    auto* p = new wv_stft_plan();
+    p->n_fft = n_fft;
+    wv::pack_stft_basis(basis.data(), n_fft, bt, side, &p->Mp);
+    const std::vector<float> bq = wv::pack_stft_q(bt, n_fft, p->Mp);
+    auto up = [](float** d, const std::vector<float>& v) {
+        return hipMalloc((void**)d, v.size() * sizeof(float)) == hipSuccess &&
+               hipMemcpy(*d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!(up(&p->basis_t, bt) && up(&p->basis_q, bq) && up(&p->side, side))) { delete p; return WV_EHIP; }
+    *out = p;
+    return WV_OK;
+}
+
+void wv_stft_plan_destroy(wv_stft_plan* p) { delete p; }
+
+int wv_stft_plan_logmag(const wv_stft_plan* p, const float* wav, float* P, int B, int T, int hop, float mean, float std, void* stream) {
+    if (!p || !wav || !P || B < 1 || T < 1 || hop < 1 || !(std > 0.f)) return WV_EINVAL;
+    wv::StftArgs a{};
+    a.wav = wav; a.basis_t = p->basis_t; a.basis_q = p->basis_q; a.side = p->side; a.P = P; a.B = B; a.T = T; a.Tf = (T + hop - 1) / hop;
+    a.n_fft = p->n_fft; a.hop = hop; a.F = p->n_fft / 2 + 1; a.Mp = p->Mp; a.mean = mean; a.inv_std = 1.f / std;
+    const hipError_t e = wv::launch_stft_logmag(a, (hipStream_t)stream);
+    return e == hipSuccess ? WV_OK : (e == hipErrorInvalidValue ? WV_EINVAL : WV_EHIP);
 }
 
 int wv_op_conv_pre(const float* x, const float* w, const float* bias, float* Y, int B, int C, int T,

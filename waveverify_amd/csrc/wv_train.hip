@@ -86,51 +86,69 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ g
 //   dh[t] = sum_{i : (t + pad - i) = n * stride, 0 <= n < Tout} w[i] * dy[n]
 //   partial[b][m][i] = sum_n dy[n] * h[n * stride + i - pad]  (i < ks),  partial[b][m][ks] = sum_n dy[n].
 constexpr int TRAIN_MAX_KS = 16;
+// CKS / CSTRIDE: compile-time kernel size and stride of the net's own stencils (0 = read them at run time): the tap loops
+// unroll to exactly ks steps and the divisions by the stride become shifts / multiplies.
+template <int CKS, int CSTRIDE>
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ h,
                                                      const float* __restrict__ w, float* __restrict__ dh,
-                                                     float* __restrict__ partial, int M, int Tin, int Tout, int ks, int stride, int pad,
-                                                     int h_shared = 0) {
+                                                     float* __restrict__ partial, int M, int Tin, int Tout, int ks_rt, int stride_rt, int pad,
+                                                     int h_shared) {
+    constexpr int NK = CKS ? CKS : TRAIN_MAX_KS;
+    const int ks = CKS ? CKS : ks_rt, stride = CSTRIDE ? CSTRIDE : stride_rt;
     __shared__ float red[4][TRAIN_MAX_KS + 1];
     const int m = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     // h_shared: one input row per clip feeds every channel (conv_pre: h = the waveform); dh may be null
     const size_t row_h = h_shared ? (size_t)b * Tin : ((size_t)b * M + m) * Tin, row_y = ((size_t)b * M + m) * Tout;
     const float* dyr = dy + row_y;
     const float* hr = h + row_h;
-    float wt[TRAIN_MAX_KS];
+    float wt[NK];
 #pragma unroll
-    for (int i = 0; i < TRAIN_MAX_KS; ++i) wt[i] = i < ks ? w[m * ks + i] : 0.f;
+    for (int i = 0; i < NK; ++i) wt[i] = (dh && i < ks) ? w[m * ks + i] : 0.f;
     for (int t = tid; dh && t < Tin; t += 256) {
         float g = 0.f;
 #pragma unroll
-        for (int i = 0; i < TRAIN_MAX_KS; ++i) {
+        for (int i = 0; i < NK; ++i) {
             const int u = t + pad - i;
             if (i < ks && u >= 0 && u % stride == 0 && u / stride < Tout) g = fmaf(wt[i], dyr[u / stride], g);
         }
         dh[((size_t)b * M + m) * Tin + t] = g;
     }
-    float acc[TRAIN_MAX_KS + 1];
+    float acc[NK + 1];
 #pragma unroll
-    for (int i = 0; i <= TRAIN_MAX_KS; ++i) acc[i] = 0.f;
+    for (int i = 0; i <= NK; ++i) acc[i] = 0.f;
     for (int n = tid; n < Tout; n += 256) {
         const float d = dyr[n];
 #pragma unroll
-        for (int i = 0; i < TRAIN_MAX_KS; ++i) {
+        for (int i = 0; i < NK; ++i) {
             const int tb = n * stride + i - pad;
             if (i < ks && tb >= 0 && tb < Tin) acc[i] = fmaf(d, hr[tb], acc[i]);
         }
-        acc[TRAIN_MAX_KS] += d;
+        acc[NK] += d;
     }
 #pragma unroll
-    for (int i = 0; i <= TRAIN_MAX_KS; ++i) {
+    for (int i = 0; i <= NK; ++i) {
         float v = acc[i];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if ((tid & 63) == 0) red[tid >> 6][i] = v;
     }
     __syncthreads();
     if (tid <= ks) {
-        const int src = tid < ks ? tid : TRAIN_MAX_KS;
+        const int src = tid < ks ? tid : NK;
         partial[((size_t)b * M + m) * (ks + 1) + tid] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
     }
+}
+
+static void launch_dw_bwd(hipStream_t s, const float* dy, const float* h, const float* w, float* dh, float* partial, int M, int B, int Tin,
+                          int Tout, int ks, int stride, int pad, int h_shared) {
+#define WV_DWB(K, S) hipLaunchKernelGGL((dw_bwd_kernel<K, S>), dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tin, Tout, ks, stride, pad, h_shared)
+    if (ks == 5 && stride == 1) WV_DWB(5, 1);
+    else if (ks == 1 && stride == 1) WV_DWB(1, 1);
+    else if (ks == 4 && stride == 2) WV_DWB(4, 2);
+    else if (ks == 8 && stride == 4) WV_DWB(8, 4);
+    else if (ks == 10 && stride == 5) WV_DWB(10, 5);
+    else if (ks == 16 && stride == 8) WV_DWB(16, 8);
+    else WV_DWB(0, 0);
+#undef WV_DWB
 }
 
 // out[j] = sum_{s < S} part[s][j], fixed order (deterministic)
@@ -171,12 +189,12 @@ __global__ void elu_bwd_tail_kernel(const float* da, const float* x, float* dx, 
 
 // ---- dW = sum_{b,t} dh[b,m,t] * ELU(s x[b,k,t]) -----------------------------------------------------------------
 // "NT" GEMM: both operands contract over their contiguous time axis.  Workgroup = 4 waves = a 64 x 64 tile of dW,
-// one 32 x 32 block per wave; clips are dealt round-robin to the gridDim.z splits.  Per step 64 time samples of 64
+// one 32 x 32 block per wave; (clip, time chunk) items are dealt round-robin to the gridDim.z splits.  Per step 64 time samples of 64
 // rows of each operand are staged in LDS with coalesced 16-byte row loads ([row][t], row stride 65 floats so that the
 // 32 lanes of a fragment read -- same t, consecutive rows -- hit 32 banks), the ELU of the second operand is applied
 // on the way in.  part[split][M][K] partial sums; a fixed-order pass adds the splits.
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ dh, const float* __restrict__ x,
-                                                      float* __restrict__ part, float s, int elu, int B, int M, int K, int T) {
+                                                      float* __restrict__ part, float s, int elu, int B, int M, int K, int T, int TC) {
     constexpr int LD = 65;
     __shared__ float As[64 * LD], Bs[64 * LD];
     const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 64, split = blockIdx.z, S = gridDim.z;
@@ -187,15 +205,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int lr = tid >> 2, lc = (tid & 3) * 16;              // loader: row lr (0..63), 16 consecutive t from lc
-    for (int b = split; b < B; b += S) {
+    const int nch = (T + TC - 1) / TC;                         // work items = (clip, TC-sample time chunk), dealt round-robin to the splits
+    for (int item = split; item < B * nch; item += S) {
+        const int b = item / nch, tb = (item - b * nch) * TC, te = min(T, tb + TC);
         const float* dhb = dh + (size_t)b * M * T;
         const float* xb = x + (size_t)b * K * T;
-        for (int t0 = 0; t0 < T; t0 += 64) {
+        for (int t0 = tb; t0 < te; t0 += 64) {
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int t = t0 + lc + q;
-                const bool tv = t < T;
+                const bool tv = t < te;
                 As[lr * LD + lc + q] = (tv && m0 + lr < M) ? dhb[(size_t)(m0 + lr) * T + t] : 0.f;
                 float xv = (tv && k0 + lr < K) ? xb[(size_t)(k0 + lr) * T + t] : 0.f;
                 xv *= s;
@@ -471,13 +491,23 @@ void wv_train_unit_destroy(wv_train_unit* h) { delete h; }
 int wv_train_half_create(int C, wv_train_unit** out) { return wv_train_unit_create(C, C, 5, 1, out); }
 void wv_train_half_destroy(wv_train_unit* h) { delete h; }
 
-static int nt_splits(int B) { return B < 32 ? B : 32; }
+// splits of the dW GEMM: enough workgroups to fill the chip even when the weight matrix is one 64 x 64 tile (C = 64 layers), within
+// a 64 MB scratch; a function of the shapes only, so the summation order -- and the result -- is reproducible
+struct NtPlan { int S, TC; };
+static NtPlan nt_plan(int B, int T, int M, int K) {
+    const long long tiles = (long long)((M + 63) / 64) * ((K + 63) / 64);
+    const int TC = 512;
+    const long long items = (long long)B * ((T + TC - 1) / TC);
+    long long S = std::min<long long>(items, std::max<long long>(1, 2048 / tiles));
+    while (S > 1 && S * M * K > (16LL << 20)) S /= 2;
+    return NtPlan{(int)S, TC};
+}
 static int t_out(const wv_train_unit* h, int Tin) { return (Tin + h->stride - 1) / h->stride; }
 
 size_t wv_train_unit_workspace_bytes(const wv_train_unit* h, int B, int Tin) {
     if (!h || B < 1 || Tin < 1) return 0;
     const size_t am = al256((size_t)B * h->M * Tin * 4), ak = al256((size_t)B * h->K * Tin * 4);
-    return 2 * am + ak + al256((size_t)B * h->M * (h->ks + 1) * 4) + al256((size_t)nt_splits(B) * h->M * h->K * 4);
+    return 2 * am + ak + al256((size_t)B * h->M * (h->ks + 1) * 4) + al256((size_t)nt_plan(B, Tin, h->M, h->K).S * h->M * h->K * 4);
 }
 size_t wv_train_half_workspace_bytes(const wv_train_unit* h, int B, int T) { return wv_train_unit_workspace_bytes(h, B, T); }
 
@@ -542,7 +572,7 @@ int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, 
     a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
     T_LAUNCH(wv::launch_pw_dw(a, s));
     // dh, and the per-clip partial sums of the tap / bias gradients
-    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(M, B), dim3(256), 0, s, dy, H, h->w_dw, DH, partial, M, Tin, Tout, ks, h->stride, h->pad);
+    wv::launch_dw_bwd(s, dy, H, h->w_dw, DH, partial, M, B, Tin, Tout, ks, h->stride, h->pad, 0);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((M * (ks + 1) + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)M * (ks + 1));
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((M + 255) / 256), dim3(256), 0, s, h->dwdb, h->dw_taps, db, M, ks);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(M), dim3(256), 0, s, g_dw, v_dw, h->inv_dw, h->dw_taps, dg_dw, dv_dw, ks);
@@ -561,8 +591,9 @@ int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, 
         }
     }
     // dW = sum dh a^T, then the weight-norm backward
-    const int S = nt_splits(B);
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((M + 63) / 64, (K + 63) / 64, S), dim3(256), 0, s, DH, x, parts, pre_scale, pre_elu, B, M, K, Tin);
+    const NtPlan np_ = nt_plan(B, Tin, M, K);
+    const int S = np_.S;
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((M + 63) / 64, (K + 63) / 64, S), dim3(256), 0, s, DH, x, parts, pre_scale, pre_elu, B, M, K, Tin, np_.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)M * K + 255) / 256)), dim3(256), 0, s, parts, h->dW, S, (size_t)M * K);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(M), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, K);
     T_LAUNCH(hipGetLastError());
@@ -715,7 +746,7 @@ int wv_train_convpre_backward(wv_train_convpre* h, const float* x, const float* 
     hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(C), dim3(256), 0, s, g, v, h->w, h->inv, (float*)nullptr, (float*)nullptr, C, ks, 0, 0,
                        (const float*)nullptr, 1.f);
     // per-clip partial sums of dW[c][i] = sum_t dy[c][t] x[t - (ks-1) + i] and of db, then the fixed-order sum over clips
-    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(C, B), dim3(256), 0, s, dy, x, h->w, (float*)nullptr, (float*)ws, C, T, T, ks, 1, ks - 1, 1);
+    wv::launch_dw_bwd(s, dy, x, h->w, (float*)nullptr, (float*)ws, C, B, T, T, ks, 1, ks - 1, 1);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((C * (ks + 1) + 255) / 256), dim3(256), 0, s, (const float*)ws, h->dwdb, B, (size_t)C * (ks + 1));
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((C + 255) / 256), dim3(256), 0, s, h->dwdb, h->taps, db, C, ks, in_scale);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g, v, h->inv, h->taps, dg, dv, ks);
@@ -752,7 +783,7 @@ int wv_train_spec_create(int C, int F, wv_train_spec** out) {
 }
 void wv_train_spec_destroy(wv_train_spec* h) { delete h; }
 size_t wv_train_spec_workspace_bytes(const wv_train_spec* h, int B, int T) {
-    return (h && B > 0 && T > 0) ? al256((size_t)nt_splits(B) * h->C * h->F * 4) : 0;
+    return (h && B > 0 && T > 0) ? al256((size_t)nt_plan(B, T, h->C, h->F).S * h->C * h->F * 4) : 0;
 }
 
 int wv_train_spec_forward(wv_train_spec* h, const float* x, const float* P, const float* g, const float* v, const float* scale_param,
@@ -778,12 +809,14 @@ int wv_train_spec_backward(wv_train_spec* h, const float* P, const float* g, con
     if (scale_param && !d_scale_param) return tfail(WV_EINVAL, "scale_param without a gradient slot");
     if (B < 1 || T < 1 || !ws || ws_bytes < wv_train_spec_workspace_bytes(h, B, T)) return tfail(WV_ENOMEM, "workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const int C = h->C, F = h->F, S = nt_splits(B);
+    const int C = h->C, F = h->F;
+    const NtPlan np_ = nt_plan(B, T, C, F);
+    const int S = np_.S;
     const size_t n = (size_t)C * F;
     hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(C), dim3(256), 0, s, g, v, h->w, h->inv, (float*)nullptr, (float*)nullptr, C, F, 0, 0,
                        (const float*)nullptr, 1.f);
     // G = sum_{b,t} dy P^T;  d scale_param = res_scale * <W, G>  (= res_scale * sum dy . (W @ P));  dW = s * G
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((C + 63) / 64, (F + 63) / 64, S), dim3(256), 0, s, dy, P, (float*)ws, 1.f, 0, B, C, F, T);
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((C + 63) / 64, (F + 63) / 64, S), dim3(256), 0, s, dy, P, (float*)ws, 1.f, 0, B, C, F, T, np_.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws, h->dW, S, n);
     if (d_scale_param) hipLaunchKernelGGL(wv::dot_small_kernel, dim3(1), dim3(256), 0, s, h->w, h->dW, n, res_scale, d_scale_param);
     hipLaunchKernelGGL(wv::scale_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dW, n, scale_param, res_scale);
@@ -827,7 +860,7 @@ void wv_train_convpost_destroy(wv_train_convpost* h) { delete h; }
 size_t wv_train_convpost_workspace_bytes(const wv_train_convpost* h, int B, int T) {
     if (!h || B < 1 || T < 1) return 0;
     const size_t ac = al256((size_t)B * h->C * T * 4), ad = al256((size_t)B * h->D * T * 4);
-    return 3 * ac + ad + al256((size_t)B * std::max(h->C * (h->ks + 1), h->D * 2) * 4) + al256((size_t)nt_splits(B) * h->D * h->C * 4);
+    return 3 * ac + ad + al256((size_t)B * std::max(h->C * (h->ks + 1), h->D * 2) * 4) + al256((size_t)nt_plan(B, T, h->D, h->C).S * h->D * h->C * 4);
 }
 
 static int convpost_fold(wv_train_convpost* h, const float* g_dw, const float* v_dw, const float* g_pw, const float* v_pw, hipStream_t s) {
@@ -865,7 +898,9 @@ int wv_train_convpost_backward(wv_train_convpost* h, const float* x, const float
     if (!h || !x || !g_dw || !v_dw || !g_pw || !v_pw || !dy || !dx || !dg_dw || !dv_dw || !dg_pw || !dv_pw || !db) return tfail(WV_EINVAL, "null argument");
     if (B < 1 || T < 1 || !ws || ws_bytes < wv_train_convpost_workspace_bytes(h, B, T)) return tfail(WV_ENOMEM, "workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const int C = h->C, D = h->D, ks = h->ks, S = nt_splits(B);
+    const int C = h->C, D = h->D, ks = h->ks;
+    const NtPlan np_ = nt_plan(B, T, D, C);
+    const int S = np_.S;
     const size_t ac = al256((size_t)B * C * T * 4), ad = al256((size_t)B * D * T * 4);
     char* w = (char*)ws;
     float* A = (float*)w; float* H = (float*)(w + ac); float* DH = (float*)(w + 2 * ac); float* Z = (float*)(w + 3 * ac);
@@ -886,10 +921,10 @@ int wv_train_convpost_backward(wv_train_convpost* h, const float* x, const float
         dZ = Z;
     }
     // db = sum dz (the bias slot of the row-sum kernel with one tap), dW = sum dz h^T
-    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(D, B), dim3(256), 0, s, dZ, dZ, h->junk, (float*)nullptr, partial, D, T, T, 1, 1, 0, 0);
+    wv::launch_dw_bwd(s, dZ, dZ, h->junk, (float*)nullptr, partial, D, B, T, T, 1, 1, 0, 0);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((D * 2 + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)D * 2);
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((D + 255) / 256), dim3(256), 0, s, h->dwdb, h->junk, db, D, 1, 1.f);
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((D + 63) / 64, (C + 63) / 64, S), dim3(256), 0, s, dZ, H, parts, 1.f, 0, B, D, C, T);
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((D + 63) / 64, (C + 63) / 64, S), dim3(256), 0, s, dZ, H, parts, 1.f, 0, B, D, C, T, np_.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)D * C + 255) / 256)), dim3(256), 0, s, parts, h->dW, S, (size_t)D * C);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(D), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, C);
     T_LAUNCH(hipGetLastError());
@@ -900,7 +935,7 @@ int wv_train_convpost_backward(wv_train_convpost* h, const float* x, const float
     t.pre_scale = 1.f; t.pre_elu = 0; t.out_scale = 1.f; t.bands = 1; t.film_stride = 2;
     T_LAUNCH(wv::launch_pw_dw(t, s));
     // through the depth-wise conv (da into the H buffer) and the ELU
-    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(C, B), dim3(256), 0, s, DH, A, h->w_dw, H, partial, C, T, T, ks, 1, ks - 1, 0);
+    wv::launch_dw_bwd(s, DH, A, h->w_dw, H, partial, C, B, T, T, ks, 1, ks - 1, 0);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((C * (ks + 1) + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)C * (ks + 1));
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((C + 255) / 256), dim3(256), 0, s, h->dwdb, h->taps, h->junk, C, ks, 1.f);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g_dw, v_dw, h->inv_dw, h->taps, dg_dw, dv_dw, ks);
@@ -941,13 +976,12 @@ int wv_train_head_create(int D, int O, int nb, int hop, wv_train_head** out) {
 }
 void wv_train_head_destroy(wv_train_head* h) { delete h; }
 
-static int head_splits(int B, size_t mk) { return (int)std::max<size_t>(1, std::min<size_t>(nt_splits(B), ((size_t)16 << 20) / std::max<size_t>(mk, 1))); }
 
 size_t wv_train_head_workspace_bytes(const wv_train_head* h, int B, int N) {
     if (!h || B < 1 || N < 1) return 0;
     const size_t hn = (size_t)h->hop * N;
     const size_t aq = al256((size_t)B * h->O * hn * 4), al = al256((size_t)B * h->nb * hn * 4);
-    const size_t p1 = (size_t)head_splits(B, (size_t)h->D * h->O * h->hop) * h->D * h->O * h->hop, p2 = (size_t)head_splits(B, (size_t)h->nb * h->O) * h->nb * h->O;
+    const size_t p1 = (size_t)nt_plan(B, N, h->D, h->O * h->hop).S * h->D * h->O * h->hop, p2 = (size_t)nt_plan(B, (int)hn, h->nb, h->O).S * h->nb * h->O;
     return 2 * aq + al + al256(std::max(p1, p2) * 4) + al256((size_t)B * std::max(h->nb, h->O) * 2 * 4);
 }
 
@@ -997,7 +1031,8 @@ int wv_train_head_backward(wv_train_head* h, const float* z, const float* w_rev,
     hipStream_t s = (hipStream_t)stream;
     const int D = h->D, O = h->O, nb = h->nb, hop = h->hop, OH = O * hop;
     const size_t hn = (size_t)hop * N, aq = al256((size_t)B * O * hn * 4), al = al256((size_t)B * nb * hn * 4);
-    const size_t p1 = (size_t)head_splits(B, (size_t)D * OH) * D * OH, p2 = (size_t)head_splits(B, (size_t)nb * O) * nb * O;
+    const NtPlan np1 = nt_plan(B, N, D, OH), np2 = nt_plan(B, (int)hn, nb, O);
+    const size_t p1 = (size_t)np1.S * D * OH, p2 = (size_t)np2.S * nb * O;
     char* w = (char*)ws;
     float* q = (float*)w; float* dq = (float*)(w + aq); float* dlq = (float*)(w + 2 * aq);
     float* parts = (float*)(w + 2 * aq + al);
@@ -1006,10 +1041,10 @@ int wv_train_head_backward(wv_train_head* h, const float* z, const float* w_rev,
     if (rc) return rc;
     hipLaunchKernelGGL(wv::time_to_frames_kernel, dim3((unsigned)((hn + 255) / 256), B * nb), dim3(256), 0, s, dlogits, dlq, T, hop, N);
     // last layer: dw_last[k][o] = sum dlq[k] . q[o] over (b, j, n);  db_last[k] = sum dlogits
-    const int S2 = head_splits(B, (size_t)nb * O);
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((nb + 63) / 64, (O + 63) / 64, S2), dim3(256), 0, s, dlq, q, parts, 1.f, 0, B, nb, O, (int)hn);
+    const int S2 = np2.S;
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((nb + 63) / 64, (O + 63) / 64, S2), dim3(256), 0, s, dlq, q, parts, 1.f, 0, B, nb, O, (int)hn, np2.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)nb * O + 255) / 256)), dim3(256), 0, s, parts, dw_last, S2, (size_t)nb * O);
-    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(nb, B), dim3(256), 0, s, dlq, dlq, h->junk, (float*)nullptr, partial, nb, (int)hn, (int)hn, 1, 1, 0, 0);
+    wv::launch_dw_bwd(s, dlq, dlq, h->junk, (float*)nullptr, partial, nb, B, (int)hn, (int)hn, 1, 1, 0, 0);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((nb * 2 + 255) / 256), dim3(256), 0, s, partial, h->scr, B, (size_t)nb * 2);
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, h->scr, h->junk, db_last, nb, 1, 1.f);
     // dq = w_last^T @ dlq
@@ -1017,11 +1052,11 @@ int wv_train_head_backward(wv_train_head* h, const float* z, const float* w_rev,
     T_LAUNCH(hipGetLastError());
     T_LAUNCH(head_gemm(dlq, head_pw(O, nb, h->wt_lT), nullptr, dq, B, (int)hn, s));
     // db_rev[o] = sum dq[o];  dw_rev[d][(o,j)] = sum_{b,n} z[d][n] dq[(o,j)][n];  dz = w_rev @ dq
-    hipLaunchKernelGGL(wv::dw_bwd_kernel, dim3(O, B), dim3(256), 0, s, dq, dq, h->junk, (float*)nullptr, partial, O, (int)hn, (int)hn, 1, 1, 0, 0);
+    wv::launch_dw_bwd(s, dq, dq, h->junk, (float*)nullptr, partial, O, B, (int)hn, (int)hn, 1, 1, 0, 0);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((O * 2 + 255) / 256), dim3(256), 0, s, partial, h->scr, B, (size_t)O * 2);
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((O + 255) / 256), dim3(256), 0, s, h->scr, h->junk, db_rev, O, 1, 1.f);
-    const int S1 = head_splits(B, (size_t)D * OH);
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((D + 63) / 64, (OH + 63) / 64, S1), dim3(256), 0, s, z, dq, parts, 1.f, 0, B, D, OH, N);
+    const int S1 = np1.S;
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((D + 63) / 64, (OH + 63) / 64, S1), dim3(256), 0, s, z, dq, parts, 1.f, 0, B, D, OH, N, np1.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)D * OH + 255) / 256)), dim3(256), 0, s, parts, dw_rev, S1, (size_t)D * OH);
     hipLaunchKernelGGL(wv::pack_wt_kernel, dim3((unsigned)(((size_t)D * OH + 255) / 256)), dim3(256), 0, s, w_rev, h->wt_dz, D, OH, wv::round_up(D, wv::M_ALIGN), 0);
     T_LAUNCH(hipGetLastError());

@@ -156,6 +156,27 @@ class _Handle:
             pass
 
 
+class StftFeatures(_Handle):
+    """Normalised log-magnitude CausalSTFT features of one scale (/root/reference/modules/conv.py:1036-1086, seanet.py:479-494)
+    with the DFT basis packed and uploaded once."""
+    _create, _destroy = "wv_stft_plan_create", "wv_stft_plan_destroy"
+
+    def __init__(self, n_fft: int, hop: int, mean: float, std: float):
+        self.n_fft, self.hop, self.mean, self.std = int(n_fft), int(hop), float(mean), float(std)
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        if self._lib.wv_stft_plan_create(self.n_fft, None, C.byref(self._h)) != 0:
+            raise RuntimeError("wv_stft_plan_create failed")
+
+    def __call__(self, wav: torch.Tensor) -> torch.Tensor:
+        wav = _f(wav)
+        B, T = wav.shape[0], wav.shape[-1]
+        P = torch.empty(B, self.n_fft // 2 + 1, -(-T // self.hop), device=wav.device)
+        if self._lib.wv_stft_plan_logmag(self._h, wav.data_ptr(), P.data_ptr(), B, T, self.hop, self.mean, self.std, TrainHalf._stream()) != 0:
+            raise RuntimeError("wv_stft_plan_logmag failed")
+        return P
+
+
 class TrainConvPre(_Handle):
     """conv_pre with live weight norm (/root/reference/modules/seanet.py:657-664): Scale(1/wav_std) -> causal SConv1d(1, C, ks).
     params: g [C], v [C,ks], b [C]."""
@@ -501,12 +522,11 @@ class EncoderNetTrainer:
     Clip lengths must keep every ResnetBlock stage a multiple of 4 samples (T = 16000 does for both nets)."""
 
     def __init__(self, cfg, state_dict, lr: float = 1e-4, max_norm: float = 1000.0, device="cuda"):
-        from . import ops as _ops
         if cfg.kind not in ("detector", "locator"):
             raise ValueError("EncoderNetTrainer: detector or locator")
         if cfg.dilation_base != 1:
             raise NotImplementedError("training units: dilation_base = 1 only")
-        self.cfg, self._ops, self.max_norm = cfg, _ops, float(max_norm)
+        self.cfg, self.max_norm = cfg, float(max_norm)
         skip = ("encoder.msg_embedding.", "encoder.film_layers.")
         items = [(k, np.asarray(v, dtype=np.float32)) for k, v in state_dict.items()
                  if not k.startswith(skip) and not k.endswith("spec.weight")]
@@ -519,13 +539,16 @@ class EncoderNetTrainer:
             off += v.size
         rs, C = cfg.res_scale_enc, cfg.channels_enc
         self.conv_pre = TrainConvPre(C, cfg.kernel_size)
-        self.scales = []
+        self.scales, stride = [], 1
         for s, r in enumerate(cfg.ratios_enc):
-            F_ = (2 ** s) * cfg.n_fft_base // 2 + 1
-            self.scales.append(dict(C=C, r=r, blocks=[TrainBlock(C) for _ in range(cfg.n_residual_enc)], spec=TrainSpecAdd(C, F_),
-                                    down=TrainUnit(C, 2 * C, 2 * r, r)))
+            n_fft = (2 ** s) * cfg.n_fft_base
+            self.scales.append(dict(C=C, r=r, blocks=[TrainBlock(C) for _ in range(cfg.n_residual_enc)], spec=TrainSpecAdd(C, n_fft // 2 + 1),
+                                    down=TrainUnit(C, 2 * C, 2 * r, r), stft=StftFeatures(n_fft, stride, cfg.spec_means[s], cfg.spec_stds[s])))
             C *= 2
-        self.spec_post = TrainSpecAdd(C, (2 ** len(cfg.ratios_enc)) * cfg.n_fft_base // 2 + 1)
+            stride *= r
+        n_fft = (2 ** len(cfg.ratios_enc)) * cfg.n_fft_base
+        self.spec_post = TrainSpecAdd(C, n_fft // 2 + 1)
+        self.stft_post = StftFeatures(n_fft, stride, cfg.spec_means[-1], cfg.spec_stds[-1])
         self.conv_post = TrainConvPost(C, cfg.dimension, cfg.last_kernel_size)
         self.nb = cfg.nbits if cfg.kind == "detector" else 1
         self.head = TrainHead(cfg.dimension, cfg.output_dim, self.nb, cfg.hop_length)
@@ -578,14 +601,14 @@ class EncoderNetTrainer:
                 y, saved = blk.forward(h, ps, self.params.get(pre + ".res_scale_param"), pre_scale, rs)
                 rec["blocks"].append((h, saved, pre_scale))
                 h = y
-            P = self._ops.stft_logmag(x, (2 ** s) * cfg.n_fft_base, stride, mean=cfg.spec_means[s], std=cfg.spec_stds[s])
+            P = sc["stft"](x)
             sp, scp = self._spec_p(f"encoder.spec_blocks.{s}")
             h = sc["spec"].forward(h, P, sp, scp, rs)
             rec["P"], rec["down_in"] = P, h
             h = sc["down"].forward(h, self._half(f"encoder.downsample.{s}", 2, 3), self.down_scale, True)
             stride *= sc["r"]
             sv["scales"].append(rec)
-        P = self._ops.stft_logmag(x, (2 ** len(self.scales)) * cfg.n_fft_base, stride, mean=cfg.spec_means[-1], std=cfg.spec_stds[-1])
+        P = self.stft_post(x)
         sp, scp = self._spec_p("encoder.spec_post")
         h = self.spec_post.forward(h, P, sp, scp, rs)
         sv["P_post"], sv["post_in"] = P, h
