@@ -313,6 +313,19 @@ int wv_train_head_backward(wv_train_head* h, const float* z, const float* w_rev,
                            float* dz, float* dw_rev, float* db_rev, float* dw_last, float* db_last, int B, int N, int T,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* The decoder's upsample unit with live weight norm (seanet.py:1110-1135; conv.py:838-881):
+ *   y[B,M,r*Tin] = (g_pw v_pw/||v_pw||)[M,K] @ ConvTranspose1d_depthwise(act(pre_scale * x[B,K,Tin]); g_ct v_ct/||v_ct|| [K,2r], stride r) + bias
+ * (causal: the last r samples of the transposed conv are trimmed).  ratio <= 8. */
+typedef struct wv_train_up wv_train_up;
+int wv_train_up_create(int K, int M, int ratio, wv_train_up** out);
+void wv_train_up_destroy(wv_train_up* h);
+size_t wv_train_up_workspace_bytes(const wv_train_up* h, int B, int Tin);
+int wv_train_up_forward(wv_train_up* h, const float* x, const float* g_ct, const float* v_ct, const float* g_pw, const float* v_pw, const float* bias,
+                        float pre_scale, int pre_elu, float* y, int B, int Tin, void* stream);
+int wv_train_up_backward(wv_train_up* h, const float* x, const float* g_ct, const float* v_ct, const float* g_pw, const float* v_pw, float pre_scale,
+                         int pre_elu, const float* dy, float* dx, float* dg_ct, float* dv_ct, float* dg_pw, float* dv_pw, float* db, int B, int Tin,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* The two BCE-with-logits losses of the training step (scripts/loss.py:947-1099), forward + gradient in one pass:
  *   LocalizationLoss: msg = NULL, Cz = 1:  mean BCE(logits[B,1,T], mask[B,1,T])
  *   DecodingLoss:     mean BCE(logits[B,Cz,T], msg[B,Cz] * mask[B,1,T])        (mask NULL = all ones)

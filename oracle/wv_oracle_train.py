@@ -184,3 +184,28 @@ def convpost_backward(x, g_dw, v_dw, g_pw, v_pw, b, dy, l2norm=True, eps=1e-12):
     dg_dw, dv_dw = fold_backward(g_dw.astype(np.float64), v_dw.astype(np.float64), dw[:, None, :])
     dg_pw, dv_pw = fold_backward(g_pw.astype(np.float64), v_pw.astype(np.float64), dW[:, :, None])
     return dict(y=y, dx=dx, dg_dw=dg_dw, dv_dw=dv_dw, dg_pw=dg_pw, dv_pw=dv_pw, db=dz.sum((0, 2)))
+
+
+def up_backward(x, s, g_ct, v_ct, g_pw, v_pw, b, dy, elu=True):
+    """The decoder's upsample unit (seanet.py:1110-1135; conv.py:838-881): act(s x) -> depth-wise ConvTranspose1d(k = 2r, stride r),
+    right-trimmed to r*T -> 1x1 + bias -> dict(y, dx, dg_ct, dv_ct, dg_pw, dv_pw, db)."""
+    x = x.astype(np.float64)
+    dy = dy.astype(np.float64)
+    wc = fold(g_ct.astype(np.float64), v_ct.astype(np.float64))[:, 0, :]         # [K, 2r]
+    W = fold(g_pw.astype(np.float64), v_pw.astype(np.float64))[:, :, 0]          # [M, K]
+    r, T = wc.shape[1] // 2, x.shape[2]
+    z = s * x
+    a = np.where(z > 0, z, np.expm1(z)) if elu else z
+    full = np.zeros(a.shape[:2] + (r * T + r,))
+    for j in range(2 * r):
+        full[:, :, j:j + r * T:r] += a * wc[None, :, j, None]
+    u = full[:, :, : r * T]
+    y = np.einsum("mk,bkt->bmt", W, u) + b.astype(np.float64)[None, :, None]
+    dW = np.einsum("bmt,bkt->mk", dy, u)
+    du = np.pad(np.einsum("mk,bmt->bkt", W, dy), ((0, 0), (0, 0), (0, r)))
+    da = sum(wc[None, :, j, None] * du[:, :, j:j + r * T:r] for j in range(2 * r))
+    dwc = np.stack([(a * du[:, :, j:j + r * T:r]).sum((0, 2)) for j in range(2 * r)], 1)
+    dx = da * (np.where(z > 0, 1.0, np.exp(z)) if elu else 1.0) * s
+    dg_ct, dv_ct = fold_backward(g_ct.astype(np.float64), v_ct.astype(np.float64), dwc[:, None, :])
+    dg_pw, dv_pw = fold_backward(g_pw.astype(np.float64), v_pw.astype(np.float64), dW[:, :, None])
+    return dict(y=y, dx=dx, dg_ct=dg_ct, dv_ct=dv_ct, dg_pw=dg_pw, dv_pw=dv_pw, db=dy.sum((0, 2)))

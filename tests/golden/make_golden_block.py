@@ -185,6 +185,43 @@ def main():
         for k, nm in names.items():
             out[f"post{i}_{k}"] = p[nm].detach().numpy().astype(np.float32)
             out[f"post{i}_d{k}"] = p[nm].grad.numpy().astype(np.float32)
+    from modules.conv import SConvTranspose1d
+    for i, (B, K, T, r, sc) in enumerate(((2, 64, 50, 8, None), (2, 48, 40, 5, 0.7071068), (1, 40, 36, 4, 0.7071068), (2, 64, 32, 2, 0.7071068))):
+        rng = np.random.default_rng(800 + i)
+        mods = ([] if sc is None else [Scale(1, value=sc, learnable=False, inplace=True)]) + [
+            torch.nn.ELU(inplace=True),
+            SConvTranspose1d(K, K, kernel_size=2 * r, stride=r, groups=K, norm="weight_norm", causal=True, trim_right_ratio=1.0, bias=False,
+                             nonlinearity="relu"),
+            SConv1d(K, K // 2, 1, norm="weight_norm", bias=True)]
+        up = torch.nn.Sequential(*mods).double()
+        sd = {}
+        for k, v in up.state_dict().items():
+            a = rng.standard_normal(tuple(v.shape))
+            if k.endswith("original0"):
+                a = 0.5 + np.abs(a)
+            elif k.endswith("original1"):
+                a = a * np.prod(v.shape[1:]) ** -0.5
+            elif k.endswith("bias"):
+                a = a * 0.1
+            else:
+                a = v.numpy()
+            sd[k] = torch.from_numpy(np.asarray(a, dtype=np.float32)).double().reshape(v.shape)
+        up.load_state_dict(sd)
+        x = torch.from_numpy(rng.standard_normal((B, K, T)).astype(np.float32)).double().requires_grad_(True)
+        y = up(x * 1.0)
+        dy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).double()
+        y.backward(dy)
+        p = dict(up.named_parameters())
+        o = 0 if sc is None else 1
+        names = dict(g_ct=f"{o + 1}.convtr.convtr.parametrizations.weight.original0", v_ct=f"{o + 1}.convtr.convtr.parametrizations.weight.original1",
+                     g_pw=f"{o + 2}.conv.conv.parametrizations.weight.original0", v_pw=f"{o + 2}.conv.conv.parametrizations.weight.original1",
+                     b=f"{o + 2}.conv.conv.bias")
+        for k, t in dict(x=x, dy=dy, y=y, dx=x.grad).items():
+            out[f"up{i}_{k}"] = t.detach().numpy().astype(np.float32)
+        for k, nm in names.items():
+            out[f"up{i}_{k}"] = p[nm].detach().numpy().astype(np.float32)
+            out[f"up{i}_d{k}"] = p[nm].grad.numpy().astype(np.float32)
+        out[f"up{i}_meta"] = np.array([r, 1.0 if sc is None else sc])
     np.savez_compressed(os.path.join(HERE, "grads_pre_spec.npz"), **out)
     print("wrote grads_pre_spec.npz", len(out), "arrays")
 

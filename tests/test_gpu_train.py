@@ -394,3 +394,34 @@ def test_head_forward_backward_vs_torch_modules(B, D, O, nb, hop, N, T):
     for k, ref in (("dz", z.grad), ("dw_rev", rev.weight.grad), ("db_rev", rev.bias.grad), ("dw_last", last.weight.grad[:, :, 0]), ("db_last", last.bias.grad)):
         assert rel(g[k], ref.numpy()) <= 1e-4, (k, rel(g[k], ref.numpy()))
         assert torch.equal(g[k], g2[k]), k
+
+
+def test_upsample_unit_gradients_vs_reference_autograd_and_oracle(golden_dir):
+    from waveverify_amd.train import TrainUp
+    f = np.load(os.path.join(golden_dir, "grads_pre_spec.npz"))
+    names = ("g_ct", "v_ct", "g_pw", "v_pw", "b")
+    keys = ("dx", "dg_ct", "dv_ct", "dg_pw", "dv_pw", "db")
+    for i in range(4):
+        r, sc = int(f[f"up{i}_meta"][0]), float(f[f"up{i}_meta"][1])
+        x, dy = f[f"up{i}_x"], f[f"up{i}_dy"]
+        u = TrainUp(x.shape[1], dy.shape[1], r)
+        p = {k: _cu(f[f"up{i}_{k}"]) for k in names}
+        assert rel(u.forward(_cu(x), p, sc), f[f"up{i}_y"]) <= 2e-5
+        g = u.backward(_cu(x), p, sc, _cu(dy))
+        for k in keys:
+            assert rel(g[k], f[f"up{i}_{k}"]) <= 1e-4, (i, k, rel(g[k], f[f"up{i}_{k}"]))
+    # the generator's decoder shapes at a training batch: 768 -> 384 (r = 8, 50 frames) and 192 -> 96 (r = 2, 8000 -> 16000)
+    for B, K, M, T, r in ((16, 768, 384, 50, 8), (4, 192, 96, 8000, 2)):
+        rng = np.random.default_rng(K + r)
+        x = rng.standard_normal((B, K, T)).astype(np.float32)
+        dy = rng.standard_normal((B, M, T * r)).astype(np.float32)
+        p = dict(g_ct=(0.5 + np.abs(rng.standard_normal((K, 1, 1)))).astype(np.float32), v_ct=(rng.standard_normal((K, 1, 2 * r)) * (2 * r) ** -0.5).astype(np.float32),
+                 g_pw=(0.5 + np.abs(rng.standard_normal((M, 1, 1)))).astype(np.float32), v_pw=(rng.standard_normal((M, K, 1)) * K ** -0.5).astype(np.float32),
+                 b=(0.1 * rng.standard_normal(M)).astype(np.float32))
+        ref = OT.up_backward(x, 0.7071068, p["g_ct"], p["v_ct"], p["g_pw"], p["v_pw"], p["b"], dy)
+        u = TrainUp(K, M, r)
+        pt = {k: _cu(v) for k, v in p.items()}
+        assert rel(u.forward(_cu(x), pt, 0.7071068), ref["y"]) <= 2e-5
+        g, g2 = u.backward(_cu(x), pt, 0.7071068, _cu(dy)), u.backward(_cu(x), pt, 0.7071068, _cu(dy))
+        for k in keys:
+            assert rel(g[k], ref[k]) <= 1e-4 and torch.equal(g[k], g2[k]), (K, k, rel(g[k], ref[k]))

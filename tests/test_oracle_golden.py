@@ -320,3 +320,13 @@ def test_training_gradient_oracle_vs_whole_reference_nets(golden_dir, name):
     for k in ref_keys:
         r = g["g:" + k]
         assert np.abs(grads[k] - r).max() <= 5e-6 * max(np.abs(r).max(), 1e-12) + 1e-14, k
+
+
+def test_train_oracle_upsample_unit_vs_reference_autograd(golden_dir):
+    from oracle import wv_oracle_train as OT
+    g = np.load(os.path.join(golden_dir, "grads_pre_spec.npz"))
+    for i in range(4):
+        r = OT.up_backward(g[f"up{i}_x"], float(g[f"up{i}_meta"][1]), *(g[f"up{i}_{k}"] for k in ("g_ct", "v_ct", "g_pw", "v_pw", "b", "dy")))
+        for k in ("y", "dx", "dg_ct", "dv_ct", "dg_pw", "dv_pw", "db"):
+            b = g[f"up{i}_{k}"]
+            assert float(np.abs(r[k].reshape(b.shape) - b).max() / max(np.abs(b).max(), 1e-30)) <= 2e-6, (i, k)

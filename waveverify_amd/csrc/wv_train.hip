@@ -388,6 +388,68 @@ __global__ void expand_bias_kernel(const float* __restrict__ b, float* __restric
     if (i < O * hop) out[i] = b[i / hop];
 }
 
+// ---- upsample unit pieces (decoder, seanet.py:1110-1135): u = depth-wise ConvTranspose1d(k = 2r, stride r) of a = act(s x), right-trimmed
+// to r * Tin (conv.py:838-881):  u[t] = a[l] w[j] + a[l-1] w[j + r],  l = t / r, j = t % r.
+__global__ __launch_bounds__(256) void convtr_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ u,
+                                                          int K, int Tin, int r, float s, int elu) {
+    const int k = blockIdx.x, b = blockIdx.y, Tout = Tin * r;
+    const float* xr = x + ((size_t)b * K + k) * Tin;
+    float* ur = u + ((size_t)b * K + k) * Tout;
+    const float* wk = w + (size_t)k * 2 * r;
+    for (int t = threadIdx.x; t < Tout; t += 256) {
+        const int l = t / r, j = t - l * r;
+        float a0 = s * xr[l];
+        if (elu) a0 = a0 > 0.f ? a0 : (__expf(a0) - 1.f);
+        float v = a0 * wk[j];
+        if (l > 0) {
+            float a1 = s * xr[l - 1];
+            if (elu) a1 = a1 > 0.f ? a1 : (__expf(a1) - 1.f);
+            v = fmaf(a1, wk[j + r], v);
+        }
+        ur[t] = v;
+    }
+}
+
+// backward: da[l] = sum_{j < 2r, l r + j < Tout} w[j] du[l r + j];  dx[l] = da[l] act'(s x[l]) s;
+// partial[b][k][j] = sum_l a[l] du[l r + j]   (2r <= TRAIN_MAX_KS taps)
+__global__ __launch_bounds__(256) void convtr_bwd_kernel(const float* __restrict__ du, const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ dx, float* __restrict__ partial, int K, int Tin, int r, float s, int elu) {
+    __shared__ float red[4][TRAIN_MAX_KS];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, Tout = Tin * r, ks = 2 * r;
+    const float* dur = du + ((size_t)b * K + k) * Tout;
+    const float* xr = x + ((size_t)b * K + k) * Tin;
+    float wt[TRAIN_MAX_KS], acc[TRAIN_MAX_KS];
+#pragma unroll
+    for (int j = 0; j < TRAIN_MAX_KS; ++j) { wt[j] = j < ks ? w[(size_t)k * ks + j] : 0.f; acc[j] = 0.f; }
+    for (int l = tid; l < Tin; l += 256) {
+        const float z = s * xr[l];
+        const float a = (!elu || z > 0.f) ? z : (__expf(z) - 1.f);
+        float g = 0.f;
+#pragma unroll
+        for (int j = 0; j < TRAIN_MAX_KS; ++j) {
+            const int t = l * r + j;
+            if (j < ks && t < Tout) { const float d = dur[t]; g = fmaf(wt[j], d, g); acc[j] = fmaf(a, d, acc[j]); }
+        }
+        if (dx) dx[((size_t)b * K + k) * Tin + l] = g * ((!elu || z > 0.f) ? 1.f : __expf(z)) * s;
+    }
+#pragma unroll
+    for (int j = 0; j < TRAIN_MAX_KS; ++j) {
+        float v = acc[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((tid & 63) == 0) red[tid >> 6][j] = v;
+    }
+    __syncthreads();
+    if (tid < ks) partial[((size_t)b * K + k) * ks + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// taps [K][2r] -> the loader's transposed, zero padded copy [2r][Kp]
+__global__ void pack_ct_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int K, int Kp, int ks) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K * ks) return;
+    const int k = i / ks, j = i - k * ks;
+    wt[(size_t)j * Kp + k] = w[i];
+}
+
 // ---- optimizer step over a FLAT parameter arena (scripts/train.py:1346-1358, conf/base.yml:128-130) ------------------
 // Parameters, gradients and both AdamW moments of a net live in contiguous arenas, so gradient clipping is one
 // two-stage sum of squares and the update one launch (and the DDP buckets are plain slices of the gradient arena).
@@ -1061,6 +1123,110 @@ int wv_train_head_backward(wv_train_head* h, const float* z, const float* w_rev,
     hipLaunchKernelGGL(wv::pack_wt_kernel, dim3((unsigned)(((size_t)D * OH + 255) / 256)), dim3(256), 0, s, w_rev, h->wt_dz, D, OH, wv::round_up(D, wv::M_ALIGN), 0);
     T_LAUNCH(hipGetLastError());
     T_LAUNCH(head_gemm(dq, head_pw(D, OH, h->wt_dz), nullptr, dz, B, N, s));
+    return WV_OK;
+}
+
+// ---- upsample unit: y[B,M,r*Tin] = W(g,v)[M,K] @ ConvT_dw(act(s x[B,K,Tin]); taps(g,v)[K,2r]) + bias (seanet.py:1110-1135) -------
+struct wv_train_up {
+    int K = 0, M = 0, r = 0, Mp = 0, KpT = 0, Kp = 0;
+    float *w_ct = nullptr, *inv_ct = nullptr, *ct_wt = nullptr, *w_pw = nullptr, *inv_pw = nullptr, *wq = nullptr, *wqT = nullptr, *wt = nullptr, *wtT = nullptr;
+    float *id_taps = nullptr, *dW = nullptr, *taps = nullptr, *scr = nullptr, *junk = nullptr;
+    std::vector<void*> owned;
+    ~wv_train_up() { for (void* p : owned) (void)hipFree(p); }
+};
+
+int wv_train_up_create(int K, int M, int ratio, wv_train_up** out) {
+    if (!out || K < 1 || K > 4096 || M < 1 || M > 4096 || ratio < 1 || 2 * ratio > wv::TRAIN_MAX_KS) return tfail(WV_EINVAL, "bad upsample shape (ratio <= 8)");
+    auto* h = new wv_train_up();
+    h->K = K; h->M = M; h->r = ratio; h->Mp = wv::round_up(M, wv::M_ALIGN); h->KpT = wv::round_up(K, wv::M_ALIGN); h->Kp = wv::round_up(K, wv::BK);
+    auto alloc = [&](float** p, size_t n) {
+        if (hipMalloc((void**)p, n * sizeof(float)) != hipSuccess) return false;
+        h->owned.push_back(*p);
+        return hipMemset(*p, 0, n * sizeof(float)) == hipSuccess;
+    };
+    const int R = std::max(K, M), ks = 2 * ratio;
+    std::vector<float> taps((size_t)R * 5, 0.f);
+    for (int m = 0; m < R; ++m) taps[(size_t)m * 5 + 4] = 1.f;
+    bool ok = alloc(&h->w_ct, (size_t)K * ks) && alloc(&h->inv_ct, K) && alloc(&h->ct_wt, (size_t)ks * h->Kp) && alloc(&h->w_pw, (size_t)M * K) &&
+              alloc(&h->inv_pw, M) && alloc(&h->wq, (size_t)wv::round_up(K, 32) * h->Mp) && alloc(&h->wqT, (size_t)wv::round_up(M, 32) * h->KpT) &&
+              alloc(&h->wt, (size_t)h->Kp * h->Mp) && alloc(&h->wtT, (size_t)wv::round_up(M, wv::BK) * h->KpT) && alloc(&h->id_taps, taps.size()) &&
+              alloc(&h->dW, (size_t)M * K) && alloc(&h->taps, (size_t)K * ks) && alloc(&h->scr, (size_t)R * 2) && alloc(&h->junk, (size_t)R) &&
+              hipMemcpy(h->id_taps, taps.data(), taps.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { delete h; return tfail(WV_EHIP, "device allocation failed"); }
+    *out = h;
+    return WV_OK;
+}
+void wv_train_up_destroy(wv_train_up* h) { delete h; }
+
+size_t wv_train_up_workspace_bytes(const wv_train_up* h, int B, int Tin) {
+    if (!h || B < 1 || Tin < 1) return 0;
+    const int Tout = Tin * h->r;
+    const size_t au = al256((size_t)B * h->K * Tout * 4);
+    return 2 * au + al256((size_t)B * std::max(h->K * 2 * h->r, h->M * 2) * 4) + al256((size_t)nt_plan(B, Tout, h->M, h->K).S * h->M * h->K * 4);
+}
+
+static int up_fold(wv_train_up* h, const float* g_ct, const float* v_ct, const float* g_pw, const float* v_pw, hipStream_t s) {
+    const int ks = 2 * h->r;
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->K), dim3(256), 0, s, g_ct, v_ct, h->w_ct, h->inv_ct, (float*)nullptr, (float*)nullptr, h->K, ks, 0, 0,
+                       (const float*)nullptr, 1.f, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(wv::pack_ct_wt_kernel, dim3((h->K * ks + 255) / 256), dim3(256), 0, s, h->w_ct, h->ct_wt, h->K, h->Kp, ks);
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->M), dim3(256), 0, s, g_pw, v_pw, h->w_pw, h->inv_pw, h->wq, h->wqT, h->M, h->K, h->Mp, h->KpT,
+                       (const float*)nullptr, 1.f, h->wt, h->wtT);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+int wv_train_up_forward(wv_train_up* h, const float* x, const float* g_ct, const float* v_ct, const float* g_pw, const float* v_pw, const float* bias,
+                        float pre_scale, int pre_elu, float* y, int B, int Tin, void* stream) {
+    if (!h || !x || !g_ct || !v_ct || !g_pw || !v_pw || !y || B < 1 || Tin < 1) return tfail(WV_EINVAL, "null / bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = up_fold(h, g_ct, v_ct, g_pw, v_pw, s);
+    if (rc) return rc;
+    wv::PwDwArgs a{};
+    a.X = x; a.pw.M = h->M; a.pw.K = h->K; a.pw.Mp = h->Mp; a.pw.Kp = h->Kp; a.pw.wq = h->wq; a.pw.wt = h->wt;
+    a.ct_w = h->w_ct; a.ct_wt = h->ct_wt; a.ratio = h->r; a.dw_w = h->id_taps; a.dw_b = bias; a.Y = y;
+    a.B = B; a.Tin = Tin; a.Tout = Tin * h->r; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
+    a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
+    T_LAUNCH(wv::launch_pw_dw(a, s));
+    return WV_OK;
+}
+
+int wv_train_up_backward(wv_train_up* h, const float* x, const float* g_ct, const float* v_ct, const float* g_pw, const float* v_pw, float pre_scale,
+                         int pre_elu, const float* dy, float* dx, float* dg_ct, float* dv_ct, float* dg_pw, float* dv_pw, float* db, int B, int Tin,
+                         void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !x || !g_ct || !v_ct || !g_pw || !v_pw || !dy || !dx || !dg_ct || !dv_ct || !dg_pw || !dv_pw || !db) return tfail(WV_EINVAL, "null argument");
+    if (B < 1 || Tin < 1 || !ws || ws_bytes < wv_train_up_workspace_bytes(h, B, Tin)) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int K = h->K, M = h->M, r = h->r, ks = 2 * r, Tout = Tin * r;
+    const size_t au = al256((size_t)B * K * Tout * 4);
+    char* w = (char*)ws;
+    float* U = (float*)w; float* DU = (float*)(w + au);
+    float* partial = (float*)(w + 2 * au);
+    float* parts = (float*)(w + 2 * au + al256((size_t)B * std::max(K * ks, M * 2) * 4));
+    int rc = up_fold(h, g_ct, v_ct, g_pw, v_pw, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wv::convtr_fwd_kernel, dim3(K, B), dim3(256), 0, s, x, h->w_ct, U, K, Tin, r, pre_scale, pre_elu);
+    // db = sum dy;  dW = sum dy u^T
+    wv::launch_dw_bwd(s, dy, dy, h->junk, (float*)nullptr, partial, M, B, Tout, Tout, 1, 1, 0, 0);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((M * 2 + 255) / 256), dim3(256), 0, s, partial, h->scr, B, (size_t)M * 2);
+    hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((M + 255) / 256), dim3(256), 0, s, h->scr, h->junk, db, M, 1, 1.f);
+    const NtPlan np_ = nt_plan(B, Tout, M, K);
+    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((M + 63) / 64, (K + 63) / 64, np_.S), dim3(256), 0, s, dy, U, parts, 1.f, 0, B, M, K, Tout, np_.TC);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)M * K + 255) / 256)), dim3(256), 0, s, parts, h->dW, np_.S, (size_t)M * K);
+    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(M), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, K);
+    T_LAUNCH(hipGetLastError());
+    // du = W^T dy
+    wv::PwDwArgs t{};
+    t.X = dy; t.pw.M = K; t.pw.K = M; t.pw.Mp = h->KpT; t.pw.Kp = wv::round_up(M, wv::BK); t.pw.wq = h->wqT; t.pw.wt = h->wtT;
+    t.dw_w = h->id_taps; t.dw_b = nullptr; t.Y = DU;
+    t.B = B; t.Tin = Tout; t.Tout = Tout; t.ks = 5; t.stride = 1; t.dil = 1; t.pad = 4;
+    t.pre_scale = 1.f; t.pre_elu = 0; t.out_scale = 1.f; t.bands = 1; t.film_stride = 2;
+    T_LAUNCH(wv::launch_pw_dw(t, s));
+    // through the transposed conv and the activation
+    hipLaunchKernelGGL(wv::convtr_bwd_kernel, dim3(K, B), dim3(256), 0, s, DU, x, h->w_ct, dx, partial, K, Tin, r, pre_scale, pre_elu);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((K * ks + 255) / 256), dim3(256), 0, s, partial, h->taps, B, (size_t)K * ks);
+    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(K), dim3(256), 0, s, g_ct, v_ct, h->inv_ct, h->taps, dg_ct, dv_ct, ks);
+    T_LAUNCH(hipGetLastError());
     return WV_OK;
 }
 

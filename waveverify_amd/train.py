@@ -320,6 +320,43 @@ class TrainHead(_Handle):
         return out
 
 
+class TrainUp(_Handle):
+    """The decoder's upsample unit with live weight norm (/root/reference/modules/seanet.py:1110-1135): [Scale] -> ELU -> depth-wise
+    SConvTranspose1d(K, K, 2r, stride r) -> SConv1d(K, M, 1, bias).  params: g_ct [K], v_ct [K,2r], g_pw [M], v_pw [M,K], b [M]."""
+    _create, _destroy = "wv_train_up_create", "wv_train_up_destroy"
+
+    def __init__(self, k_in: int, m_out: int, ratio: int):
+        self.K, self.M, self.r = int(k_in), int(m_out), int(ratio)
+        self._open(self.K, self.M, self.r)
+
+    def _p(self, p):
+        return (_f(p["g_ct"]).reshape(self.K), _f(p["v_ct"]).reshape(self.K, 2 * self.r), _f(p["g_pw"]).reshape(self.M),
+                _f(p["v_pw"]).reshape(self.M, self.K), _f(p["b"]).reshape(self.M))
+
+    def forward(self, x, p, pre_scale: float, pre_elu: bool = True):
+        x = _f(x)
+        B, _, T = x.shape
+        g_ct, v_ct, g_pw, v_pw, b = self._p(p)
+        y = torch.empty(B, self.M, T * self.r, device=x.device)
+        self._check(self._lib.wv_train_up_forward(self._h, x.data_ptr(), g_ct.data_ptr(), v_ct.data_ptr(), g_pw.data_ptr(), v_pw.data_ptr(),
+                                                  b.data_ptr(), float(pre_scale), int(pre_elu), y.data_ptr(), B, T, TrainHalf._stream()),
+                    "wv_train_up_forward")
+        return y
+
+    def backward(self, x, p, pre_scale: float, dy, pre_elu: bool = True):
+        x, dy = _f(x), _f(dy)
+        B, _, T = x.shape
+        g_ct, v_ct, g_pw, v_pw, b = self._p(p)
+        out = dict(dx=torch.empty_like(x), dg_ct=torch.empty_like(g_ct), dv_ct=torch.empty_like(v_ct), dg_pw=torch.empty_like(g_pw),
+                   dv_pw=torch.empty_like(v_pw), db=torch.empty_like(b))
+        ws = torch.empty(int(self._lib.wv_train_up_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=x.device)
+        self._check(self._lib.wv_train_up_backward(
+            self._h, x.data_ptr(), g_ct.data_ptr(), v_ct.data_ptr(), g_pw.data_ptr(), v_pw.data_ptr(), float(pre_scale), int(pre_elu),
+            dy.data_ptr(), out["dx"].data_ptr(), out["dg_ct"].data_ptr(), out["dv_ct"].data_ptr(), out["dg_pw"].data_ptr(), out["dv_pw"].data_ptr(),
+            out["db"].data_ptr(), B, T, ws.data_ptr(), ws.numel(), TrainHalf._stream()), "wv_train_up_backward")
+        return out
+
+
 class _HalfParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("g_pw", "v_pw", "g_dw", "v_dw", "bias")]
 
