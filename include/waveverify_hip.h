@@ -326,6 +326,19 @@ int wv_train_up_backward(wv_train_up* h, const float* x, const float* g_ct, cons
                          int pre_elu, const float* dy, float* dx, float* dg_ct, float* dv_ct, float* dg_pw, float* dv_pw, float* db, int B, int Tin,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* The decoder's tail with live weight norm (seanet.py:1166-1204; generator.py:396-413 trims to T):
+ *   delta[B,1,T] = tanh( wav_std * ( causal conv1d(ELU(post * x[B,C,Tin]), g v/||v|| [1,C,ks]) + bias ) )[..., :T],  T <= Tin
+ * (the watermarked audio is delta + the input clip: watermarking.py:423-441).  g [1], v [1,C,ks] (norm over the whole tensor). */
+typedef struct wv_train_tail wv_train_tail;
+int wv_train_tail_create(int C, int ks, wv_train_tail** out);
+void wv_train_tail_destroy(wv_train_tail* h);
+size_t wv_train_tail_workspace_bytes(const wv_train_tail* h, int B);
+int wv_train_tail_forward(wv_train_tail* h, const float* x, const float* g, const float* v, const float* bias, float post, float wav_std,
+                          float* delta, int B, int Tin, int T, void* stream);
+int wv_train_tail_backward(wv_train_tail* h, const float* x, const float* g, const float* v, float post, float wav_std, const float* delta,
+                           const float* d_delta, float* dx, float* dg, float* dv, float* db, int B, int Tin, int T,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* The two BCE-with-logits losses of the training step (scripts/loss.py:947-1099), forward + gradient in one pass:
  *   LocalizationLoss: msg = NULL, Cz = 1:  mean BCE(logits[B,1,T], mask[B,1,T])
  *   DecodingLoss:     mean BCE(logits[B,Cz,T], msg[B,Cz] * mask[B,1,T])        (mask NULL = all ones)

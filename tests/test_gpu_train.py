@@ -425,3 +425,30 @@ def test_upsample_unit_gradients_vs_reference_autograd_and_oracle(golden_dir):
         g, g2 = u.backward(_cu(x), pt, 0.7071068, _cu(dy)), u.backward(_cu(x), pt, 0.7071068, _cu(dy))
         for k in keys:
             assert rel(g[k], ref[k]) <= 1e-4 and torch.equal(g[k], g2[k]), (K, k, rel(g[k], ref[k]))
+
+
+@pytest.mark.parametrize("B,C,Tin,T,ks", [(4, 96, 16000, 16000, 5), (2, 96, 16320, 16001, 5), (3, 8, 40, 37, 7)])
+def test_decoder_tail_vs_torch_autograd(B, C, Tin, T, ks):
+    """Scale(post) -> ELU -> causal weight-normed Conv1d(C, 1, ks) -> Scale(wav_std) -> Tanh -> [:T] (seanet.py:1166-1204) written with
+    torch.nn.functional in float64 (the reference builds exactly these torch ops; SConv1d's causal padding = left pad ks-1)."""
+    from waveverify_amd.train import TrainTail
+    import torch.nn.functional as F
+    torch.manual_seed(C + ks)
+    post, wav_std = 0.7071068, 0.1122080159
+    g = (0.5 + torch.rand(1, 1, 1, dtype=torch.float64)).requires_grad_(True)
+    v = (torch.randn(1, C, ks, dtype=torch.float64) * (C * ks) ** -0.5).requires_grad_(True)
+    b = (0.1 * torch.randn(1, dtype=torch.float64)).requires_grad_(True)
+    x = torch.randn(B, C, Tin, dtype=torch.float64, requires_grad=True)
+    w = g * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+    delta = torch.tanh(wav_std * F.conv1d(F.pad(F.elu(x * post), (ks - 1, 0)), w, b))[..., :T]
+    dd = torch.randn_like(delta)
+    delta.backward(dd)
+    u = TrainTail(C, ks)
+    p = dict(g=g.detach().float().cuda(), v=v.detach().float().cuda(), b=b.detach().float().cuda())
+    got = u.forward(x.detach().float().cuda(), p, post, wav_std, T)
+    assert rel(got, delta.detach().numpy()) <= 2e-5
+    gr = u.backward(x.detach().float().cuda(), p, post, wav_std, got, dd.float().cuda())
+    gr2 = u.backward(x.detach().float().cuda(), p, post, wav_std, got, dd.float().cuda())
+    for k, ref in (("dx", x.grad), ("dg", g.grad), ("dv", v.grad), ("db", b.grad)):
+        assert rel(gr[k], ref.numpy()) <= 1e-4, (k, rel(gr[k], ref.numpy()))
+        assert torch.equal(gr[k], gr2[k])

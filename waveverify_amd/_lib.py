@@ -91,6 +91,12 @@ SIGNATURES = {
     "wv_train_up_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_int, _VP, C.c_int, C.c_int, _VP]),
     "wv_train_up_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int,
                                        _VP, C.c_size_t, _VP]),
+    "wv_train_tail_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_VP)]),
+    "wv_train_tail_destroy": (None, [_VP]),
+    "wv_train_tail_workspace_bytes": (C.c_size_t, [_VP, C.c_int]),
+    "wv_train_tail_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, C.c_int, C.c_int, C.c_int, _VP]),
+    "wv_train_tail_backward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int,
+                                         _VP, C.c_size_t, _VP]),
     "wv_train_block_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "wv_train_block_destroy": (None, [_VP]),
     "wv_train_block_saved_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),

@@ -450,6 +450,54 @@ __global__ void pack_ct_wt_kernel(const float* __restrict__ w, float* __restrict
     wt[(size_t)j * Kp + k] = w[i];
 }
 
+// ---- decoder tail (seanet.py:1166-1204): delta = tanh(wav_std * (conv1d(ELU(post * h), w[1,C,ks]) + b)) --------------------------
+// One workgroup per (channel, clip) row.  dq[u] = d_delta[u] (1 - delta[u]^2) wav_std is formed on the fly (u < T; the decoder's
+// extra samples past T were trimmed: no gradient);  dh[t] = post ELU'(post h[t]) sum_i w[c][i] dq[t + ks-1 - i];
+// partial[b][c][i] = sum_n dq[n] ELU(post h[n - (ks-1) + i]),  partial[b][c][ks] = sum_n dq[n].
+__global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ delta,
+                                                        const float* __restrict__ dd, float* __restrict__ dh, float* __restrict__ partial,
+                                                        int C, int Tin, int T, int ks, float post, float wav_std) {
+    __shared__ float red[4][TRAIN_MAX_KS + 1];
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* hr = h + ((size_t)b * C + c) * Tin;
+    const float* ddr = dd + (size_t)b * T;
+    const float* der = delta + (size_t)b * T;
+    float wt[TRAIN_MAX_KS], acc[TRAIN_MAX_KS + 1];
+#pragma unroll
+    for (int i = 0; i < TRAIN_MAX_KS; ++i) { wt[i] = i < ks ? w[c * ks + i] : 0.f; acc[i] = 0.f; }
+    acc[TRAIN_MAX_KS] = 0.f;
+    for (int t = tid; t < Tin; t += 256) {
+        float g = 0.f;
+#pragma unroll
+        for (int i = 0; i < TRAIN_MAX_KS; ++i) {
+            const int u = t + (ks - 1) - i;
+            if (i < ks && u < T) { const float dl = der[u]; g = fmaf(wt[i], ddr[u] * (1.f - dl * dl) * wav_std, g); }
+        }
+        const float z = post * hr[t];
+        dh[((size_t)b * C + c) * Tin + t] = g * (z > 0.f ? 1.f : __expf(z)) * post;
+    }
+    for (int n = tid; n < T; n += 256) {
+        const float dl = der[n], d = ddr[n] * (1.f - dl * dl) * wav_std;
+#pragma unroll
+        for (int i = 0; i < TRAIN_MAX_KS; ++i) {
+            const int tb = n - (ks - 1) + i;
+            if (i < ks && tb >= 0) { const float z = post * hr[tb]; acc[i] = fmaf(d, z > 0.f ? z : (__expf(z) - 1.f), acc[i]); }
+        }
+        acc[TRAIN_MAX_KS] += d;
+    }
+#pragma unroll
+    for (int i = 0; i <= TRAIN_MAX_KS; ++i) {
+        float v = acc[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((tid & 63) == 0) red[tid >> 6][i] = v;
+    }
+    __syncthreads();
+    if (tid <= ks) {
+        const int src = tid < ks ? tid : TRAIN_MAX_KS;
+        partial[((size_t)b * C + c) * (ks + 1) + tid] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
+    }
+}
+
 // ---- optimizer step over a FLAT parameter arena (scripts/train.py:1346-1358, conf/base.yml:128-130) ------------------
 // Parameters, gradients and both AdamW moments of a net live in contiguous arenas, so gradient clipping is one
 // two-stage sum of squares and the update one launch (and the DDP buckets are plain slices of the gradient arena).
@@ -1227,6 +1275,61 @@ int wv_train_up_backward(wv_train_up* h, const float* x, const float* g_ct, cons
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((K * ks + 255) / 256), dim3(256), 0, s, partial, h->taps, B, (size_t)K * ks);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(K), dim3(256), 0, s, g_ct, v_ct, h->inv_ct, h->taps, dg_ct, dv_ct, ks);
     T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+// ---- decoder tail ------------------------------------------------------------------------------------------------------------------
+struct wv_train_tail {
+    int C = 0, ks = 0;
+    float *w = nullptr, *inv = nullptr, *dwdb = nullptr, *taps = nullptr, *dbv = nullptr;
+    std::vector<void*> owned;
+    ~wv_train_tail() { for (void* p : owned) (void)hipFree(p); }
+};
+
+int wv_train_tail_create(int C, int ks, wv_train_tail** out) {
+    if (!out || C < 1 || C > 4096 || ks < 1 || ks > wv::TRAIN_MAX_KS) return tfail(WV_EINVAL, "bad channel count / kernel size");
+    auto* h = new wv_train_tail();
+    h->C = C; h->ks = ks;
+    auto alloc = [&](float** p, size_t n) {
+        if (hipMalloc((void**)p, n * sizeof(float)) != hipSuccess) return false;
+        h->owned.push_back(*p);
+        return true;
+    };
+    if (!(alloc(&h->w, (size_t)C * ks) && alloc(&h->inv, 1) && alloc(&h->dwdb, (size_t)C * (ks + 1)) && alloc(&h->taps, (size_t)C * ks) && alloc(&h->dbv, C))) {
+        delete h;
+        return tfail(WV_EHIP, "device allocation failed");
+    }
+    *out = h;
+    return WV_OK;
+}
+void wv_train_tail_destroy(wv_train_tail* h) { delete h; }
+size_t wv_train_tail_workspace_bytes(const wv_train_tail* h, int B) { return (h && B > 0) ? al256((size_t)B * h->C * (h->ks + 1) * 4) : 0; }
+
+int wv_train_tail_forward(wv_train_tail* h, const float* x, const float* g, const float* v, const float* bias, float post, float wav_std,
+                          float* delta, int B, int Tin, int T, void* stream) {
+    if (!h || !x || !g || !v || !delta || B < 1 || T < 1 || T > Tin) return tfail(WV_EINVAL, "null / bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(1), dim3(256), 0, s, g, v, h->w, h->inv, (float*)nullptr, (float*)nullptr, 1, h->C * h->ks, 0, 0,
+                       (const float*)nullptr, 1.f, (float*)nullptr, (float*)nullptr);
+    T_LAUNCH(hipGetLastError());
+    T_LAUNCH(wv::launch_tail(x, h->w, bias, nullptr, delta, B, h->C, Tin, T, h->ks, post, wav_std, s));
+    return WV_OK;
+}
+
+int wv_train_tail_backward(wv_train_tail* h, const float* x, const float* g, const float* v, float post, float wav_std, const float* delta,
+                           const float* d_delta, float* dx, float* dg, float* dv, float* db, int B, int Tin, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !x || !g || !v || !delta || !d_delta || !dx || !dg || !dv || !db) return tfail(WV_EINVAL, "null argument");
+    if (B < 1 || T < 1 || T > Tin || !ws || ws_bytes < wv_train_tail_workspace_bytes(h, B)) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = h->C, ks = h->ks;
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(1), dim3(256), 0, s, g, v, h->w, h->inv, (float*)nullptr, (float*)nullptr, 1, C * ks, 0, 0,
+                       (const float*)nullptr, 1.f, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(wv::tail_bwd_kernel, dim3(C, B), dim3(256), 0, s, x, h->w, delta, d_delta, dx, (float*)ws, C, Tin, T, ks, post, wav_std);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((C * (ks + 1) + 255) / 256), dim3(256), 0, s, (const float*)ws, h->dwdb, B, (size_t)C * (ks + 1));
+    hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((C + 255) / 256), dim3(256), 0, s, h->dwdb, h->taps, h->dbv, C, ks, 1.f);
+    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(1), dim3(256), 0, s, g, v, h->inv, h->taps, dg, dv, C * ks);
+    T_LAUNCH(hipGetLastError());
+    T_LAUNCH(hipMemcpyAsync(db, h->dbv, sizeof(float), hipMemcpyDeviceToDevice, s));      // every channel row holds the same sum of dq
     return WV_OK;
 }
 

@@ -357,6 +357,37 @@ class TrainUp(_Handle):
         return out
 
 
+class TrainTail(_Handle):
+    """The decoder's tail with live weight norm (/root/reference/modules/seanet.py:1166-1204): Scale(post) -> ELU -> causal
+    SConv1d(C, 1, ks) -> Scale(wav_std) -> Tanh, trimmed to the clip length.  params: g [1], v [1,C,ks], b [1]."""
+    _create, _destroy = "wv_train_tail_create", "wv_train_tail_destroy"
+
+    def __init__(self, channels: int, ks: int):
+        self.C, self.ks = int(channels), int(ks)
+        self._open(self.C, self.ks)
+
+    def forward(self, x, p, post: float, wav_std: float, T: int):
+        x = _f(x)
+        B, _, Tin = x.shape
+        g, v, b = _f(p["g"]).reshape(1), _f(p["v"]).reshape(self.C, self.ks), _f(p["b"]).reshape(1)
+        delta = torch.empty(B, 1, T, device=x.device)
+        self._check(self._lib.wv_train_tail_forward(self._h, x.data_ptr(), g.data_ptr(), v.data_ptr(), b.data_ptr(), float(post), float(wav_std),
+                                                    delta.data_ptr(), B, Tin, int(T), TrainHalf._stream()), "wv_train_tail_forward")
+        return delta
+
+    def backward(self, x, p, post: float, wav_std: float, delta, d_delta):
+        x, delta, dd = _f(x), _f(delta), _f(d_delta)
+        B, _, Tin = x.shape
+        g, v = _f(p["g"]).reshape(1), _f(p["v"]).reshape(self.C, self.ks)
+        out = dict(dx=torch.empty_like(x), dg=torch.empty_like(g), dv=torch.empty_like(v), db=torch.empty(1, device=x.device))
+        ws = torch.empty(int(self._lib.wv_train_tail_workspace_bytes(self._h, B)), dtype=torch.uint8, device=x.device)
+        self._check(self._lib.wv_train_tail_backward(
+            self._h, x.data_ptr(), g.data_ptr(), v.data_ptr(), float(post), float(wav_std), delta.data_ptr(), dd.data_ptr(), out["dx"].data_ptr(),
+            out["dg"].data_ptr(), out["dv"].data_ptr(), out["db"].data_ptr(), B, Tin, delta.shape[-1], ws.data_ptr(), ws.numel(), TrainHalf._stream()),
+            "wv_train_tail_backward")
+        return out
+
+
 class _HalfParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("g_pw", "v_pw", "g_dw", "v_dw", "bias")]
 
