@@ -339,6 +339,22 @@ int wv_train_tail_backward(wv_train_tail* h, const float* x, const float* g, con
                            const float* d_delta, float* dx, float* dg, float* dv, float* db, int B, int Tin, int T,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* Message MLP + FiLM (seanet.py:518-550,831-846,905-966).  `params` / `dparams` are one packed block:
+ *   W0 [E][msg_dim], b0 [E], layers x (W [E][E], b [E]), FW [n_scales][bands][2][E] (gamma row, beta row), FB [n_scales][bands][2]
+ * (wv_train_film_param_count floats).  film[B][n_scales][bands][2] = (gamma, beta) per clip, scale and frequency band;
+ *   e0 = W0 msg + b0, e_l = relu(W_l e_{l-1} + b_l), gamma/beta = <FW, e_L> + FB.
+ * wv_train_film_apply: y[b,c,t] = x * gamma[b][scale][band(c)] + beta (band = c / (C / bands));  its backward returns dx and fills
+ * dfilm's entries of `scale`; wv_train_film_backward turns the complete dfilm into parameter gradients (ws = forward's buffer). */
+size_t wv_train_film_param_count(int msg_dim, int E, int layers, int n_scales, int bands);
+size_t wv_train_film_workspace_bytes(int B, int msg_dim, int E, int layers, int n_scales, int bands);
+int wv_train_film_forward(const float* msg, const float* params, float* film, int B, int msg_dim, int E, int layers, int n_scales, int bands,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int wv_train_film_backward(const float* msg, const float* params, const float* dfilm, float* dparams, int B, int msg_dim, int E, int layers,
+                           int n_scales, int bands, void* workspace, size_t workspace_bytes, void* stream);
+int wv_train_film_apply(const float* x, const float* film, float* y, int B, int C, int T, int bands, int n_scales, int scale, void* stream);
+int wv_train_film_apply_backward(const float* x, const float* film, const float* dy, float* dx, float* dfilm, int B, int C, int T, int bands,
+                                 int n_scales, int scale, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The two BCE-with-logits losses of the training step (scripts/loss.py:947-1099), forward + gradient in one pass:
  *   LocalizationLoss: msg = NULL, Cz = 1:  mean BCE(logits[B,1,T], mask[B,1,T])
  *   DecodingLoss:     mean BCE(logits[B,Cz,T], msg[B,Cz] * mask[B,1,T])        (mask NULL = all ones)

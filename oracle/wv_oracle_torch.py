@@ -78,7 +78,7 @@ def encoder_forward(net, x, msg):
     if msg is not None:
         if msg.shape[0] != x.shape[0]:
             msg = msg.repeat(int(math.ceil(x.shape[0] / msg.shape[0])), 1)[: x.shape[0]]
-        e = F.linear(msg.float(), net.w("encoder.msg_embedding.0.weight"), net.w("encoder.msg_embedding.0.bias"))
+        e = F.linear(msg.to(x.dtype), net.w("encoder.msg_embedding.0.weight"), net.w("encoder.msg_embedding.0.bias"))
         for i in range(cfg.embedding_layers):
             j = 1 + 2 * i
             e = F.relu(F.linear(e, net.w(f"encoder.msg_embedding.{j}.weight"), net.w(f"encoder.msg_embedding.{j}.bias")))

@@ -60,3 +60,16 @@ def loss_and_grads(cfg, sd, x, mask, msg=None, need_dx=False):
     loss.backward()
     grads = {k: t.grad.numpy() for k, t in net.leaf.items() if t.grad is not None}
     return float(loss.detach()), logits.detach().numpy(), grads, (xt.grad.numpy() if need_dx else None)
+
+
+def generator_loss_and_grads(cfg, sd, x, msg, target, need_dx=False):
+    """wm = G(x, msg)[..., :T] + x (generator.py:360-423, watermarking.py:423-441); loss = mean((wm - target)^2) -- any
+    differentiable function of wm would do: it only seeds dL/d(wm).  -> (loss, wm, {key: grad}, dx or None)."""
+    net = LiveNet(cfg, sd)
+    xt = torch.tensor(np.asarray(x), dtype=torch.float64, requires_grad=need_dx)
+    mt = torch.tensor(np.asarray(msg), dtype=torch.float64)
+    wm = OTc.decoder_forward(net, OTc.encoder_forward(net, xt, mt))[..., : xt.shape[-1]] + xt
+    loss = ((wm - torch.tensor(np.asarray(target), dtype=torch.float64)) ** 2).mean()
+    loss.backward()
+    grads = {k: t.grad.numpy() for k, t in net.leaf.items() if t.grad is not None}
+    return float(loss.detach()), wm.detach().numpy(), grads, (xt.grad.numpy() if need_dx else None)

@@ -91,3 +91,90 @@ def test_full_size_net_gradients_vs_oracle_and_training_steps(kind, B):
             assert d <= 2e-5 + 5e-3 * 1e-3, (it, k, d)                       # AdamW normalises: a step is <= lr per element
         losses.append(float(loss.item()))
     assert all(np.isfinite(losses))
+
+
+# ---- generator -----------------------------------------------------------------------------------------------------------------
+def test_film_mlp_vs_torch_modules():
+    """Message MLP + FiLM heads + the modulation itself against the torch modules the reference builds (nn.Linear chains,
+    seanet.py:518-550,831-846), float64 autograd."""
+    from waveverify_amd.train import FilmMlp
+    cfg = default_config("generator")
+    sd = random_state_dict(cfg, 3, parametrized=True)
+    fm = FilmMlp(cfg)
+    params = {k: _cu(np.asarray(sd[k], np.float32)) for k in fm.keys}
+    gviews = {k: torch.zeros_like(v) for k, v in params.items()}
+    rng = np.random.default_rng(0)
+    B, C, T, s = 5, 128, 64, 1
+    msg = rng.integers(0, 2, (B, cfg.msg_dimension)).astype(np.float32)
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    dy = rng.standard_normal((B, C, T)).astype(np.float32)
+    leaf = {k: torch.tensor(np.asarray(sd[k]), dtype=torch.float64, requires_grad=True) for k in fm.keys}
+    e = torch.nn.functional.linear(torch.from_numpy(msg).double(), leaf["encoder.msg_embedding.0.weight"], leaf["encoder.msg_embedding.0.bias"])
+    for i in range(cfg.embedding_layers):
+        e = torch.relu(torch.nn.functional.linear(e, leaf[f"encoder.msg_embedding.{1 + 2 * i}.weight"], leaf[f"encoder.msg_embedding.{1 + 2 * i}.bias"]))
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    bw, bands = C // cfg.freq_bands, []
+    for b in range(cfg.freq_bands):
+        ga = torch.nn.functional.linear(e, leaf[f"encoder.film_layers.{s}.{b}.gamma_layer.weight"], leaf[f"encoder.film_layers.{s}.{b}.gamma_layer.bias"]).unsqueeze(-1)
+        be = torch.nn.functional.linear(e, leaf[f"encoder.film_layers.{s}.{b}.beta_layer.weight"], leaf[f"encoder.film_layers.{s}.{b}.beta_layer.bias"]).unsqueeze(-1)
+        bands.append(xt[:, b * bw:(b + 1) * bw] * ga + be)
+    y = torch.cat(bands, 1)
+    y.backward(torch.from_numpy(dy).double())
+    film = fm.forward(_cu(msg), params)
+    got = fm.apply(_cu(x), film, s)
+    assert float((got.cpu().double() - y.detach()).abs().max()) <= 2e-5 * float(y.detach().abs().max())
+    dfilm = torch.zeros_like(film)
+    dx = fm.apply_backward(_cu(x), film, _cu(dy), dfilm, s)
+    assert float((dx.cpu().double() - xt.grad).abs().max()) <= 2e-5 * float(xt.grad.abs().max())
+    fm.backward(dfilm, gviews)
+    for k in fm.keys:
+        r = leaf[k].grad
+        got_k = gviews[k].cpu().double()
+        if r is None:                                      # the other scales' heads: untouched by this loss
+            assert float(got_k.abs().max()) == 0.0, k
+        else:
+            assert float((got_k - r).abs().max()) <= 1e-4 * max(float(r.abs().max()), 1e-12), k
+
+
+def test_generator_gradients_vs_reference_autograd(golden_dir):
+    from waveverify_amd.train import GeneratorTrainer
+    g = np.load(os.path.join(golden_dir, "netgrads_generator.npz"))
+    c = ast.literal_eval(str(g["cfg"][0]))
+    seed, kind = c.pop("seed"), c.pop("kind")
+    cfg = default_config(kind, **c)
+    tr = GeneratorTrainer(cfg, random_state_dict(cfg, seed, parametrized=True))
+    wm = tr.forward(_cu(g["x"]), _cu(g["msg"]))
+    assert float(np.abs(wm.cpu().numpy() - g["wm"]).max()) <= 2e-5
+    d_wm = 2.0 * (wm - _cu(g["target"])) / wm.numel()
+    tr.backward(d_wm)
+    check_grads(tr, {k[2:]: g[k] for k in g.files if k.startswith("g:")}, tol=2e-3)      # the fixture itself is float32 autograd
+
+
+def test_full_size_generator_gradients_vs_oracle_and_a_step():
+    """The default generator (22.7 GFLOP per clip forward) at 2 x 1 s: watermarked audio and every gradient vs the float64 oracle, one
+    optimizer step vs torch's AdamW on the oracle's gradients."""
+    from waveverify_amd.train import GeneratorTrainer
+    cfg = default_config("generator")
+    sd = random_state_dict(cfg, 0, parametrized=True)
+    rng = np.random.default_rng(21)
+    B, T = 2, 16000
+    x = (0.1 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    msg = rng.integers(0, 2, (B, cfg.nbits)).astype(np.float32)
+    target = (x + 0.01 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    ref_loss, ref_wm, ref_grads, ref_dx = OTT.generator_loss_and_grads(cfg, sd, x, msg, target)
+    tr = GeneratorTrainer(cfg, sd, lr=1e-3, max_norm=1.0)
+    wm = tr.forward(_cu(x), _cu(msg))
+    assert float(np.abs(wm.cpu().numpy() - ref_wm).max()) <= 2e-5
+    tr.backward(2.0 * (wm - _cu(target)) / wm.numel())
+    check_grads(tr, ref_grads, tol=5e-4)
+    keys = list(tr.params)
+    ref_p = {k: torch.nn.Parameter(torch.from_numpy(np.asarray(sd[k], dtype=np.float32).copy())) for k in keys}
+    opt = torch.optim.AdamW(list(ref_p.values()), lr=1e-3, betas=(0.8, 0.99))
+    for k, p in ref_p.items():
+        p.grad = torch.from_numpy(ref_grads[k].astype(np.float32)).view_as(p)
+    ref_norm = torch.nn.utils.clip_grad_norm_(list(ref_p.values()), 1.0)
+    opt.step()
+    norm = tr.apply_gradients()
+    assert abs(float(norm.item()) - float(ref_norm)) <= 5e-4 * float(ref_norm)
+    for k, p in ref_p.items():
+        assert float((tr.params[k].detach().cpu() - p.detach()).abs().max()) <= 2e-5 + 5e-6, k

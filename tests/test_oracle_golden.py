@@ -330,3 +330,25 @@ def test_train_oracle_upsample_unit_vs_reference_autograd(golden_dir):
         for k in ("y", "dx", "dg_ct", "dv_ct", "dg_pw", "dv_pw", "db"):
             b = g[f"up{i}_{k}"]
             assert float(np.abs(r[k].reshape(b.shape) - b).max() / max(np.abs(b).max(), 1e-30)) <= 2e-6, (i, k)
+
+
+def test_training_gradient_oracle_vs_whole_reference_generator(golden_dir):
+    """The generator's gradient oracle against the reference Generator's own autograd (float32: its encoder casts the message to
+    float32, so the module cannot run in float64) -- all 190-odd tensors incl. message MLP, FiLM heads, decoder."""
+    import ast
+    from oracle import wv_oracle_train_torch as OTT
+    from waveverify_amd.config import default_config
+    from waveverify_amd.init import random_state_dict
+    g = np.load(os.path.join(golden_dir, "netgrads_generator.npz"))
+    c = ast.literal_eval(str(g["cfg"][0]))
+    seed, kind = c.pop("seed"), c.pop("kind")
+    cfg = default_config(kind, **c)
+    sd = random_state_dict(cfg, seed, parametrized=True)
+    loss, wm, grads, dx = OTT.generator_loss_and_grads(cfg, sd, g["x"], g["msg"], g["target"], need_dx=True)
+    assert abs(loss - float(g["loss"])) <= 1e-4 * abs(loss)
+    assert np.abs(wm - g["wm"]).max() <= 2e-6
+    ref_keys = [k[2:] for k in g.files if k.startswith("g:")]
+    assert sorted(ref_keys) == sorted(grads)
+    for k in ref_keys:
+        r = g["g:" + k]
+        assert np.abs(grads[k] - r).max() <= 2e-3 * max(np.abs(r).max(), 1e-12) + 1e-9, (k, np.abs(grads[k] - r).max(), np.abs(r).max())

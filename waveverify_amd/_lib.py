@@ -97,6 +97,12 @@ SIGNATURES = {
     "wv_train_tail_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, C.c_int, C.c_int, C.c_int, _VP]),
     "wv_train_tail_backward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int,
                                          _VP, C.c_size_t, _VP]),
+    "wv_train_film_param_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "wv_train_film_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "wv_train_film_forward": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_train_film_backward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_train_film_apply": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
+    "wv_train_film_apply_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     "wv_train_block_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "wv_train_block_destroy": (None, [_VP]),
     "wv_train_block_saved_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),

@@ -498,6 +498,115 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__
     }
 }
 
+// ---- message MLP + FiLM (seanet.py:518-550,831-846,905-966) -------------------------------------------------------------------------
+// Packed parameter block (and gradient block, same layout):  W0 [E][Dm], b0 [E], then L x (W [E][E], b [E]), then the FiLM heads
+// FW [S][bands][2][E] (gamma row, beta row) and FB [S][bands][2].  One workgroup per clip; E <= 256.
+//   e0 = W0 msg + b0;  e_l = relu(W_l e_{l-1} + b_l);  film[b][s][band][0|1] = <FW[s][band][0|1], e_L> + FB
+constexpr int FILM_MAX_E = 256, FILM_MAX_L = 4;
+__global__ __launch_bounds__(256) void msg_film_fwd_kernel(const float* __restrict__ msg, const float* __restrict__ P, float* __restrict__ film,
+                                                            float* __restrict__ acts, int Dm, int E, int L, int NF) {
+    __shared__ float e[2][FILM_MAX_E];
+    const int b = blockIdx.x, j = threadIdx.x;
+    const float* W0 = P; const float* b0 = P + (size_t)E * Dm;
+    if (j < E) {
+        float a = b0[j];
+        for (int i = 0; i < Dm; ++i) a = fmaf(W0[(size_t)j * Dm + i], msg[(size_t)b * Dm + i], a);
+        e[0][j] = a;
+        if (acts) acts[((size_t)b * (L + 1)) * E + j] = a;
+    }
+    __syncthreads();
+    const float* Wl = b0 + E;
+    int cur = 0;
+    for (int l = 0; l < L; ++l) {
+        if (j < E) {
+            float a = Wl[(size_t)E * E + j];
+            for (int i = 0; i < E; ++i) a = fmaf(Wl[(size_t)j * E + i], e[cur][i], a);
+            a = fmaxf(a, 0.f);
+            e[cur ^ 1][j] = a;
+            if (acts) acts[((size_t)b * (L + 1) + l + 1) * E + j] = a;
+        }
+        __syncthreads();
+        cur ^= 1;
+        Wl += (size_t)E * E + E;
+    }
+    const float* FW = Wl; const float* FB = FW + (size_t)NF * E;
+    for (int f = j; f < NF; f += 256) {
+        float a = FB[f];
+        for (int i = 0; i < E; ++i) a = fmaf(FW[(size_t)f * E + i], e[cur][i], a);
+        film[(size_t)b * NF + f] = a;
+    }
+}
+
+// backward of the above for one clip: per-clip gradient block gpart[b][...] (summed over clips afterwards, fixed order)
+__global__ __launch_bounds__(256) void msg_film_bwd_kernel(const float* __restrict__ msg, const float* __restrict__ P, const float* __restrict__ acts,
+                                                            const float* __restrict__ dfilm, float* __restrict__ gpart, int Dm, int E, int L, int NF, size_t np) {
+    __shared__ float de[FILM_MAX_E], dz[FILM_MAX_E];
+    const int b = blockIdx.x, j = threadIdx.x;
+    float* G = gpart + (size_t)b * np;
+    const size_t off_l0 = (size_t)E * Dm + E, per = (size_t)E * E + E, off_f = off_l0 + (size_t)L * per;
+    const float* FW = P + off_f;
+    const float* eL = acts + ((size_t)b * (L + 1) + L) * E;
+    const float* df = dfilm + (size_t)b * NF;
+    // FiLM heads
+    for (int f = j; f < NF; f += 256) G[off_f + (size_t)NF * E + f] = df[f];
+    for (size_t i = j; i < (size_t)NF * E; i += 256) G[off_f + i] = df[i / E] * eL[i % E];
+    if (j < E) {
+        float a = 0.f;
+        for (int f = 0; f < NF; ++f) a = fmaf(df[f], FW[(size_t)f * E + j], a);
+        de[j] = a;
+    }
+    __syncthreads();
+    for (int l = L - 1; l >= 0; --l) {
+        const float* Wl = P + off_l0 + (size_t)l * per;
+        const float* eout = acts + ((size_t)b * (L + 1) + l + 1) * E;
+        const float* ein = acts + ((size_t)b * (L + 1) + l) * E;
+        if (j < E) dz[j] = eout[j] > 0.f ? de[j] : 0.f;
+        __syncthreads();
+        float* GW = G + off_l0 + (size_t)l * per;
+        for (size_t i = j; i < (size_t)E * E; i += 256) GW[i] = dz[i / E] * ein[i % E];
+        if (j < E) GW[(size_t)E * E + j] = dz[j];
+        float a = 0.f;
+        if (j < E) for (int o = 0; o < E; ++o) a = fmaf(Wl[(size_t)o * E + j], dz[o], a);
+        __syncthreads();
+        if (j < E) de[j] = a;
+        __syncthreads();
+    }
+    for (size_t i = j; i < (size_t)E * Dm; i += 256) G[i] = de[i / Dm] * msg[(size_t)b * Dm + i % Dm];
+    if (j < E) G[(size_t)E * Dm + j] = de[j];
+}
+
+// FiLM on the activations: y = x * gamma[b][band] + beta[b][band], band = c / (C / bands);  film points at this scale's [B][NF] block
+__global__ __launch_bounds__(256) void film_apply_kernel(const float* __restrict__ x, const float* __restrict__ film, float* __restrict__ y,
+                                                          int C, int T, int bands, int NF, int s_off) {
+    const int c = blockIdx.x, b = blockIdx.y, band = c / (C / bands);
+    const float g = film[(size_t)b * NF + s_off + band * 2], be = film[(size_t)b * NF + s_off + band * 2 + 1];
+    const size_t row = ((size_t)b * C + c) * T;
+    for (int t = threadIdx.x; t < T; t += 256) y[row + t] = fmaf(x[row + t], g, be);
+}
+// dx = dy * gamma;  rowsum[b][c] = (sum_t dy x, sum_t dy)
+__global__ __launch_bounds__(256) void film_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ film, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, float* __restrict__ rowsum, int C, int T, int bands, int NF, int s_off) {
+    __shared__ float sh[4];
+    const int c = blockIdx.x, b = blockIdx.y, band = c / (C / bands);
+    const float g = film[(size_t)b * NF + s_off + band * 2];
+    const size_t row = ((size_t)b * C + c) * T;
+    float a0 = 0.f, a1 = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) { const float d = dy[row + t]; a0 = fmaf(d, x[row + t], a0); a1 += d; dx[row + t] = d * g; }
+    const float s0 = block_sum(a0, sh);
+    __syncthreads();
+    const float s1 = block_sum(a1, sh);
+    if (threadIdx.x == 0) { rowsum[((size_t)b * C + c) * 2] = s0; rowsum[((size_t)b * C + c) * 2 + 1] = s1; }
+}
+// dfilm[b][s_off + band*2 + {0,1}] = sum over the band's channels of rowsum (fixed order)
+__global__ void film_band_reduce_kernel(const float* __restrict__ rowsum, float* __restrict__ dfilm, int B, int C, int bands, int NF, int s_off) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * bands * 2) return;
+    const int b = i / (bands * 2), r = i - b * bands * 2, band = r >> 1, which = r & 1, bw = C / bands;
+    float a = 0.f;
+    for (int c = band * bw; c < (band + 1) * bw; ++c) a += rowsum[((size_t)b * C + c) * 2 + which];
+    dfilm[(size_t)b * NF + s_off + band * 2 + which] = a;
+}
+
 // ---- optimizer step over a FLAT parameter arena (scripts/train.py:1346-1358, conf/base.yml:128-130) ------------------
 // Parameters, gradients and both AdamW moments of a net live in contiguous arenas, so gradient clipping is one
 // two-stage sum of squares and the update one launch (and the DDP buckets are plain slices of the gradient arena).
@@ -1330,6 +1439,64 @@ int wv_train_tail_backward(wv_train_tail* h, const float* x, const float* g, con
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(1), dim3(256), 0, s, g, v, h->inv, h->taps, dg, dv, C * ks);
     T_LAUNCH(hipGetLastError());
     T_LAUNCH(hipMemcpyAsync(db, h->dbv, sizeof(float), hipMemcpyDeviceToDevice, s));      // every channel row holds the same sum of dq
+    return WV_OK;
+}
+
+// ---- message MLP + FiLM ------------------------------------------------------------------------------------------------------------
+size_t wv_train_film_param_count(int msg_dim, int E, int layers, int n_scales, int bands) {
+    if (msg_dim < 1 || E < 1 || layers < 0 || n_scales < 1 || bands < 1) return 0;
+    return (size_t)E * msg_dim + E + (size_t)layers * ((size_t)E * E + E) + (size_t)n_scales * bands * 2 * (E + 1);
+}
+size_t wv_train_film_workspace_bytes(int B, int msg_dim, int E, int layers, int n_scales, int bands) {
+    return al256((size_t)B * (layers + 1) * E * 4) + al256((size_t)B * wv_train_film_param_count(msg_dim, E, layers, n_scales, bands) * 4);
+}
+
+static bool film_shape_ok(int B, int Dm, int E, int L, int S, int bands) {
+    return B >= 1 && Dm >= 1 && E >= 1 && E <= wv::FILM_MAX_E && L >= 0 && L <= wv::FILM_MAX_L && S >= 1 && bands >= 1;
+}
+
+int wv_train_film_forward(const float* msg, const float* params, float* film, int B, int msg_dim, int E, int layers, int n_scales, int bands,
+                          void* ws, size_t ws_bytes, void* stream) {
+    if (!msg || !params || !film || !film_shape_ok(B, msg_dim, E, layers, n_scales, bands)) return tfail(WV_EINVAL, "null / bad argument (E <= 256, layers <= 4)");
+    if (!ws || ws_bytes < wv_train_film_workspace_bytes(B, msg_dim, E, layers, n_scales, bands)) return tfail(WV_ENOMEM, "workspace too small");
+    hipLaunchKernelGGL(wv::msg_film_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, msg, params, film, (float*)ws, msg_dim, E, layers, n_scales * bands * 2);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+/* `ws` must be the buffer forward used (it holds the MLP activations). */
+int wv_train_film_backward(const float* msg, const float* params, const float* dfilm, float* dparams, int B, int msg_dim, int E, int layers,
+                           int n_scales, int bands, void* ws, size_t ws_bytes, void* stream) {
+    if (!msg || !params || !dfilm || !dparams || !film_shape_ok(B, msg_dim, E, layers, n_scales, bands)) return tfail(WV_EINVAL, "null / bad argument");
+    if (!ws || ws_bytes < wv_train_film_workspace_bytes(B, msg_dim, E, layers, n_scales, bands)) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t np = wv_train_film_param_count(msg_dim, E, layers, n_scales, bands);
+    float* acts = (float*)ws;
+    float* gpart = (float*)((char*)ws + al256((size_t)B * (layers + 1) * E * 4));
+    hipLaunchKernelGGL(wv::msg_film_bwd_kernel, dim3(B), dim3(256), 0, s, msg, params, acts, dfilm, gpart, msg_dim, E, layers, n_scales * bands * 2, np);
+    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, gpart, dparams, B, np);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+int wv_train_film_apply(const float* x, const float* film, float* y, int B, int C, int T, int bands, int n_scales, int scale, void* stream) {
+    if (!x || !film || !y || B < 1 || C < 1 || T < 1 || bands < 1 || C % bands || scale < 0 || scale >= n_scales) return tfail(WV_EINVAL, "null / bad argument");
+    hipLaunchKernelGGL(wv::film_apply_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, film, y, C, T, bands, n_scales * bands * 2, scale * bands * 2);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+/* dfilm: the [B][n_scales*bands*2] gradient block; this call fills the entries of `scale`.  ws: B*C*2 floats. */
+int wv_train_film_apply_backward(const float* x, const float* film, const float* dy, float* dx, float* dfilm, int B, int C, int T, int bands,
+                                 int n_scales, int scale, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !film || !dy || !dx || !dfilm || B < 1 || C < 1 || T < 1 || bands < 1 || C % bands || scale < 0 || scale >= n_scales)
+        return tfail(WV_EINVAL, "null / bad argument");
+    if (!ws || ws_bytes < (size_t)B * C * 2 * sizeof(float)) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int NF = n_scales * bands * 2, so = scale * bands * 2;
+    hipLaunchKernelGGL(wv::film_apply_bwd_kernel, dim3(C, B), dim3(256), 0, s, x, film, dy, dx, (float*)ws, C, T, bands, NF, so);
+    hipLaunchKernelGGL(wv::film_band_reduce_kernel, dim3((B * bands * 2 + 255) / 256), dim3(256), 0, s, (const float*)ws, dfilm, B, C, bands, NF, so);
+    T_LAUNCH(hipGetLastError());
     return WV_OK;
 }
 

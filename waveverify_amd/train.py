@@ -580,24 +580,83 @@ class BlockTrainer:
         return loss, norm
 
 
-class EncoderNetTrainer:
-    """The training step of the Detector or the Locator on the HIP units: SEANetEncoder (msg = None) + head under the reference's
-    BCE loss (/root/reference/model/detector.py:278-318, locator.py:228-299, modules/seanet.py:883-976, scripts/loss.py:947-1099,
-    scripts/train.py:1346-1358).  `state_dict` is the reference's PARAMETRIZED layout (weight norm original0 / original1); every
-    tensor that receives a gradient in the reference lives in one flat arena (`self.arena`, views in `self.params`), its gradient
-    in `self.grads`; the message MLP and FiLM layers of the encoder are unused without a message and stay out, as they stay
-    untouched in the reference (grad None).  One process per GPU: `step` all-reduces the gradient arena over RCCL.
-    Clip lengths must keep every ResnetBlock stage a multiple of 4 samples (T = 16000 does for both nets)."""
+class FilmMlp:
+    """Message MLP + FiLM heads (/root/reference/modules/seanet.py:518-550,831-846): packs the reference's parameters
+    (`encoder.msg_embedding.*`, `encoder.film_layers.{s}.{b}.{gamma,beta}_layer.*`) into the block the kernels read, and scatters
+    the gradient block back by key."""
 
-    def __init__(self, cfg, state_dict, lr: float = 1e-4, max_norm: float = 1000.0, device="cuda"):
-        if cfg.kind not in ("detector", "locator"):
-            raise ValueError("EncoderNetTrainer: detector or locator")
+    def __init__(self, cfg):
+        self._lib = _lib.load()
+        self.Dm, self.E, self.L, self.S, self.bands = cfg.msg_dimension, cfg.embedding_dim, cfg.embedding_layers, len(cfg.strides), cfg.freq_bands
+        self.NF = self.S * self.bands * 2
+        self.keys = ["encoder.msg_embedding.0.weight", "encoder.msg_embedding.0.bias"]
+        for i in range(self.L):
+            self.keys += [f"encoder.msg_embedding.{1 + 2 * i}.weight", f"encoder.msg_embedding.{1 + 2 * i}.bias"]
+        self.fw = [f"encoder.film_layers.{s}.{b}.{n}_layer.weight" for s in range(self.S) for b in range(self.bands) for n in ("gamma", "beta")]
+        self.fb = [k[:-len("weight")] + "bias" for k in self.fw]
+        self.keys += self.fw + self.fb
+        self.np = int(self._lib.wv_train_film_param_count(self.Dm, self.E, self.L, self.S, self.bands))
+        self._ws = None
+
+    def pack(self, params) -> torch.Tensor:
+        flat = torch.cat([params[k].reshape(-1) for k in self.keys])
+        assert flat.numel() == self.np
+        return flat
+
+    def forward(self, msg: torch.Tensor, params) -> torch.Tensor:
+        msg = _f(msg)
+        B = msg.shape[0]
+        self._packed, self._msg = self.pack(params), msg
+        film = torch.empty(B, self.NF, device=msg.device)
+        self._ws = torch.empty(int(self._lib.wv_train_film_workspace_bytes(B, self.Dm, self.E, self.L, self.S, self.bands)), dtype=torch.uint8,
+                               device=msg.device)
+        if self._lib.wv_train_film_forward(msg.data_ptr(), self._packed.data_ptr(), film.data_ptr(), B, self.Dm, self.E, self.L, self.S, self.bands,
+                                           self._ws.data_ptr(), self._ws.numel(), TrainHalf._stream()) != 0:
+            raise RuntimeError(f"wv_train_film_forward: {self._lib.wv_train_last_error().decode()}")
+        return film
+
+    def apply(self, x, film, scale: int):
+        x = _f(x)
+        B, Cc, T = x.shape
+        y = torch.empty_like(x)
+        if self._lib.wv_train_film_apply(x.data_ptr(), film.data_ptr(), y.data_ptr(), B, Cc, T, self.bands, self.S, scale, TrainHalf._stream()) != 0:
+            raise RuntimeError(f"wv_train_film_apply: {self._lib.wv_train_last_error().decode()}")
+        return y
+
+    def apply_backward(self, x, film, dy, dfilm, scale: int):
+        x, dy = _f(x), _f(dy)
+        B, Cc, T = x.shape
+        dx = torch.empty_like(x)
+        ws = torch.empty(B * Cc * 2, device=x.device)
+        if self._lib.wv_train_film_apply_backward(x.data_ptr(), film.data_ptr(), dy.data_ptr(), dx.data_ptr(), dfilm.data_ptr(), B, Cc, T, self.bands,
+                                                  self.S, scale, ws.data_ptr(), ws.numel() * 4, TrainHalf._stream()) != 0:
+            raise RuntimeError(f"wv_train_film_apply_backward: {self._lib.wv_train_last_error().decode()}")
+        return dx
+
+    def backward(self, dfilm, gviews) -> None:
+        B = self._msg.shape[0]
+        dp = torch.empty(self.np, device=dfilm.device)
+        if self._lib.wv_train_film_backward(self._msg.data_ptr(), self._packed.data_ptr(), dfilm.data_ptr(), dp.data_ptr(), B, self.Dm, self.E, self.L,
+                                            self.S, self.bands, self._ws.data_ptr(), self._ws.numel(), TrainHalf._stream()) != 0:
+            raise RuntimeError(f"wv_train_film_backward: {self._lib.wv_train_last_error().decode()}")
+        off = 0
+        for k in self.keys:
+            n = gviews[k].numel()
+            gviews[k].copy_(dp[off:off + n].view_as(gviews[k]))
+            off += n
+
+
+class _NetTrainer:
+    """Shared part of the net-level training steps: the flat parameter / gradient arenas keyed by the reference's PARAMETRIZED
+    state-dict names, and SEANetEncoder.forward / backward on the training units (/root/reference/modules/seanet.py:883-976)."""
+
+    def _build(self, cfg, state_dict, with_msg: bool, lr: float, max_norm: float, device):
         if cfg.dilation_base != 1:
             raise NotImplementedError("training units: dilation_base = 1 only")
-        self.cfg, self.max_norm = cfg, float(max_norm)
-        skip = ("encoder.msg_embedding.", "encoder.film_layers.")
+        self.cfg, self.max_norm, self.with_msg = cfg, float(max_norm), with_msg
+        skip = () if with_msg else ("encoder.msg_embedding.", "encoder.film_layers.")
         items = [(k, np.asarray(v, dtype=np.float32)) for k, v in state_dict.items()
-                 if not k.startswith(skip) and not k.endswith("spec.weight")]
+                 if not (skip and k.startswith(skip)) and not k.endswith("spec.weight")]
         n = sum(v.size for _, v in items)
         self.arena, self.grads = torch.empty(n, device=device), torch.zeros(n, device=device)
         self.params, self.gviews, off = {}, {}, 0
@@ -618,15 +677,14 @@ class EncoderNetTrainer:
         self.spec_post = TrainSpecAdd(C, n_fft // 2 + 1)
         self.stft_post = StftFeatures(n_fft, stride, cfg.spec_means[-1], cfg.spec_stds[-1])
         self.conv_post = TrainConvPost(C, cfg.dimension, cfg.last_kernel_size)
-        self.nb = cfg.nbits if cfg.kind == "detector" else 1
-        self.head = TrainHead(cfg.dimension, cfg.output_dim, self.nb, cfg.hop_length)
+        self.film = FilmMlp(cfg) if with_msg else None
         self.down_scale = (1 + cfg.n_residual_enc * rs ** 2) ** -0.5
         self.opt = FlatAdamW(n, lr=lr, device=device)
-        self._saved = None
+        self._enc = None
 
     # ---- parameter access by the reference's keys ------------------------------------------------------------------------------
-    def _wn(self, conv):          # weight-normed SConv1d "<conv>.conv.conv"
-        b = conv + ".conv.conv.parametrizations.weight."
+    def _wn(self, conv, inner=".conv.conv"):          # weight-normed SConv1d "<conv>.conv.conv" (or ".convtr.convtr")
+        b = conv + inner + ".parametrizations.weight."
         return self.params[b + "original0"], self.params[b + "original1"]
 
     def _half(self, pre, pw, dw):
@@ -634,8 +692,8 @@ class EncoderNetTrainer:
         g_dw, v_dw = self._wn(f"{pre}.{dw}")
         return dict(g_pw=g_pw, v_pw=v_pw, g_dw=g_dw, v_dw=v_dw, b_dw=self.params[f"{pre}.{dw}.conv.conv.bias"])
 
-    def _put(self, conv, dg, dv):
-        b = conv + ".conv.conv.parametrizations.weight."
+    def _put(self, conv, dg, dv, inner=".conv.conv"):
+        b = conv + inner + ".parametrizations.weight."
         self.gviews[b + "original0"].copy_(dg.view_as(self.gviews[b + "original0"]))
         self.gviews[b + "original1"].copy_(dv.view_as(self.gviews[b + "original1"]))
 
@@ -648,59 +706,65 @@ class EncoderNetTrainer:
         g, v = self._wn(pre + ".layer")
         return dict(g=g, v=v), self.params.get(pre + ".scale_param")
 
-    def _head_p(self):
-        return dict(w_rev=self.params["reverse_convolution.weight"], b_rev=self.params["reverse_convolution.bias"],
-                    w_last=self.params["last_layer.weight"], b_last=self.params["last_layer.bias"])
-
-    # ---- forward / backward ----------------------------------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        cfg, rs = self.cfg, self.cfg.res_scale_enc
-        x = _f(x)
-        sv = dict(x=x, scales=[])
-        g, v = self._wn("encoder.conv_pre.1")
-        h = self.conv_pre.forward(x, dict(g=g, v=v, b=self.params["encoder.conv_pre.1.conv.conv.bias"]), 1.0 / cfg.wav_std)
-        stride = 1
-        for s, sc in enumerate(self.scales):
-            rec = dict(blocks=[])
-            for j, blk in enumerate(sc["blocks"]):
-                pre = f"encoder.blocks.{s}.{j}"
-                ps = [self._half(pre + ".block", 1, 2), self._half(pre + ".block", 4, 5)]
-                pre_scale = (1 + (j + 1) * rs ** 2) ** -0.5                         # idx = j + 1 (seanet.py:183,684)
-                y, saved = blk.forward(h, ps, self.params.get(pre + ".res_scale_param"), pre_scale, rs)
-                rec["blocks"].append((h, saved, pre_scale))
-                h = y
-            P = sc["stft"](x)
-            sp, scp = self._spec_p(f"encoder.spec_blocks.{s}")
-            h = sc["spec"].forward(h, P, sp, scp, rs)
-            rec["P"], rec["down_in"] = P, h
-            h = sc["down"].forward(h, self._half(f"encoder.downsample.{s}", 2, 3), self.down_scale, True)
-            stride *= sc["r"]
-            sv["scales"].append(rec)
-        P = self.stft_post(x)
-        sp, scp = self._spec_p("encoder.spec_post")
-        h = self.spec_post.forward(h, P, sp, scp, rs)
-        sv["P_post"], sv["post_in"] = P, h
-        z = self.conv_post.forward(h, self._post_p())
-        sv["z"] = z
-        self._saved = sv
-        return self.head.forward(z, self._head_p(), x.shape[-1])
-
     def _post_p(self):
         g_dw, v_dw = self._wn("encoder.conv_post.1")
         g_pw, v_pw = self._wn("encoder.conv_post.2")
         return dict(g_dw=g_dw, v_dw=v_dw, g_pw=g_pw, v_pw=v_pw, b=self.params["encoder.conv_post.2.conv.conv.bias"])
 
-    def backward(self, dlogits: torch.Tensor, need_dx: bool = False):
-        """Fills `self.grads` (every view of `self.gviews`); returns dL/dx through conv_pre when asked.  (The spectrogram
-        branches' gradient towards the audio is not part of it yet: the STFT has no backward here.)"""
-        cfg, rs, sv = self.cfg, self.cfg.res_scale_enc, self._saved
+    def _block_fwd(self, blk, pre, h, pre_scale, rs):
+        ps = [self._half(pre + ".block", 1, 2), self._half(pre + ".block", 4, 5)]
+        y, saved = blk.forward(h, ps, self.params.get(pre + ".res_scale_param"), pre_scale, rs)
+        return y, (h, saved, pre_scale)
+
+    def _block_bwd(self, blk, pre, rec, dh, rs):
+        h_in, saved, pre_scale = rec
+        ps = [self._half(pre + ".block", 1, 2), self._half(pre + ".block", 4, 5)]
+        rsp = self.params.get(pre + ".res_scale_param")
+        gb = blk.backward(h_in, ps, rsp, pre_scale, rs, dh, saved)
+        self._put_half(pre + ".block", 1, 2, gb["halves"][0])
+        self._put_half(pre + ".block", 4, 5, gb["halves"][1])
+        if rsp is not None:
+            self.gviews[pre + ".res_scale_param"].copy_(gb["d_res_scale_param"])
+        return gb["dx"]
+
+    # ---- the encoder -----------------------------------------------------------------------------------------------------------------
+    def encoder_forward(self, x: torch.Tensor, msg: Optional[torch.Tensor]) -> torch.Tensor:
+        cfg, rs = self.cfg, self.cfg.res_scale_enc
+        sv = dict(x=x, scales=[], film=None)
+        if self.with_msg:
+            msg = _f(msg)
+            if msg.shape[0] != x.shape[0]:                                         # one message for the batch (watermarking.py:320-329)
+                msg = msg.repeat(-(-x.shape[0] // msg.shape[0]), 1)[: x.shape[0]].contiguous()
+            sv["film"] = self.film.forward(msg, self.params)
+        g, v = self._wn("encoder.conv_pre.1")
+        h = self.conv_pre.forward(x, dict(g=g, v=v, b=self.params["encoder.conv_pre.1.conv.conv.bias"]), 1.0 / cfg.wav_std)
+        for s, sc in enumerate(self.scales):
+            rec = dict(blocks=[])
+            for j, blk in enumerate(sc["blocks"]):
+                h, r_ = self._block_fwd(blk, f"encoder.blocks.{s}.{j}", h, (1 + (j + 1) * rs ** 2) ** -0.5, rs)   # idx = j + 1 (seanet.py:183,684)
+                rec["blocks"].append(r_)
+            P = sc["stft"](x)
+            sp, scp = self._spec_p(f"encoder.spec_blocks.{s}")
+            h = sc["spec"].forward(h, P, sp, scp, rs)
+            rec["P"], rec["down_in"] = P, h
+            h = sc["down"].forward(h, self._half(f"encoder.downsample.{s}", 2, 3), self.down_scale, True)
+            if self.with_msg:
+                rec["film_in"] = h
+                h = self.film.apply(h, sv["film"], s)
+            sv["scales"].append(rec)
+        P = self.stft_post(x)
+        sp, scp = self._spec_p("encoder.spec_post")
+        h = self.spec_post.forward(h, P, sp, scp, rs)
+        sv["P_post"], sv["post_in"] = P, h
+        self._enc = sv
+        return self.conv_post.forward(h, self._post_p())
+
+    def encoder_backward(self, dz: torch.Tensor, need_dx: bool = False):
+        """(The spectrogram branches' gradient towards the audio is not part of dx yet: the STFT has no backward here.)"""
+        cfg, rs, sv = self.cfg, self.cfg.res_scale_enc, self._enc
         if sv is None:
             raise RuntimeError("backward before forward")
-        g = self.head.backward(sv["z"], self._head_p(), dlogits)
-        for k, name in (("dw_rev", "reverse_convolution.weight"), ("db_rev", "reverse_convolution.bias"), ("dw_last", "last_layer.weight"),
-                        ("db_last", "last_layer.bias")):
-            self.gviews[name].copy_(g[k].view_as(self.gviews[name]))
-        g = self.conv_post.backward(sv["post_in"], self._post_p(), g["dz"])
+        g = self.conv_post.backward(sv["post_in"], self._post_p(), dz)
         self._put("encoder.conv_post.1", g["dg_dw"], g["dv_dw"])
         self._put("encoder.conv_post.2", g["dg_pw"], g["dv_pw"])
         self.gviews["encoder.conv_post.2.conv.conv.bias"].copy_(g["db"])
@@ -713,37 +777,159 @@ class EncoderNetTrainer:
             if scp is not None:
                 self.gviews[pre + ".scale_param"].copy_(gs["d_scale_param"])
         spec_back(self.spec_post, "encoder.spec_post", sv["P_post"], dh)
+        dfilm = torch.zeros_like(sv["film"]) if self.with_msg else None
         for s in reversed(range(len(self.scales))):
             sc, rec = self.scales[s], sv["scales"][s]
+            if self.with_msg:
+                dh = self.film.apply_backward(rec["film_in"], sv["film"], dh, dfilm, s)
             gd = sc["down"].backward(rec["down_in"], self._half(f"encoder.downsample.{s}", 2, 3), self.down_scale, dh, True, True)
             self._put_half(f"encoder.downsample.{s}", 2, 3, gd)
             dh = gd["dx"]
             spec_back(sc["spec"], f"encoder.spec_blocks.{s}", rec["P"], dh)          # the add passes dh through unchanged
             for j in reversed(range(len(sc["blocks"]))):
-                pre = f"encoder.blocks.{s}.{j}"
-                h_in, saved, pre_scale = rec["blocks"][j]
-                ps = [self._half(pre + ".block", 1, 2), self._half(pre + ".block", 4, 5)]
-                rsp = self.params.get(pre + ".res_scale_param")
-                gb = sc["blocks"][j].backward(h_in, ps, rsp, pre_scale, rs, dh, saved)
-                self._put_half(pre + ".block", 1, 2, gb["halves"][0])
-                self._put_half(pre + ".block", 4, 5, gb["halves"][1])
-                if rsp is not None:
-                    self.gviews[pre + ".res_scale_param"].copy_(gb["d_res_scale_param"])
-                dh = gb["dx"]
+                dh = self._block_bwd(sc["blocks"][j], f"encoder.blocks.{s}.{j}", rec["blocks"][j], dh, rs)
+        if self.with_msg:
+            self.film.backward(dfilm, self.gviews)
         gv = self._wn("encoder.conv_pre.1")
         gp = self.conv_pre.backward(sv["x"], dict(g=gv[0], v=gv[1], b=self.params["encoder.conv_pre.1.conv.conv.bias"]), 1.0 / cfg.wav_std,
                                     dh, need_dx)
         self._put("encoder.conv_pre.1", gp["dg"], gp["dv"])
         self.gviews["encoder.conv_pre.1.conv.conv.bias"].copy_(gp["db"])
-        self._saved = None
+        self._enc = None
         return gp["dx"]
+
+    def _optimizer_step(self):
+        from .parallel import allreduce_mean_flat_
+        allreduce_mean_flat_(self.grads)
+        return self.opt.step(self.arena, self.grads, self.max_norm)
+
+
+class EncoderNetTrainer(_NetTrainer):
+    """The training step of the Detector or the Locator on the HIP units: SEANetEncoder (msg = None) + head under the reference's
+    BCE loss (/root/reference/model/detector.py:278-318, locator.py:228-299, modules/seanet.py:883-976, scripts/loss.py:947-1099,
+    scripts/train.py:1346-1358).  `state_dict` is the reference's PARAMETRIZED layout (weight norm original0 / original1); every
+    tensor that receives a gradient in the reference lives in one flat arena (`self.arena`, views in `self.params`), its gradient
+    in `self.grads`; the message MLP and FiLM layers of the encoder are unused without a message and stay out, as they stay
+    untouched in the reference (grad None).  One process per GPU: `step` all-reduces the gradient arena over RCCL.
+    Clip lengths must keep every ResnetBlock stage a multiple of 4 samples (T = 16000 does for both nets)."""
+
+    def __init__(self, cfg, state_dict, lr: float = 1e-4, max_norm: float = 1000.0, device="cuda"):
+        if cfg.kind not in ("detector", "locator"):
+            raise ValueError("EncoderNetTrainer: detector or locator")
+        self._build(cfg, state_dict, False, lr, max_norm, device)
+        self.nb = cfg.nbits if cfg.kind == "detector" else 1
+        self.head = TrainHead(cfg.dimension, cfg.output_dim, self.nb, cfg.hop_length)
+        self._z = None
+
+    def _head_p(self):
+        return dict(w_rev=self.params["reverse_convolution.weight"], b_rev=self.params["reverse_convolution.bias"],
+                    w_last=self.params["last_layer.weight"], b_last=self.params["last_layer.bias"])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = _f(x)
+        self._z = self.encoder_forward(x, None)
+        return self.head.forward(self._z, self._head_p(), x.shape[-1])
+
+    def backward(self, dlogits: torch.Tensor, need_dx: bool = False):
+        """Fills `self.grads` (every view of `self.gviews`); returns dL/dx through conv_pre when asked."""
+        if self._z is None:
+            raise RuntimeError("backward before forward")
+        g = self.head.backward(self._z, self._head_p(), dlogits)
+        for k, name in (("dw_rev", "reverse_convolution.weight"), ("db_rev", "reverse_convolution.bias"), ("dw_last", "last_layer.weight"),
+                        ("db_last", "last_layer.bias")):
+            self.gviews[name].copy_(g[k].view_as(self.gviews[name]))
+        self._z = None
+        return self.encoder_backward(g["dz"], need_dx)
 
     def step(self, x: torch.Tensor, mask: torch.Tensor, msg: Optional[torch.Tensor] = None):
         """One optimizer step on this rank's clips: LocalizationLoss (locator: msg None) or DecodingLoss (detector) ->
         backward -> mean all-reduce of the gradient arena -> clip + AdamW + ExponentialLR.  Returns (loss, gradient norm)."""
-        from .parallel import allreduce_mean_flat_
         logits = self.forward(x)
         loss, dz = bce_logits(logits, mask, msg)
         self.backward(dz)
-        allreduce_mean_flat_(self.grads)
-        return loss, self.opt.step(self.arena, self.grads, self.max_norm)
+        return loss, self._optimizer_step()
+
+
+class GeneratorTrainer(_NetTrainer):
+    """Forward and backward of the Generator on the HIP units (/root/reference/model/generator.py:290-423, modules/seanet.py:883-976
+    with the message path, :1067-1226 decoder; model/watermarking.py:423-441: wm = G(x, msg)[..., :T] + x).  `forward(x, msg)` returns
+    the watermarked audio; `backward(d_wm)` takes the gradient of ANY loss on it (the reference's waveform / spectral / adversarial
+    losses stay on PyTorch-ROCm) and fills `self.grads`; `apply_gradients()` all-reduces and steps AdamW."""
+
+    def __init__(self, cfg, state_dict, lr: float = 1e-4, max_norm: float = 1000.0, device="cuda"):
+        from .params import decoder_layout
+        if cfg.kind != "generator":
+            raise ValueError("GeneratorTrainer: generator")
+        self._build(cfg, state_dict, True, lr, max_norm, device)
+        self.i_pw0, self.i_dw0, self.ups, self.i_last = decoder_layout(cfg)
+        Ctop = (2 ** len(cfg.strides)) * cfg.channels_dec
+        self.dec_in = TrainUnit(cfg.dimension, Ctop, cfg.kernel_size, 1)
+        self.dec_ups = [dict(up=TrainUp(C, C // 2, r), blocks=[TrainBlock(C // 2) for _ in res]) for _, _, res, r, C in self.ups]
+        self.tail = TrainTail(cfg.channels_dec, cfg.last_kernel_size)
+        self.post = (1 + cfg.n_residual_dec * cfg.res_scale_dec ** 2) ** -0.5
+        self._dec = None
+
+    def _in_p(self):
+        g_pw, v_pw = self._wn(f"decoder.model.{self.i_pw0}")
+        g_dw, v_dw = self._wn(f"decoder.model.{self.i_dw0}")
+        return dict(g_pw=g_pw, v_pw=v_pw, g_dw=g_dw, v_dw=v_dw, b_dw=self.params[f"decoder.model.{self.i_dw0}.conv.conv.bias"])
+
+    def _up_p(self, ct, pw):
+        g_ct, v_ct = self._wn(f"decoder.model.{ct}", ".convtr.convtr")
+        g_pw, v_pw = self._wn(f"decoder.model.{pw}")
+        return dict(g_ct=g_ct, v_ct=v_ct, g_pw=g_pw, v_pw=v_pw, b=self.params[f"decoder.model.{pw}.conv.conv.bias"])
+
+    def _tail_p(self):
+        g, v = self._wn(f"decoder.model.{self.i_last}")
+        return dict(g=g, v=v, b=self.params[f"decoder.model.{self.i_last}.conv.conv.bias"])
+
+    def forward(self, x: torch.Tensor, msg: torch.Tensor) -> torch.Tensor:
+        cfg, rs = self.cfg, self.cfg.res_scale_dec
+        x = _f(x)
+        z = self.encoder_forward(x, msg)
+        sv = dict(z=z, ups=[])
+        h = self.dec_in.forward(z, self._in_p(), 1.0, False)
+        for i, ((ct, pw, res, r, C), du) in enumerate(zip(self.ups, self.dec_ups)):
+            rec = dict(up_in=h, blocks=[])
+            h = du["up"].forward(h, self._up_p(ct, pw), self.post if i > 0 else 1.0, True)
+            for j, (ri, blk) in enumerate(zip(res, du["blocks"])):
+                h, r_ = self._block_fwd(blk, f"decoder.model.{ri}", h, (1 + j * rs ** 2) ** -0.5, rs)               # idx = j (seanet.py:1143-1161)
+                rec["blocks"].append(r_)
+            sv["ups"].append(rec)
+        sv["tail_in"] = h
+        delta = self.tail.forward(h, self._tail_p(), self.post, cfg.wav_std, x.shape[-1])
+        sv["delta"] = delta
+        self._dec = sv
+        return delta + x
+
+    def backward(self, d_wm: torch.Tensor, need_dx: bool = False):
+        """d_wm = dLoss/d(watermarked audio) [B,1,T].  Returns the gradient towards the input audio through the generator's conv_pre
+        path plus the identity (wm = delta + x) when asked."""
+        cfg, rs, sv = self.cfg, self.cfg.res_scale_dec, self._dec
+        if sv is None:
+            raise RuntimeError("backward before forward")
+        d_wm = _f(d_wm)
+        g = self.tail.backward(sv["tail_in"], self._tail_p(), self.post, cfg.wav_std, sv["delta"], d_wm)
+        self._put(f"decoder.model.{self.i_last}", g["dg"], g["dv"])
+        self.gviews[f"decoder.model.{self.i_last}.conv.conv.bias"].copy_(g["db"])
+        dh = g["dx"]
+        for i in reversed(range(len(self.ups))):
+            (ct, pw, res, r, C), du, rec = self.ups[i], self.dec_ups[i], sv["ups"][i]
+            for j in reversed(range(len(res))):
+                dh = self._block_bwd(du["blocks"][j], f"decoder.model.{res[j]}", rec["blocks"][j], dh, rs)
+            gu = du["up"].backward(rec["up_in"], self._up_p(ct, pw), self.post if i > 0 else 1.0, dh, True)
+            self._put(f"decoder.model.{ct}", gu["dg_ct"], gu["dv_ct"], ".convtr.convtr")
+            self._put(f"decoder.model.{pw}", gu["dg_pw"], gu["dv_pw"])
+            self.gviews[f"decoder.model.{pw}.conv.conv.bias"].copy_(gu["db"])
+            dh = gu["dx"]
+        gi = self.dec_in.backward(sv["z"], self._in_p(), 1.0, dh, False, True)
+        self._put(f"decoder.model.{self.i_pw0}", gi["dg_pw"], gi["dv_pw"])
+        self._put(f"decoder.model.{self.i_dw0}", gi["dg_dw"], gi["dv_dw"])
+        self.gviews[f"decoder.model.{self.i_dw0}.conv.conv.bias"].copy_(gi["db_dw"])
+        self._dec = None
+        dx = self.encoder_backward(gi["dx"], need_dx)
+        return None if dx is None else dx + d_wm
+
+    def apply_gradients(self):
+        """Mean all-reduce of the gradient arena over the ranks, clip_grad_norm_, AdamW, ExponentialLR (scripts/train.py:1346-1358)."""
+        return self._optimizer_step()
