@@ -188,6 +188,11 @@ typedef struct wv_stft_plan wv_stft_plan;
 int wv_stft_plan_create(int n_fft, const float* basis_or_null, wv_stft_plan** out);
 void wv_stft_plan_destroy(wv_stft_plan* p);
 int wv_stft_plan_logmag(const wv_stft_plan* p, const float* wav, float* P, int B, int T, int hop, float mean, float std, void* stream);
+/* backward of the features towards the audio: dwav[B,1,T] (+)= d/dwav of <dP, P(wav)> (training the generator through the detector's and
+ * locator's spectrogram branches).  The clamps of the reference (conv.py:1078, seanet.py:484) pass no gradient where |STFT|^2 <= 1e-10. */
+size_t wv_stft_plan_backward_workspace_bytes(const wv_stft_plan* p, int B, int T, int hop);
+int wv_stft_plan_backward(const wv_stft_plan* p, const float* wav, const float* dP, float* dwav, int accumulate, int B, int T, int hop, float std,
+                          void* workspace, size_t workspace_bytes, void* stream);
 int wv_op_conv_pre(const float* x, const float* w, const float* bias, float* Y, int B, int C,
                    int T, int ks, float in_scale, void* stream);
 
@@ -275,7 +280,8 @@ int wv_train_convpre_backward(wv_train_convpre* h, const float* x, const float* 
 /* SpecBlock add with live weight norm (seanet.py:463-511): y[B,C,T] = x + s * ((g v/||v||)[C,F] @ P[B,F,T]),
  * s = res_scale * scale_param[0] (scale_param: device scalar of zero_init blocks, or NULL).  P is the normalised
  * log-magnitude STFT of the waveform (no parameters; wv_op_stft_logmag / the model's STFT kernel).  dx = dy (identity)
- * is the caller's; backward returns dg [C], dv [C,F] and d(scale_param).  y may alias x. */
+ * is the caller's; backward returns dg [C], dv [C,F], d(scale_param) and, when asked, dP = s W^T dy (the gradient towards the
+ * features, continued to the audio by wv_stft_plan_backward).  y may alias x. */
 typedef struct wv_train_spec wv_train_spec;
 int wv_train_spec_create(int C, int F, wv_train_spec** out);
 void wv_train_spec_destroy(wv_train_spec* h);
@@ -283,7 +289,7 @@ size_t wv_train_spec_workspace_bytes(const wv_train_spec* h, int B, int T);
 int wv_train_spec_forward(wv_train_spec* h, const float* x, const float* P, const float* g, const float* v, const float* scale_param,
                           float res_scale, float* y, int B, int T, void* stream);
 int wv_train_spec_backward(wv_train_spec* h, const float* P, const float* g, const float* v, const float* scale_param, float res_scale,
-                           const float* dy, float* dg, float* dv, float* d_scale_param, int B, int T,
+                           const float* dy, float* dg, float* dv, float* d_scale_param, float* dP /* [B,F,T] or NULL */, int B, int T,
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* conv_post with live weight norm (seanet.py:795-822): y[B,D,T] = L2Norm( (g_pw v_pw/||v_pw||)[D,C] @ DW_ks( ELU(x[B,C,T]) ; g_dw v_dw/||v_dw|| ) + bias )

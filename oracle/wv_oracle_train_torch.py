@@ -73,3 +73,19 @@ def generator_loss_and_grads(cfg, sd, x, msg, target, need_dx=False):
     loss.backward()
     grads = {k: t.grad.numpy() for k, t in net.leaf.items() if t.grad is not None}
     return float(loss.detach()), wm.detach().numpy(), grads, (xt.grad.numpy() if need_dx else None)
+
+
+def joint_decoding_loss_and_grads(cfgG, sdG, cfgD, sdD, x, msg, mask):
+    """The watermarking objective in miniature (watermarking.py:340-441, loss.py:1020-1099): wm = G(x, msg)[..., :T] + x;
+    loss = DecodingLoss(D(wm), mask, msg).  -> (loss, {G key: grad}, {D key: grad}, dL/d(wm))."""
+    G, D = LiveNet(cfgG, sdG), LiveNet(cfgD, sdD)
+    xt = torch.tensor(np.asarray(x), dtype=torch.float64)
+    mt = torch.tensor(np.asarray(msg), dtype=torch.float64)
+    wm = OTc.decoder_forward(G, OTc.encoder_forward(G, xt, mt))[..., : xt.shape[-1]] + xt
+    wm.retain_grad()
+    logits = logits_of(D, wm)
+    target = mt.unsqueeze(2) * torch.tensor(np.asarray(mask), dtype=torch.float64)
+    loss = F.binary_cross_entropy_with_logits(logits, target.expand_as(logits), reduction="mean")
+    loss.backward()
+    return (float(loss.detach()), {k: t.grad.numpy() for k, t in G.leaf.items() if t.grad is not None},
+            {k: t.grad.numpy() for k, t in D.leaf.items() if t.grad is not None}, wm.grad.numpy())

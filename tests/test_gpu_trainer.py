@@ -20,13 +20,20 @@ def _cu(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def check_grads(tr, ref_grads, tol=2e-4):
+def check_grads(tr, ref_grads, tol=2e-4, loose=None):
+    """Every gradient tensor within tol of its own largest magnitude.  Scalars (FiLM gamma / beta biases, scale parameters) are sums
+    over a whole activation tensor whose terms cancel: they are held to the largest scalar gradient of the net instead of to themselves."""
     assert sorted(tr.gviews) == sorted(ref_grads)
+    scalar_scale = max([float(np.abs(r).max()) for r in ref_grads.values() if r.size <= 4] + [1e-30])
     worst = ("", 0.0)
     for k, r in ref_grads.items():
         got = tr.gviews[k].detach().cpu().numpy().astype(np.float64)
         assert np.isfinite(got).all(), k
-        e = float(np.abs(got - r.reshape(got.shape)).max() / max(np.abs(r).max(), 1e-30))
+        scale = max(float(np.abs(r).max()), scalar_scale if r.size <= 4 else 0.0, 1e-30)
+        e = float(np.abs(got - r.reshape(got.shape)).max() / scale)
+        if loose and any(t in k for t in loose[0]):
+            assert e <= loose[1], (k, e)
+            continue
         if e > worst[1]:
             worst = (k, e)
     assert worst[1] <= tol, worst
@@ -178,3 +185,63 @@ def test_full_size_generator_gradients_vs_oracle_and_a_step():
     assert abs(float(norm.item()) - float(ref_norm)) <= 5e-4 * float(ref_norm)
     for k, p in ref_p.items():
         assert float((tr.params[k].detach().cpu() - p.detach()).abs().max()) <= 2e-5 + 5e-6, k
+
+
+# ---- gradients towards the audio, and the generator trained THROUGH the detector ----------------------------------------------------
+@pytest.mark.parametrize("n_fft,hop,T", [(64, 1, 1000), (128, 2, 1000), (256, 8, 4000), (1024, 320, 16000), (64, 4, 37)])
+def test_stft_feature_backward_vs_torch_autograd(n_fft, hop, T):
+    """d<dP, P(wav)>/dwav against torch autograd of the reference's formula (conv1d with the windowed DFT basis, sqrt(clamp), log(clamp),
+    normalise; conv.py:1055-1078, seanet.py:484-494) in float64, with the pinned basis."""
+    from oracle import wv_oracle as O
+    from waveverify_amd.train import StftFeatures
+    import torch.nn.functional as F
+    rng = np.random.default_rng(n_fft + hop)
+    B = 3
+    wav = (0.1 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    wav[1, 0, : T // 3] = 0.0                                       # silence: the clamped region passes no gradient
+    st = StftFeatures(n_fft, hop, -4.3, 2.8)
+    P = st(_cu(wav))
+    dP = rng.standard_normal(tuple(P.shape)).astype(np.float32)
+    w = torch.from_numpy(wav).double().requires_grad_(True)
+    basis = torch.from_numpy(O.dft_basis(n_fft)).double()[:, None, :]
+    c = F.conv1d(F.pad(w, (n_fft - 1, 0)), basis, None, stride=hop)
+    Fq = n_fft // 2 + 1
+    y = (((c[:, :Fq] ** 2 + c[:, Fq:] ** 2).clamp_min(1e-12).sqrt().clamp_min(1e-5).log()) - (-4.3)) / 2.8
+    y.backward(torch.from_numpy(dP).double())
+    dw = torch.zeros(B, 1, T, device="cuda")
+    st.backward(_cu(wav), _cu(dP), dw, accumulate=False)
+    ref = w.grad.numpy()
+    assert float(np.abs(dw.cpu().numpy() - ref).max()) <= 2e-4 * float(np.abs(ref).max())
+    st.backward(_cu(wav), _cu(dP), dw, accumulate=True)             # accumulates
+    assert float(np.abs(dw.cpu().numpy() - 2 * ref).max()) <= 4e-4 * float(np.abs(ref).max())
+
+
+def test_generator_trained_through_the_detector_vs_oracle():
+    """The watermarking objective in miniature: wm = G(x, msg) + x, DecodingLoss(D(wm), mask, msg).  The detector's backward hands
+    dL/d(wm) -- through conv_pre AND all five spectrogram branches -- to the generator's backward; every gradient of BOTH nets against
+    the float64 oracle over the two nets."""
+    from waveverify_amd.train import EncoderNetTrainer, GeneratorTrainer, bce_logits
+    cfgG, cfgD = default_config("generator"), default_config("detector")
+    sdG, sdD = random_state_dict(cfgG, 0, parametrized=True), random_state_dict(cfgD, 0, parametrized=True)
+    rng = np.random.default_rng(5)
+    B, T = 2, 16000
+    x = (0.1 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    msg = rng.integers(0, 2, (B, cfgG.nbits)).astype(np.float32)
+    mask = (rng.random((B, 1, T)) < 0.8).astype(np.float32)
+    ref_loss, gG, gD, ref_dwm = OTT.joint_decoding_loss_and_grads(cfgG, sdG, cfgD, sdD, x, msg, mask)
+    G, D = GeneratorTrainer(cfgG, sdG), EncoderNetTrainer(cfgD, sdD)
+    wm = G.forward(_cu(x), _cu(msg))
+    logits = D.forward(wm)
+    loss, dz = bce_logits(logits, _cu(mask), _cu(msg))
+    assert abs(float(loss.item()) - ref_loss) <= 2e-5 * ref_loss
+    d_wm = D.backward(dz, need_dx=True)
+    # conv_pre + five spectrogram branches; d log|STFT| = re / |STFT|^2 amplifies the f32 rounding of quiet bins: 5e-3 of the peak
+    assert float(np.abs(d_wm.cpu().numpy() - ref_dwm).max()) <= 5e-3 * float(np.abs(ref_dwm).max())
+    G.backward(d_wm)
+    check_grads(D, gD, tol=5e-4)
+    # FiLM / message-MLP gradients are sums of dL/dy over whole activation tensors whose terms cancel: the error of dL/d(wm) shows there
+    check_grads(G, gG, tol=1e-2, loose=(("film_layers", "msg_embedding"), 1e-1))
+    # the same generator backward fed with the oracle's exact dL/d(wm): the strict bar again
+    G.forward(_cu(x), _cu(msg))
+    G.backward(_cu(ref_dwm.astype(np.float32)))
+    check_grads(G, gG, tol=1e-3)

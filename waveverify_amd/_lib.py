@@ -70,7 +70,7 @@ SIGNATURES = {
     "wv_train_spec_destroy": (None, [_VP]),
     "wv_train_spec_workspace_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),
     "wv_train_spec_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, C.c_int, C.c_int, _VP]),
-    "wv_train_spec_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_train_spec_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     "wv_train_convpost_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
     "wv_train_convpost_destroy": (None, [_VP]),
     "wv_train_convpost_workspace_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),
@@ -85,6 +85,8 @@ SIGNATURES = {
     "wv_stft_plan_create": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
     "wv_stft_plan_destroy": (None, [_VP]),
     "wv_stft_plan_logmag": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _VP]),
+    "wv_stft_plan_backward_workspace_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int, C.c_int]),
+    "wv_stft_plan_backward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _VP, C.c_size_t, _VP]),
     "wv_train_up_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
     "wv_train_up_destroy": (None, [_VP]),
     "wv_train_up_workspace_bytes": (C.c_size_t, [_VP, C.c_int, C.c_int]),

@@ -170,11 +170,53 @@ int wv_op_stft_logmag(const float* wav, const float* basis_or_null, float* P, in
 }  // extern "C"
 
 // A resident plan of the same op (the basis packed and uploaded once): what a training step calls once per scale and step.
+// It also carries the BACKWARD of the features towards the audio (training the generator through the detector / locator):
+//   C = Basis[2F][n] @ frames(wav)  (re rows, then im rows);  p = re^2 + im^2;  P = (0.5 ln max(p, 1e-10) - mean) / std
+//   dC = dP * {re, im} / (std * p)  where p > 1e-10 (the clamps of conv.py:1078 / seanet.py:484 pass no gradient below), else 0
+//   dwav = overlap-add( Basis^T[n][2F] @ dC )
+// on the generic GEMM core: frames are materialised ([B][n_fft][Tf], a few MB per clip), two GEMMs, three small kernels.
 struct wv_stft_plan {
     int n_fft = 0, Mp = 0;
     float *basis_t = nullptr, *basis_q = nullptr, *side = nullptr;
-    ~wv_stft_plan() { (void)hipFree(basis_t); (void)hipFree(basis_q); (void)hipFree(side); }
+    float *wt_fwd = nullptr, *wt_bwd = nullptr;      // K-major packs of Basis [2F][n] and of Basis^T [n][2F]
+    ~wv_stft_plan() { (void)hipFree(basis_t); (void)hipFree(basis_q); (void)hipFree(side); (void)hipFree(wt_fwd); (void)hipFree(wt_bwd); }
 };
+
+namespace {
+__global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restrict__ wav, float* __restrict__ X, int T, int Tf, int n_fft, int hop) {
+    const int n = blockIdx.y, b = blockIdx.z;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= Tf) return;
+    const int sidx = t * hop + n - (n_fft - 1);
+    X[((size_t)b * n_fft + n) * Tf + t] = (sidx >= 0 && sidx < T) ? wav[(size_t)b * T + sidx] : 0.f;
+}
+// in place: C[b][f] (re), C[b][F + f] (im) <- their gradients
+__global__ __launch_bounds__(256) void stft_dc_kernel(float* __restrict__ Cm, const float* __restrict__ dP, int F, int Tf, float inv_std) {
+    const int f = blockIdx.y, b = blockIdx.z;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= Tf) return;
+    float* re = Cm + ((size_t)b * 2 * F + f) * Tf + t;
+    float* im = Cm + ((size_t)b * 2 * F + F + f) * Tf + t;
+    const float r = *re, i = *im, p = fmaf(r, r, i * i);
+    const float g = p > 1e-10f ? dP[((size_t)b * F + f) * Tf + t] * inv_std / p : 0.f;
+    *re = g * r; *im = g * i;
+}
+// dwav[b][s] (+)= sum over frames t and taps n with t*hop + n - (n_fft-1) = s of Q[b][n][t]   (fixed order: t ascending)
+__global__ __launch_bounds__(256) void stft_overlap_add_kernel(const float* __restrict__ Q, float* __restrict__ dwav, int T, int Tf, int n_fft, int hop, int accumulate) {
+    const int b = blockIdx.y;
+    const int sidx = blockIdx.x * 256 + threadIdx.x;
+    if (sidx >= T) return;
+    const int base = sidx + (n_fft - 1);                     // n = base - t*hop in [0, n_fft)
+    int t_lo = (base - (n_fft - 1) + hop - 1) / hop;
+    if (t_lo < 0) t_lo = 0;
+    int t_hi = base / hop;
+    if (t_hi > Tf - 1) t_hi = Tf - 1;
+    float a = 0.f;
+    for (int t = t_lo; t <= t_hi; ++t) a += Q[((size_t)b * n_fft + (base - t * hop)) * Tf + t];
+    dwav[(size_t)b * T + sidx] = accumulate ? dwav[(size_t)b * T + sidx] + a : a;
+}
+size_t al256o(size_t x) { return (x + 255) & ~(size_t)255; }
+}  // namespace
 
 extern "C" {
 
@@ -186,11 +228,20 @@ int wv_stft_plan_create(int n_fft, const float* basis_or_null, wv_stft_plan** ou
     p->n_fft = n_fft;
     wv::pack_stft_basis(basis.data(), n_fft, bt, side, &p->Mp);
     const std::vector<float> bq = wv::pack_stft_q(bt, n_fft, p->Mp);
+    const int F = n_fft / 2 + 1, M2 = 2 * F;
+    const int Mp_f = wv::round_up(M2, wv::M_ALIGN), Kp_f = wv::round_up(n_fft, wv::BK);
+    const int Mp_b = wv::round_up(n_fft, wv::M_ALIGN), Kp_b = wv::round_up(M2, wv::BK);
+    std::vector<float> wf((size_t)Kp_f * Mp_f, 0.f), wb((size_t)Kp_b * Mp_b, 0.f);
+    for (int m = 0; m < M2; ++m)
+        for (int n = 0; n < n_fft; ++n) {
+            wf[(size_t)n * Mp_f + m] = basis[(size_t)m * n_fft + n];
+            wb[(size_t)m * Mp_b + n] = basis[(size_t)m * n_fft + n];
+        }
     auto up = [](float** d, const std::vector<float>& v) {
         return hipMalloc((void**)d, v.size() * sizeof(float)) == hipSuccess &&
                hipMemcpy(*d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     };
-    if (!(up(&p->basis_t, bt) && up(&p->basis_q, bq) && up(&p->side, side))) { delete p; return WV_EHIP; }
+    if (!(up(&p->basis_t, bt) && up(&p->basis_q, bq) && up(&p->side, side) && up(&p->wt_fwd, wf) && up(&p->wt_bwd, wb))) { delete p; return WV_EHIP; }
     *out = p;
     return WV_OK;
 }
@@ -204,6 +255,36 @@ int wv_stft_plan_logmag(const wv_stft_plan* p, const float* wav, float* P, int B
     a.n_fft = p->n_fft; a.hop = hop; a.F = p->n_fft / 2 + 1; a.Mp = p->Mp; a.mean = mean; a.inv_std = 1.f / std;
     const hipError_t e = wv::launch_stft_logmag(a, (hipStream_t)stream);
     return e == hipSuccess ? WV_OK : (e == hipErrorInvalidValue ? WV_EINVAL : WV_EHIP);
+}
+
+size_t wv_stft_plan_backward_workspace_bytes(const wv_stft_plan* p, int B, int T, int hop) {
+    if (!p || B < 1 || T < 1 || hop < 1) return 0;
+    const int Tf = (T + hop - 1) / hop, F = p->n_fft / 2 + 1;
+    return al256o((size_t)B * p->n_fft * Tf * 4) + al256o((size_t)B * 2 * F * Tf * 4);
+}
+
+int wv_stft_plan_backward(const wv_stft_plan* p, const float* wav, const float* dP, float* dwav, int accumulate, int B, int T, int hop, float std,
+                          void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !wav || !dP || !dwav || B < 1 || T < 1 || hop < 1 || !(std > 0.f) || B > 65535) return WV_EINVAL;
+    if (!ws || ws_bytes < wv_stft_plan_backward_workspace_bytes(p, B, T, hop)) return WV_ENOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = p->n_fft, F = n / 2 + 1, Tf = (T + hop - 1) / hop;
+    float* X = (float*)ws;
+    float* Cm = (float*)((char*)ws + al256o((size_t)B * n * Tf * 4));
+    hipLaunchKernelGGL(stft_frames_kernel, dim3((Tf + 255) / 256, n, B), dim3(256), 0, s, wav, X, T, Tf, n, hop);
+    auto gemm = [&](const float* Xin, int M, int K, const float* wt, float* Y) {
+        wv::DwPwArgs a{};
+        a.X = Xin; a.pw.M = M; a.pw.K = K; a.pw.Mp = wv::round_up(M, wv::M_ALIGN); a.pw.Kp = wv::round_up(K, wv::BK); a.pw.wt = wt; a.pw.wq = nullptr;
+        a.bias = nullptr; a.Y = Y; a.B = B; a.Tin = Tf; a.Tout = Tf; a.mode = 0; a.ks = 1; a.pre_scale = 1.f; a.pre_elu = 0; a.l2norm = 0; a.out_scale = 1.f;
+        return wv::launch_dw_pw(a, s);
+    };
+    hipError_t e = gemm(X, 2 * F, n, p->wt_fwd, Cm);
+    if (e != hipSuccess) return WV_EHIP;
+    hipLaunchKernelGGL(stft_dc_kernel, dim3((Tf + 255) / 256, F, B), dim3(256), 0, s, Cm, dP, F, Tf, 1.f / std);
+    e = gemm(Cm, n, 2 * F, p->wt_bwd, X);                          // Q into the frames buffer
+    if (e != hipSuccess) return WV_EHIP;
+    hipLaunchKernelGGL(stft_overlap_add_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, X, dwav, T, Tf, n, hop, accumulate);
+    return hipGetLastError() == hipSuccess ? WV_OK : WV_EHIP;
 }
 
 int wv_op_conv_pre(const float* x, const float* w, const float* bias, float* Y, int B, int C, int T,

@@ -977,7 +977,8 @@ int wv_train_convpre_backward(wv_train_convpre* h, const float* x, const float* 
 // ---- SpecBlock add: y = x + s * (W(g,v)[C,F] @ P[B,F,T]),  s = res_scale * scale_param[0] (seanet.py:463-511) ----------------
 struct wv_train_spec {
     int C = 0, F = 0, Mp = 0;
-    float *w = nullptr, *inv = nullptr, *wq = nullptr, *wt = nullptr, *dW = nullptr, *id_taps = nullptr;
+    float *w = nullptr, *inv = nullptr, *wq = nullptr, *wt = nullptr, *wqT = nullptr, *wtT = nullptr, *dW = nullptr, *id_taps = nullptr;
+    int KpT = 0;
     std::vector<void*> owned;
     ~wv_train_spec() { for (void* p : owned) (void)hipFree(p); }
 };
@@ -985,15 +986,17 @@ struct wv_train_spec {
 int wv_train_spec_create(int C, int F, wv_train_spec** out) {
     if (!out || C < 1 || C > 4096 || F < 1 || F > 4096) return tfail(WV_EINVAL, "bad channel count");
     auto* h = new wv_train_spec();
-    h->C = C; h->F = F; h->Mp = wv::round_up(C, wv::M_ALIGN);
+    h->C = C; h->F = F; h->Mp = wv::round_up(C, wv::M_ALIGN); h->KpT = wv::round_up(F, wv::M_ALIGN);
     auto alloc = [&](float** p, size_t n, bool zero) {
         if (hipMalloc((void**)p, n * sizeof(float)) != hipSuccess) return false;
         h->owned.push_back(*p);
         return !zero || hipMemset(*p, 0, n * sizeof(float)) == hipSuccess;
     };
-    std::vector<float> taps((size_t)C * 5, 0.f);
-    for (int m = 0; m < C; ++m) taps[(size_t)m * 5 + 4] = 1.f;
-    bool ok = alloc(&h->w, (size_t)C * F, false) && alloc(&h->inv, C, false) && alloc(&h->wq, (size_t)wv::round_up(F, 32) * h->Mp, true) &&
+    const int R = std::max(C, F);
+    std::vector<float> taps((size_t)R * 5, 0.f);
+    for (int m = 0; m < R; ++m) taps[(size_t)m * 5 + 4] = 1.f;
+    bool ok = alloc(&h->wqT, (size_t)wv::round_up(C, 32) * h->KpT, true) && alloc(&h->wtT, (size_t)wv::round_up(C, wv::BK) * h->KpT, true) &&
+              alloc(&h->w, (size_t)C * F, false) && alloc(&h->inv, C, false) && alloc(&h->wq, (size_t)wv::round_up(F, 32) * h->Mp, true) &&
               alloc(&h->wt, (size_t)wv::round_up(F, wv::BK) * h->Mp, true) && alloc(&h->dW, (size_t)C * F, false) && alloc(&h->id_taps, taps.size(), false) &&
               hipMemcpy(h->id_taps, taps.data(), taps.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { delete h; return tfail(WV_EHIP, "device allocation failed"); }
@@ -1023,7 +1026,7 @@ int wv_train_spec_forward(wv_train_spec* h, const float* x, const float* P, cons
 }
 
 int wv_train_spec_backward(wv_train_spec* h, const float* P, const float* g, const float* v, const float* scale_param, float res_scale,
-                           const float* dy, float* dg, float* dv, float* d_scale_param, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+                           const float* dy, float* dg, float* dv, float* d_scale_param, float* dP, int B, int T, void* ws, size_t ws_bytes, void* stream) {
     if (!h || !P || !g || !v || !dy || !dg || !dv) return tfail(WV_EINVAL, "null argument");
     if (scale_param && !d_scale_param) return tfail(WV_EINVAL, "scale_param without a gradient slot");
     if (B < 1 || T < 1 || !ws || ws_bytes < wv_train_spec_workspace_bytes(h, B, T)) return tfail(WV_ENOMEM, "workspace too small");
@@ -1032,8 +1035,18 @@ int wv_train_spec_backward(wv_train_spec* h, const float* P, const float* g, con
     const NtPlan np_ = nt_plan(B, T, C, F);
     const int S = np_.S;
     const size_t n = (size_t)C * F;
-    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(C), dim3(256), 0, s, g, v, h->w, h->inv, (float*)nullptr, (float*)nullptr, C, F, 0, 0,
-                       (const float*)nullptr, 1.f);
+    // plain W for the parameter gradients; (s W)^T packs when the gradient towards the features is wanted
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(C), dim3(256), 0, s, g, v, h->w, h->inv, (float*)nullptr, dP ? h->wqT : (float*)nullptr, C, F, 0, h->KpT,
+                       scale_param, res_scale, (float*)nullptr, dP ? h->wtT : (float*)nullptr);
+    if (dP) {                                                   // dP = (s W)^T @ dy
+        T_LAUNCH(hipGetLastError());
+        wv::PwDwArgs t{};
+        t.X = dy; t.pw.M = F; t.pw.K = C; t.pw.Mp = h->KpT; t.pw.Kp = wv::round_up(C, wv::BK); t.pw.wq = h->wqT; t.pw.wt = h->wtT;
+        t.dw_w = h->id_taps; t.dw_b = nullptr; t.Y = dP;
+        t.B = B; t.Tin = T; t.Tout = T; t.ks = 5; t.stride = 1; t.dil = 1; t.pad = 4;
+        t.pre_scale = 1.f; t.pre_elu = 0; t.out_scale = 1.f; t.bands = 1; t.film_stride = 2;
+        T_LAUNCH(wv::launch_pw_dw(t, s));
+    }
     // G = sum_{b,t} dy P^T;  d scale_param = res_scale * <W, G>  (= res_scale * sum dy . (W @ P));  dW = s * G
     hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((C + 63) / 64, (F + 63) / 64, S), dim3(256), 0, s, dy, P, (float*)ws, 1.f, 0, B, C, F, T, np_.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws, h->dW, S, n);

@@ -176,6 +176,15 @@ class StftFeatures(_Handle):
             raise RuntimeError("wv_stft_plan_logmag failed")
         return P
 
+    def backward(self, wav: torch.Tensor, dP: torch.Tensor, dwav: torch.Tensor, accumulate: bool = True) -> None:
+        """dwav (+)= the gradient of <dP, features(wav)> towards the audio."""
+        wav, dP = _f(wav), _f(dP)
+        B, T = wav.shape[0], wav.shape[-1]
+        ws = torch.empty(int(self._lib.wv_stft_plan_backward_workspace_bytes(self._h, B, T, self.hop)), dtype=torch.uint8, device=wav.device)
+        if self._lib.wv_stft_plan_backward(self._h, wav.data_ptr(), dP.data_ptr(), dwav.data_ptr(), int(accumulate), B, T, self.hop, self.std,
+                                           ws.data_ptr(), ws.numel(), TrainHalf._stream()) != 0:
+            raise RuntimeError("wv_stft_plan_backward failed")
+
 
 class TrainConvPre(_Handle):
     """conv_pre with live weight norm (/root/reference/modules/seanet.py:657-664): Scale(1/wav_std) -> causal SConv1d(1, C, ks).
@@ -228,17 +237,18 @@ class TrainSpecAdd(_Handle):
                                                     TrainHalf._stream()), "wv_train_spec_forward")
         return y
 
-    def backward(self, P, p, scale_param, res_scale: float, dy):
+    def backward(self, P, p, scale_param, res_scale: float, dy, need_dP: bool = False):
         P, dy = _f(P), _f(dy)
         B, _, T = dy.shape
         g, v = _f(p["g"]).reshape(self.C), _f(p["v"]).reshape(self.C, self.F)
         sp = None if scale_param is None else _f(scale_param).reshape(1)
-        out = dict(dg=torch.empty_like(g), dv=torch.empty_like(v), d_scale_param=None if sp is None else torch.empty(1, device=dy.device))
+        out = dict(dg=torch.empty_like(g), dv=torch.empty_like(v), d_scale_param=None if sp is None else torch.empty(1, device=dy.device),
+                   dP=torch.empty_like(P) if need_dP else None)
         ws = torch.empty(int(self._lib.wv_train_spec_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=dy.device)
         self._check(self._lib.wv_train_spec_backward(
             self._h, P.data_ptr(), g.data_ptr(), v.data_ptr(), None if sp is None else sp.data_ptr(), float(res_scale), dy.data_ptr(),
-            out["dg"].data_ptr(), out["dv"].data_ptr(), None if sp is None else out["d_scale_param"].data_ptr(), B, T, ws.data_ptr(),
-            ws.numel(), TrainHalf._stream()), "wv_train_spec_backward")
+            out["dg"].data_ptr(), out["dv"].data_ptr(), None if sp is None else out["d_scale_param"].data_ptr(),
+            out["dP"].data_ptr() if need_dP else None, B, T, ws.data_ptr(), ws.numel(), TrainHalf._stream()), "wv_train_spec_backward")
         return out
 
 
@@ -760,7 +770,8 @@ class _NetTrainer:
         return self.conv_post.forward(h, self._post_p())
 
     def encoder_backward(self, dz: torch.Tensor, need_dx: bool = False):
-        """(The spectrogram branches' gradient towards the audio is not part of dx yet: the STFT has no backward here.)"""
+        """Fills the encoder's gradients; with need_dx returns dL/d(audio): through conv_pre AND through every scale's spectrogram
+        branch (SpecBlock 1x1 -> normalise -> log -> |STFT|)."""
         cfg, rs, sv = self.cfg, self.cfg.res_scale_enc, self._enc
         if sv is None:
             raise RuntimeError("backward before forward")
@@ -770,13 +781,17 @@ class _NetTrainer:
         self.gviews["encoder.conv_post.2.conv.conv.bias"].copy_(g["db"])
         dh = g["dx"]
 
-        def spec_back(unit, pre, P, dy):
+        dx_spec = torch.zeros_like(sv["x"]) if need_dx else None
+
+        def spec_back(unit, stft, pre, P, dy):
             sp, scp = self._spec_p(pre)
-            gs = unit.backward(P, sp, scp, rs, dy)
+            gs = unit.backward(P, sp, scp, rs, dy, need_dx)
             self._put(pre + ".layer", gs["dg"], gs["dv"])
             if scp is not None:
                 self.gviews[pre + ".scale_param"].copy_(gs["d_scale_param"])
-        spec_back(self.spec_post, "encoder.spec_post", sv["P_post"], dh)
+            if need_dx:
+                stft.backward(sv["x"], gs["dP"], dx_spec, True)
+        spec_back(self.spec_post, self.stft_post, "encoder.spec_post", sv["P_post"], dh)
         dfilm = torch.zeros_like(sv["film"]) if self.with_msg else None
         for s in reversed(range(len(self.scales))):
             sc, rec = self.scales[s], sv["scales"][s]
@@ -785,7 +800,7 @@ class _NetTrainer:
             gd = sc["down"].backward(rec["down_in"], self._half(f"encoder.downsample.{s}", 2, 3), self.down_scale, dh, True, True)
             self._put_half(f"encoder.downsample.{s}", 2, 3, gd)
             dh = gd["dx"]
-            spec_back(sc["spec"], f"encoder.spec_blocks.{s}", rec["P"], dh)          # the add passes dh through unchanged
+            spec_back(sc["spec"], sc["stft"], f"encoder.spec_blocks.{s}", rec["P"], dh)          # the add passes dh through unchanged
             for j in reversed(range(len(sc["blocks"]))):
                 dh = self._block_bwd(sc["blocks"][j], f"encoder.blocks.{s}.{j}", rec["blocks"][j], dh, rs)
         if self.with_msg:
@@ -796,7 +811,7 @@ class _NetTrainer:
         self._put("encoder.conv_pre.1", gp["dg"], gp["dv"])
         self.gviews["encoder.conv_pre.1.conv.conv.bias"].copy_(gp["db"])
         self._enc = None
-        return gp["dx"]
+        return gp["dx"] + dx_spec if need_dx else None
 
     def _optimizer_step(self):
         from .parallel import allreduce_mean_flat_
