@@ -368,6 +368,10 @@ int wv_train_film_apply_backward(const float* x, const float* film, const float*
 size_t wv_train_bce_workspace_bytes(void);
 int wv_train_bce_logits(const float* logits, const float* mask, const float* msg, float* loss, float* dlogits, float grad_scale,
                         int B, int Cz, int T, void* workspace, size_t workspace_bytes, void* stream);
+/* Waveform loss of the generator update (scripts/train.py:1322, audiotools L1Loss): loss = mean |a - b|, da (optional) =
+ * grad_scale * sign(a - b) / n.  Workspace: wv_train_bce_workspace_bytes(). */
+int wv_train_l1(const float* a, const float* b, float* loss, float* da, float grad_scale, size_t n, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Optimizer step over FLAT device arenas (a net's parameters / gradients / AdamW moments are contiguous; scripts/train.py:1346-1358,
  * conf/base.yml:128-130): wv_train_sumsq = sum of squares of the gradient arena (fixed-order two-stage sum; device scalar `out`);
  * wv_train_adamw = torch.nn.utils.clip_grad_norm_(max_norm) -- when grad_sumsq is given -- followed by torch.optim.AdamW's
@@ -402,6 +406,11 @@ const char* wv_train_last_error(void);
 int wv_aug_localize_sequence(const float* original, const float* watermarked, const int* plan, int nseg, int seg_len,
                              int seq_mode, int seq_a, int seq_b, int seq_c, const int* perm,
                              float* wm_out, float* orig_out, float* mask_out, int B, int C, int T, int T_out, void* stream);
+/* gradient of the augmented audio towards the watermarked input: d_wm[b,c,ts] = d_out[b,c,t] where out[t] was copied from wm[ts]
+ * (plan code 0), else 0.  inv_* = the INVERSE of the forward's sequence map (reverse and chunk swap are their own inverses; roll by a
+ * -> roll by T - a; permutation -> its inverse permutation). */
+int wv_aug_backward(const float* d_out, const int* plan, int nseg, int seg_len, int inv_mode, int inv_a, int inv_b, int inv_c, const int* inv_perm,
+                    float* d_wm, int B, int C, int T, int T_out, void* stream);
 int wv_aug_sequence(const float* in0, const float* in1, const float* in2, float* out0, float* out1, float* out2,
                     int seq_mode, int seq_a, int seq_b, int seq_c, const int* perm, int rows, int T, int T_out, void* stream);
 

@@ -89,3 +89,42 @@ def joint_decoding_loss_and_grads(cfgG, sdG, cfgD, sdD, x, msg, mask):
     loss.backward()
     return (float(loss.detach()), {k: t.grad.numpy() for k, t in G.leaf.items() if t.grad is not None},
             {k: t.grad.numpy() for k, t in D.leaf.items() if t.grad is not None}, wm.grad.numpy())
+
+
+def watermark_step_loss_and_grads(cfgG, sdG, cfgD, sdD, cfgL, sdL, x, msg, plan, seg_len, seq, lambdas):
+    """The generator-update objective of the reference's step for the losses on this path (watermarking.py:340-421, train.py:1296-1344):
+    wm = G(x, msg) + x; the localisation + sequence augmentation as a differentiable select (plan [B][nseg] codes 0 keep / 1 revert /
+    2 zero / 3 + j clip j's original; seq = (mode, a, b, c, perm, t_out) with out[t] = in[src(t)]); D and L on the augmented audio;
+    loss = l_dec DecodingLoss + l_loc LocalizationLoss + l_wav mean|wm - x|.  -> (losses dict, grads of G, D, L)."""
+    G, D, L = LiveNet(cfgG, sdG), LiveNet(cfgD, sdD), LiveNet(cfgL, sdL)
+    xt = torch.tensor(np.asarray(x), dtype=torch.float64)
+    mt = torch.tensor(np.asarray(msg), dtype=torch.float64)
+    B, _, T = xt.shape
+    wm = OTc.decoder_forward(G, OTc.encoder_forward(G, xt, mt))[..., :T] + xt
+    mode, a, b, c, perm, t_out = seq
+    t = np.arange(t_out)
+    if mode == 1:
+        src = T - 1 - t
+    elif mode == 2:
+        src = (t - a) % T
+    elif mode == 3:
+        src = np.asarray(perm)[t // a] * a + t % a
+    elif mode == 4:
+        src = np.where((t >= a) & (t < a + c), b + (t - a), np.where((t >= b) & (t < b + c), a + (t - b), t))
+    else:
+        src = t
+    src_t = torch.from_numpy(src.astype(np.int64))
+    code = torch.from_numpy(np.asarray(plan)[:, src // seg_len].astype(np.int64))[:, None, :]           # [B,1,t_out]
+    wm_s, x_s = wm[:, :, src_t], xt[:, :, src_t]
+    other = torch.clamp(code - 3, min=0)[:, 0, :]                                                        # [B,t_out]
+    x_other = torch.stack([xt[other[i], 0, src_t] for i in range(B)])[:, None, :]
+    wm_aug = torch.where(code == 0, wm_s, torch.where(code == 1, x_s, torch.where(code == 2, torch.zeros_like(x_s), x_other)))
+    mask = (code == 0).to(torch.float64)
+    dec = F.binary_cross_entropy_with_logits(logits_of(D, wm_aug), (mt.unsqueeze(2) * mask), reduction="mean")
+    loc = F.binary_cross_entropy_with_logits(logits_of(L, wm_aug), mask, reduction="mean")
+    wav = (wm - xt).abs().mean()
+    loss = lambdas["dec/loss"] * dec + lambdas["loc/loss"] * loc + lambdas["waveform/loss"] * wav
+    loss.backward()
+    g = lambda n: {k: t_.grad.numpy() for k, t_ in n.leaf.items() if t_.grad is not None}            # noqa: E731
+    return ({"loss": float(loss.detach()), "dec/loss": float(dec.detach()), "loc/loss": float(loc.detach()), "waveform/loss": float(wav.detach())},
+            g(G), g(D), g(L))

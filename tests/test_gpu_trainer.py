@@ -245,3 +245,35 @@ def test_generator_trained_through_the_detector_vs_oracle():
     G.forward(_cu(x), _cu(msg))
     G.backward(_cu(ref_dwm.astype(np.float32)))
     check_grads(G, gG, tol=1e-3)
+
+
+def test_watermark_step_vs_oracle():
+    """One whole generator-update step of the reference's loop for the losses on this path: G -> augmentation -> D, L -> weighted BCE +
+    waveform losses -> backward through D, L, the augmentation's select and G.  Losses and the gradients of all three nets against the
+    float64 oracle composed of the same pieces (the augmentation as a differentiable torch select with the SAME plan)."""
+    from waveverify_amd.train import WatermarkTrainer
+    cfgs = [default_config(k) for k in ("generator", "detector", "locator")]
+    sds = [random_state_dict(c, 0, parametrized=True) for c in cfgs]
+    rng = np.random.default_rng(8)
+    B, T = 3, 16000
+    x = (0.1 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    msg = rng.integers(0, 2, (B, 16)).astype(np.float32)
+    tr = WatermarkTrainer(cfgs[0], sds[0], cfgs[1], sds[1], cfgs[2], sds[2], lr=1e-4)
+    # gradients BEFORE the optimizer moves the parameters: take them from the arenas right after step() (AdamW does not touch .grads)
+    np.random.seed(4); torch.manual_seed(4)
+    out = tr.step(_cu(x), _cu(msg))
+    plan, seg_len, sm, _ = tr.aug.last
+    ref, gG, gD, gL = OTT.watermark_step_loss_and_grads(cfgs[0], sds[0], cfgs[1], sds[1], cfgs[2], sds[2], x, msg, plan, seg_len,
+                                                         (sm.mode, sm.a, sm.b, sm.c, sm.perm, sm.t_out), tr.lambdas)
+    for k in ("dec/loss", "loc/loss", "waveform/loss", "loss"):
+        assert abs(float(out[k].item()) - ref[k]) <= 5e-5 * abs(ref[k]), (k, float(out[k].item()), ref[k])
+    st = out["stats"]          # merged as the reference merges them: the sequence stats' 'unchanged' overrides the localisation one
+    assert abs(st["original_revert"] + st["zero_replace"] + st["cross_substitute"] - 20.0) < 1e-9
+    check_grads(tr.D, gD, tol=1e-3)
+    check_grads(tr.L, gL, tol=1e-3)
+    check_grads(tr.G, gG, tol=2e-2, loose=(("film_layers", "msg_embedding"), 2e-1))
+    # the parameters moved, and by no more than one AdamW step (lr per element, + decay)
+    for net, sd in zip((tr.G, tr.D, tr.L), sds):
+        for k in list(net.params)[:20]:
+            d = float((net.params[k].cpu() - torch.from_numpy(np.asarray(sd[k], np.float32))).abs().max())
+            assert 0.0 < d <= 1.2e-4 + 1e-6 * float(np.abs(sd[k]).max()), (k, d)

@@ -114,11 +114,13 @@ SIGNATURES = {
                                           _VP, C.c_size_t, _VP]),
     "wv_train_bce_workspace_bytes": (C.c_size_t, []),
     "wv_train_bce_logits": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_float, C.c_int, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_train_l1": (C.c_int, [_VP, _VP, _VP, _VP, C.c_float, C.c_size_t, _VP, C.c_size_t, _VP]),
     "wv_train_sumsq": (C.c_int, [_VP, C.c_size_t, _VP, _VP, C.c_size_t, _VP]),
     "wv_train_adamw": (C.c_int, [_VP, _VP, _VP, _VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                  _VP, C.c_float, _VP]),
     "wv_aug_localize_sequence": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP,
                                            _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
+    "wv_aug_backward": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "wv_aug_sequence": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP,
                                   C.c_int, C.c_int, C.c_int, _VP]),
     "wv_profile_enable": (C.c_int, [C.c_int]),

@@ -91,6 +91,39 @@ def _launch(original, watermarked, plan, seg_len, sm: SeqMap):
     return outs
 
 
+def inverse_map(sm: SeqMap, t_in: int) -> SeqMap:
+    """The map that undoes `sm` on the output axis (out[t] = in[src(t)]  <=>  t = inverse.src(ts))."""
+    if sm.mode == SEQ_ROLL:
+        return SeqMap(SEQ_ROLL, a=t_in - sm.a, t_out=sm.t_out)
+    if sm.mode == SEQ_PERMUTE:
+        inv = np.empty_like(np.asarray(sm.perm))
+        inv[np.asarray(sm.perm)] = np.arange(len(sm.perm), dtype=inv.dtype)
+        return SeqMap(SEQ_PERMUTE, a=sm.a, perm=inv, t_out=sm.t_out)
+    return SeqMap(sm.mode, sm.a, sm.b, sm.c, None, sm.t_out)          # identity, reverse, chunk swap: self-inverse
+
+
+def backward_to_watermarked(d_out: torch.Tensor, plan, seg_len: int, sm: SeqMap, t_in: int) -> torch.Tensor:
+    """Gradient of the augmented audio towards the watermarked input of `_launch` (the select passes it where the sample was kept)."""
+    lib = _lib.load()
+    d_out = _dev(d_out)
+    B, Cc, T_out = d_out.shape
+    inv = inverse_map(sm, t_in)
+    plan_d = perm_d = None
+    nseg = 0
+    if plan is not None:
+        plan = np.ascontiguousarray(plan, dtype=np.int32)
+        nseg = plan.shape[1]
+        plan_d = torch.from_numpy(plan).to(d_out.device)
+    if inv.mode == SEQ_PERMUTE:
+        perm_d = torch.from_numpy(np.ascontiguousarray(inv.perm, dtype=np.int32)).to(d_out.device)
+    d_wm = torch.empty(B, Cc, t_in, dtype=torch.float32, device=d_out.device)
+    rc = lib.wv_aug_backward(d_out.data_ptr(), plan_d.data_ptr() if plan_d is not None else None, nseg, int(seg_len), inv.mode, inv.a, inv.b, inv.c,
+                             perm_d.data_ptr() if perm_d is not None else None, d_wm.data_ptr(), B, Cc, t_in, T_out, _stream())
+    if rc != 0:
+        raise RuntimeError(f"wv_aug_backward failed ({rc})")
+    return d_wm
+
+
 def apply_sequence_map(tensors: List[Optional[torch.Tensor]], sm: SeqMap) -> List[Optional[torch.Tensor]]:
     """The sequence map alone on up to three [B,C,T] tensors (one launch)."""
     lib = _lib.load()
@@ -279,6 +312,12 @@ class TemporalAugmenter:
             raise RuntimeError(f"Failed to apply augmentation: {str(e)}") from e
         stats_seq = dict(seq._finish_stats(B))
         wm, upd, mask = _launch(original, watermarked, plan, loc.segment_length, sm)
+        self.last = (plan, loc.segment_length, sm, T)                # what backward() needs
         return Signal(wm, self.sample_rate), mask, upd, {**stats_loc, **stats_seq}
+
+    def backward(self, d_augmented: torch.Tensor) -> torch.Tensor:
+        """dL/d(watermarked) from dL/d(augmented watermarked) of the last forward."""
+        plan, seg_len, sm, T = self.last
+        return backward_to_watermarked(d_augmented, plan, seg_len, sm, T)
 
     __call__ = forward

@@ -124,6 +124,26 @@ __global__ __launch_bounds__(256) void seq_kernel(SeqArgs p) {
     }
 }
 
+// Backward of wv_aug_localize_sequence towards the WATERMARKED input: the forward is a select, so the gradient of an output sample
+// goes to the watermarked sample it was copied from and nowhere else (reverted / zeroed / substituted segments carry none; the
+// segment permutation drops the clip's tail).  inv = the inverse of the forward's sequence map (out[t] = in[src(t)] <=> t = inv.src(ts)).
+struct AugBwdArgs {
+    const float* d_out; const int* plan; float* d_wm;
+    int B, C, T, T_out, nseg, seg_len;
+    SeqMap inv;
+};
+__global__ __launch_bounds__(256) void aug_bwd_kernel(AugBwdArgs p) {
+    const int ts = blockIdx.x * 256 + threadIdx.x;
+    const int bc = blockIdx.y, b = bc / p.C;
+    if (ts >= p.T) return;
+    float g = 0.f;
+    if (ts < p.T_out || p.inv.mode != WV_SEQ_PERMUTE) {
+        const int code = p.plan ? p.plan[b * p.nseg + ts / p.seg_len] : 0;
+        if (code == 0) g = p.d_out[(size_t)bc * p.T_out + p.inv.src(ts)];
+    }
+    p.d_wm[(size_t)bc * p.T + ts] = g;
+}
+
 static bool seq_ok(int mode, int a, int b, int c, const int* perm, int T, int T_out) {
     switch (mode) {
         case WV_SEQ_IDENTITY: case WV_SEQ_REVERSE: return T_out == T;
@@ -163,6 +183,17 @@ int wv_aug_sequence(const float* in0, const float* in1, const float* in2, float*
     hipStream_t s = (hipStream_t)stream;
     wv::prof::Scope ps(s, "augment_seq", 0.0, 4.0 * rows * n * ((double)T_out * 2.0));
     hipLaunchKernelGGL(wv::seq_kernel, dim3((T_out + 1023) / 1024, rows), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? WV_OK : WV_EHIP;
+}
+
+int wv_aug_backward(const float* d_out, const int* plan, int nseg, int seg_len, int inv_mode, int inv_a, int inv_b, int inv_c, const int* inv_perm,
+                    float* d_wm, int B, int C, int T, int T_out, void* stream) {
+    if (!d_out || !d_wm || B < 1 || C < 1 || T < 1 || (long long)B * C > 65535) return WV_EINVAL;
+    if (plan && (seg_len < 1 || nseg != (T + seg_len - 1) / seg_len)) return WV_EINVAL;
+    // the inverse map runs over the OUTPUT axis: it is a map of length T_out (identity / reverse / roll / chunk swap: T_out == T)
+    if (!wv::seq_ok(inv_mode, inv_a, inv_b, inv_c, inv_perm, T_out, T_out)) return WV_EINVAL;
+    wv::AugBwdArgs a{d_out, plan, d_wm, B, C, T, T_out, nseg, plan ? seg_len : 1, wv::SeqMap{inv_mode, inv_a, inv_b, inv_c, inv_perm, T_out}};
+    hipLaunchKernelGGL(wv::aug_bwd_kernel, dim3((T + 255) / 256, B * C), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? WV_OK : WV_EHIP;
 }
 

@@ -607,6 +607,20 @@ __global__ void film_band_reduce_kernel(const float* __restrict__ rowsum, float*
     dfilm[(size_t)b * NF + s_off + band * 2 + which] = a;
 }
 
+// ---- waveform loss: mean |a - b| and its gradient towards a (audiotools L1Loss in scripts/train.py:1322; sign(0) = 0 as torch) ----
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ da,
+                                                  float* __restrict__ partial, float gscale, size_t n) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)RED_BLOCKS * 256) {
+        const float d = a[i] - b[i];
+        acc += fabsf(d);
+        if (da) da[i] = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
+    }
+    const float t = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
 // ---- optimizer step over a FLAT parameter arena (scripts/train.py:1346-1358, conf/base.yml:128-130) ------------------
 // Parameters, gradients and both AdamW moments of a net live in contiguous arenas, so gradient clipping is one
 // two-stage sum of squares and the update one launch (and the DDP buckets are plain slices of the gradient arena).
@@ -1509,6 +1523,16 @@ int wv_train_film_apply_backward(const float* x, const float* film, const float*
     const int NF = n_scales * bands * 2, so = scale * bands * 2;
     hipLaunchKernelGGL(wv::film_apply_bwd_kernel, dim3(C, B), dim3(256), 0, s, x, film, dy, dx, (float*)ws, C, T, bands, NF, so);
     hipLaunchKernelGGL(wv::film_band_reduce_kernel, dim3((B * bands * 2 + 255) / 256), dim3(256), 0, s, (const float*)ws, dfilm, B, C, bands, NF, so);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
+int wv_train_l1(const float* a, const float* b, float* loss, float* da, float grad_scale, size_t n, void* ws, size_t ws_bytes, void* stream) {
+    if (!a || !b || !loss || !n) return tfail(WV_EINVAL, "null / bad argument");
+    if (!ws || ws_bytes < wv_train_bce_workspace_bytes()) return tfail(WV_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wv::l1_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, a, b, da, (float*)ws, grad_scale / (float)n, n);
+    hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, wv::RED_BLOCKS, 1.f / (float)n, loss);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }

@@ -948,3 +948,71 @@ class GeneratorTrainer(_NetTrainer):
     def apply_gradients(self):
         """Mean all-reduce of the gradient arena over the ranks, clip_grad_norm_, AdamW, ExponentialLR (scripts/train.py:1346-1358)."""
         return self._optimizer_step()
+
+
+def l1_loss(a: torch.Tensor, b: torch.Tensor, grad_scale: float = 1.0, want_grad: bool = True):
+    """mean |a - b| (the reference's waveform loss, scripts/train.py:1322) -> (loss [1], grad_scale * dloss/da or None)."""
+    a, b = _f(a), _f(b)
+    if a.shape != b.shape:
+        raise ValueError(f"shape mismatch: {tuple(a.shape)} vs {tuple(b.shape)}")
+    lib = _lib.load()
+    loss = torch.empty(1, device=a.device)
+    da = torch.empty_like(a) if want_grad else None
+    ws = torch.empty(int(lib.wv_train_bce_workspace_bytes()), dtype=torch.uint8, device=a.device)
+    if lib.wv_train_l1(a.data_ptr(), b.data_ptr(), loss.data_ptr(), None if da is None else da.data_ptr(), float(grad_scale), a.numel(),
+                       ws.data_ptr(), ws.numel(), TrainHalf._stream()) != 0:
+        raise RuntimeError(f"wv_train_l1: {lib.wv_train_last_error().decode()}")
+    return loss, da
+
+
+class WatermarkTrainer:
+    """The generator-update step of the reference's training loop on the HIP units (/root/reference/model/watermarking.py:340-421
+    `_forward_train`, scripts/train.py:1296-1358 `_update_generator`), for the losses that live on this path:
+
+        wm = G(x, msg) + x  ->  localisation + sequence augmentation (one launch, reference RNG order)  ->  D, L on the augmented audio
+        loss = lambda_dec * DecodingLoss(D) + lambda_loc * LocalizationLoss(L) + lambda_wav * mean|wm - x|      (conf/base.yml:141-150)
+        backward through D and L to the audio (conv_pre and every spectrogram branch), through the augmentation's select, through G;
+        mean all-reduce of the three gradient arenas; clip_grad_norm_ on the GENERATOR's parameters only (train.py:1351-1353); AdamW
+        on all three nets.
+
+    Not on this path (they stay on PyTorch-ROCm): the audio effects between augmentation and detection (identity here),
+    the mel / multi-scale-STFT losses and the discriminator; `extra_d_wm` is where their gradient towards the watermarked audio enters."""
+
+    LAMBDAS = {"waveform/loss": 1000.0, "loc/loss": 100.0, "dec/loss": 10000.0}
+
+    def __init__(self, cfgG, sdG, cfgD, sdD, cfgL, sdL, lr: float = 1e-4, max_norm: float = 1000.0, sample_rate: int = 16000,
+                 window_duration: float = 0.1, device="cuda"):
+        from .augment import TemporalAugmenter
+        self.G = GeneratorTrainer(cfgG, sdG, lr, max_norm, device)
+        self.D = EncoderNetTrainer(cfgD, sdD, lr, max_norm, device)
+        self.L = EncoderNetTrainer(cfgL, sdL, lr, max_norm, device)
+        self.aug = TemporalAugmenter(sample_rate, window_duration)
+        self.lambdas = dict(self.LAMBDAS)
+
+    def step(self, x: torch.Tensor, msg: torch.Tensor, extra_d_wm: Optional[torch.Tensor] = None, augment: bool = True):
+        from .parallel import allreduce_mean_flat_
+        x, msg = _f(x), _f(msg)
+        lam = self.lambdas
+        wm = self.G.forward(x, msg)
+        if augment:
+            sig, mask, _, stats = self.aug.forward(x, wm)
+            wm_aug = sig.audio_data
+        else:
+            wm_aug, mask, stats = wm, torch.ones_like(wm), {}
+        dec, dzD = bce_logits(self.D.forward(wm_aug), mask, msg, grad_scale=lam["dec/loss"])
+        d_aug = self.D.backward(dzD, need_dx=True)
+        loc, dzL = bce_logits(self.L.forward(wm_aug), mask, None, grad_scale=lam["loc/loss"])
+        d_aug = d_aug + self.L.backward(dzL, need_dx=True)
+        d_wm = self.aug.backward(d_aug) if augment else d_aug
+        wav, d_wav = l1_loss(wm, x, grad_scale=lam["waveform/loss"])
+        d_wm = d_wm + d_wav
+        if extra_d_wm is not None:
+            d_wm = d_wm + _f(extra_d_wm)
+        self.G.backward(d_wm)
+        for net in (self.G, self.D, self.L):
+            allreduce_mean_flat_(net.grads)
+        norm = self.G.opt.step(self.G.arena, self.G.grads, self.G.max_norm)          # clipping: the generator only
+        self.D.opt.step(self.D.arena, self.D.grads, None)
+        self.L.opt.step(self.L.arena, self.L.grads, None)
+        total = lam["dec/loss"] * dec + lam["loc/loss"] * loc + lam["waveform/loss"] * wav
+        return {"loss": total, "dec/loss": dec, "loc/loss": loc, "waveform/loss": wav, "grad_norm": norm, "stats": stats}
