@@ -49,11 +49,11 @@ def parse():
     ap.add_argument("--cpu-clips", type=int, default=16, help="clips of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="embed_detect",
-                    choices=["embed_detect", "longform", "detector_stress", "grad_allreduce", "train_det_loc"],
+                    choices=["embed_detect", "longform", "detector_stress", "grad_allreduce", "train_step"],
                     help="embed_detect = BASELINE configs[1] (the headline); longform = configs[3] "
                          "(32 x 30 s, embed+locate+detect); detector_stress = configs[4] (1024 clips, detector "
-                         "only); grad_allreduce = configs[2]'s gradient exchange (no model compute); train_det_loc = the "
-                         "detector + locator part of configs[2]'s training step (64 clips per GPU) on the HIP training units")
+                         "only); grad_allreduce = configs[2]'s gradient exchange (no model compute); train_step = the "
+                         "part of configs[2]'s training step that runs on the HIP training units (G+D+L, 64 clips per GPU)")
     ap.add_argument("--bucket-mb", type=float, default=25.0, help="grad_allreduce: bucket size")
     return ap.parse_args()
 
@@ -131,28 +131,28 @@ def grad_allreduce(a, dev, dist, world, rank):
             note="bus GB/s = 2(N-1)/N * bytes / time (ring); xGMI gives one ~153 GB/s link per peer")), flush=True)
 
 
-def train_det_loc(a, dev, dist, world, rank):
-    """The detector and locator training steps of BASELINE configs[2] (64 clips x 1 s per GPU): live weight norm, forward,
-    DecodingLoss / LocalizationLoss, backward, mean all-reduce of the flat gradient arenas (RCCL when N > 1), clip + AdamW.
-    The generator / discriminator part of the reference's step is not built yet, so this is NOT the headline metric."""
+def train_step(a, dev, dist, world, rank):
+    """BASELINE configs[2] (64 clips x 1 s per GPU): the generator-update step of the reference's loop on the HIP training units
+    (waveverify_amd.train.WatermarkTrainer): G forward, one-launch augmentation, D and L forward, DecodingLoss / LocalizationLoss /
+    waveform loss, backward through D, L, the augmentation and G with live weight norm, mean all-reduce of the three flat gradient
+    arenas (RCCL when N > 1), generator-only clipping, AdamW.  The reference's step also has audio effects, mel / STFT losses and a
+    discriminator, which stay on PyTorch and are NOT in this number, so it is not the headline metric."""
     from waveverify_amd.config import default_config
     from waveverify_amd.init import random_state_dict, synthetic_clips
-    from waveverify_amd.train import EncoderNetTrainer
+    from waveverify_amd.train import WatermarkTrainer
     B = 64 if a.batch == 256 else a.batch
     T = int(round(a.seconds * 16000))
     x_np, msg_np = synthetic_clips(B, T, seed=1234 + rank)
-    rng = np.random.default_rng(99 + rank)
     x, msg = torch.from_numpy(x_np).to(dev), torch.from_numpy(msg_np.astype(np.float32)).to(dev)
-    mask = torch.from_numpy((rng.random((B, 1, T)) < 0.8).astype(np.float32)).to(dev)
-    cfgD, cfgL = default_config("detector"), default_config("locator")
-    trD = EncoderNetTrainer(cfgD, random_state_dict(cfgD, 0, parametrized=True), device=dev)
-    trL = EncoderNetTrainer(cfgL, random_state_dict(cfgL, 0, parametrized=True), device=dev)
-    losses = []
+    cfgs = [default_config(k) for k in ("generator", "detector", "locator")]
+    sds = [random_state_dict(c, 0, parametrized=True) for c in cfgs]
+    tr = WatermarkTrainer(cfgs[0], sds[0], cfgs[1], sds[1], cfgs[2], sds[2], device=dev)
+    np.random.seed(1234 + rank)
+    torch.manual_seed(1234 + rank)
+    outs = []
 
     def step():
-        ld, _ = trD.step(x, mask, msg)
-        ll, _ = trL.step(x, mask, None)
-        losses.append((ld, ll))
+        outs.append(tr.step(x, msg))
 
     for _ in range(a.warmup):
         step()
@@ -172,16 +172,17 @@ def train_det_loc(a, dev, dist, world, rank):
         elapsed = float(t.item())
     if rank == 0:
         ms = elapsed / a.steps * 1e3
-        first, last = losses[0], losses[-1]
+        pick = lambda o: {k: round(float(o[k].item()), 5) for k in ("dec/loss", "loc/loss", "waveform/loss")}       # noqa: E731
         print(json.dumps(dict(
-            metric="clips/sec detector+locator training step, 1s@16kHz bs=64 per GPU", value=round(world * B * a.steps / elapsed, 2),
-            unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
-            vs_baseline=None, dtype="f32", data="synthetic",
-            config=dict(workload=f"train_det_loc: detector + locator training steps of BASELINE.json configs[2] ({B} clips x {a.seconds:g} s per GPU); "
-                                 "generator / discriminator steps not built", batch_per_gpu=B, global_batch=B * world, clip_samples=T,
-                        parallelism=f"dp{world} (flat gradient arenas, bucketed mean all-reduce)",
-                        parameters=dict(detector=int(trD.arena.numel()), locator=int(trL.arena.numel()))),
-            loss_first=[round(float(v.item()), 5) for v in first], loss_last=[round(float(v.item()), 5) for v in last],
+            metric="clips/sec training step (generator update: G+D+L forward/backward, BCE + waveform losses), 1s@16kHz bs=64 per GPU",
+            value=round(world * B * a.steps / elapsed, 2), unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+            ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload=f"train_step: BASELINE.json configs[2] per-GPU batch ({B} clips x {a.seconds:g} s); the part of the reference's "
+                                 "generator update that runs on the HIP training units (no audio effects, mel/STFT losses or discriminator)",
+                        batch_per_gpu=B, global_batch=B * world, clip_samples=T,
+                        parallelism=f"dp{world} (three flat gradient arenas, bucketed mean all-reduce)",
+                        parameters=dict(generator=int(tr.G.arena.numel()), detector=int(tr.D.arena.numel()), locator=int(tr.L.arena.numel()))),
+            losses_first=pick(outs[0]), losses_last=pick(outs[-1]),
             note="first correct version of the backward path (recompute-based, unfused); no roofline claim")), flush=True)
 
 
@@ -199,8 +200,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)          # RCCL; used for barrier + MAX only (embed/detect)
         world = dist.get_world_size()                            # n_gpus is what RCCL reports
-    if a.workload in ("grad_allreduce", "train_det_loc"):
-        (grad_allreduce if a.workload == "grad_allreduce" else train_det_loc)(a, dev, dist, world, rank)
+    if a.workload in ("grad_allreduce", "train_step"):
+        (grad_allreduce if a.workload == "grad_allreduce" else train_step)(a, dev, dist, world, rank)
         if dist:
             dist.destroy_process_group()
         return
