@@ -187,55 +187,106 @@ __global__ void elu_bwd_tail_kernel(const float* da, const float* x, float* dx, 
     dx[i] = da[i] * (z > 0.f ? 1.f : __expf(z)) * s;
 }
 
-// ---- dW = sum_{b,t} dh[b,m,t] * ELU(s x[b,k,t]) -----------------------------------------------------------------
-// "NT" GEMM: both operands contract over their contiguous time axis.  Workgroup = 4 waves = a 64 x 64 tile of dW,
-// one 32 x 32 block per wave; (clip, time chunk) items are dealt round-robin to the gridDim.z splits.  Per step 64 time samples of 64
-// rows of each operand are staged in LDS with coalesced 16-byte row loads ([row][t], row stride 65 floats so that the
-// 32 lanes of a fragment read -- same t, consecutive rows -- hit 32 banks), the ELU of the second operand is applied
-// on the way in.  part[split][M][K] partial sums; a fixed-order pass adds the splits.
+// ---- dW = sum_{b,t} dh[b,m,t] * act(s x[b,k,t]) -----------------------------------------------------------------
+// "NT" GEMM: both operands contract over their contiguous time axis.  Workgroup = 4 waves = a (64 RB) x (64 RB) tile of dW, each wave
+// RB x RB blocks of 32 x 32 (RB = 2: 64 accumulator registers; every LDS operand read then feeds two MFMAs).  Per step 32 time samples
+// of the tile's rows of both operands are staged in LDS ([row][t], row stride 33 floats: the 32 lanes of a fragment read -- same t,
+// consecutive rows -- hit 32 banks) from 16-byte global loads that are issued one step ahead of the matrix work; the activation of
+// the second operand is applied on the way in.  (clip, time chunk) items are dealt round-robin to the gridDim.z splits;
+// part[split][M][K] partial sums, a fixed-order pass adds the splits.
+template <int RB>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ dh, const float* __restrict__ x,
                                                       float* __restrict__ part, float s, int elu, int B, int M, int K, int T, int TC) {
-    constexpr int LD = 65;
-    __shared__ float As[64 * LD], Bs[64 * LD];
-    const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 64, split = blockIdx.z, S = gridDim.z;
+    constexpr int TS = 32, LD = TS + 1, ROWS = 64 * RB, NV = ROWS * TS / 4 / 256;      // float4 loads per thread and operand
+    __shared__ float As[ROWS * LD], Bs[ROWS * LD];
+    const int m0 = blockIdx.x * ROWS, k0 = blockIdx.y * ROWS, split = blockIdx.z, S = gridDim.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wk = wave & 1;
     const int i31 = lane & 31, hh = lane >> 5;
-    f32x16 acc;
+    const bool vec = (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    f32x16 acc[RB][RB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int lr = tid >> 2, lc = (tid & 3) * 16;              // loader: row lr (0..63), 16 consecutive t from lc
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[NV], rb[NV];
+    auto fetch = [&](const float* dhb, const float* xb, int t0, int te) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + v * 256, row = idx / (TS / 4), t = t0 + (idx % (TS / 4)) * 4;
+            f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+            if (vec && t + 3 < te) {
+                if (m0 + row < M) a4 = *reinterpret_cast<const f32x4*>(dhb + (size_t)(m0 + row) * T + t);
+                if (k0 + row < K) b4 = *reinterpret_cast<const f32x4*>(xb + (size_t)(k0 + row) * T + t);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (t + e < te) {
+                        if (m0 + row < M) a4[e] = dhb[(size_t)(m0 + row) * T + t + e];
+                        if (k0 + row < K) b4[e] = xb[(size_t)(k0 + row) * T + t + e];
+                    }
+            }
+            ra[v] = a4; rb[v] = b4;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + v * 256, row = idx / (TS / 4), c = (idx % (TS / 4)) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                As[row * LD + c + e] = ra[v][e];
+                const float xv = rb[v][e] * s;
+                Bs[row * LD + c + e] = (!elu || xv > 0.f) ? xv : (__expf(xv) - 1.f);     // act(0) = 0 keeps the padding neutral
+            }
+        }
+    };
     const int nch = (T + TC - 1) / TC;                         // work items = (clip, TC-sample time chunk), dealt round-robin to the splits
     for (int item = split; item < B * nch; item += S) {
         const int b = item / nch, tb = (item - b * nch) * TC, te = min(T, tb + TC);
         const float* dhb = dh + (size_t)b * M * T;
         const float* xb = x + (size_t)b * K * T;
-        for (int t0 = tb; t0 < te; t0 += 64) {
+        fetch(dhb, xb, tb, te);
+        for (int t0 = tb; t0 < te; t0 += TS) {
+            __syncthreads();                                       // the previous step's fragments have been read
+            commit();
             __syncthreads();
+            if (t0 + TS < te) fetch(dhb, xb, t0 + TS, te);          // next step's loads fly under this step's MFMAs
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int t = t0 + lc + q;
-                const bool tv = t < te;
-                As[lr * LD + lc + q] = (tv && m0 + lr < M) ? dhb[(size_t)(m0 + lr) * T + t] : 0.f;
-                float xv = (tv && k0 + lr < K) ? xb[(size_t)(k0 + lr) * T + t] : 0.f;
-                xv *= s;
-                Bs[lr * LD + lc + q] = (!elu || xv > 0.f) ? xv : (__expf(xv) - 1.f);     // ELU(0) = 0 keeps the padding neutral
-            }
-            __syncthreads();
+            for (int kk = 0; kk < TS; kk += 2) {
+                float av[RB], bv[RB];
 #pragma unroll
-            for (int kk = 0; kk < 64; kk += 2) {
-                const float a = As[(32 * wm + i31) * LD + kk + hh];
-                const float bq = Bs[(32 * wk + i31) * LD + kk + hh];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+                for (int i = 0; i < RB; ++i) av[i] = As[(32 * (RB * wm + i) + i31) * LD + kk + hh];
+#pragma unroll
+                for (int j = 0; j < RB; ++j) bv[j] = Bs[(32 * (RB * wk + j) + i31) * LD + kk + hh];
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
         }
     }
     float* P = part + (size_t)split * M * K;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hh, k = k0 + 32 * wk + i31;
-        if (m < M && k < K) P[(size_t)m * K + k] = acc[r];
-    }
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * (RB * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * hh, k = k0 + 32 * (RB * wk + j) + i31;
+                if (m < M && k < K) P[(size_t)m * K + k] = acc[i][j][r];
+            }
+}
+
+// tile edge: 128 when both dimensions fill it, else 64
+static int nt_tile(int M, int K) { return (M > 64 && K > 64) ? 128 : 64; }
+static void launch_gemm_nt(hipStream_t st, const float* dh, const float* x, float* part, float s, int elu, int B, int M, int K, int T, int S, int TC) {
+    if (nt_tile(M, K) == 128)
+        hipLaunchKernelGGL((gemm_nt_kernel<2>), dim3((M + 127) / 128, (K + 127) / 128, S), dim3(256), 0, st, dh, x, part, s, elu, B, M, K, T, TC);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<1>), dim3((M + 63) / 64, (K + 63) / 64, S), dim3(256), 0, st, dh, x, part, s, elu, B, M, K, T, TC);
 }
 
 // ---- residual block glue: y = x + s * v;  dv = s * dy and sum(dy * v);  dx += dy ---------------------------------
@@ -728,7 +779,8 @@ void wv_train_half_destroy(wv_train_unit* h) { delete h; }
 // a 64 MB scratch; a function of the shapes only, so the summation order -- and the result -- is reproducible
 struct NtPlan { int S, TC; };
 static NtPlan nt_plan(int B, int T, int M, int K) {
-    const long long tiles = (long long)((M + 63) / 64) * ((K + 63) / 64);
+    const int te = (M > 64 && K > 64) ? 128 : 64;
+    const long long tiles = (long long)((M + te - 1) / te) * ((K + te - 1) / te);
     const int TC = 512;
     const long long items = (long long)B * ((T + TC - 1) / TC);
     long long S = std::min<long long>(items, std::max<long long>(1, 2048 / tiles));
@@ -826,7 +878,7 @@ int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, 
     // dW = sum dh a^T, then the weight-norm backward
     const NtPlan np_ = nt_plan(B, Tin, M, K);
     const int S = np_.S;
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((M + 63) / 64, (K + 63) / 64, S), dim3(256), 0, s, DH, x, parts, pre_scale, pre_elu, B, M, K, Tin, np_.TC);
+    wv::launch_gemm_nt(s, DH, x, parts, pre_scale, pre_elu, B, M, K, Tin, S, np_.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)M * K + 255) / 256)), dim3(256), 0, s, parts, h->dW, S, (size_t)M * K);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(M), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, K);
     T_LAUNCH(hipGetLastError());
@@ -1062,7 +1114,7 @@ int wv_train_spec_backward(wv_train_spec* h, const float* P, const float* g, con
         T_LAUNCH(wv::launch_pw_dw(t, s));
     }
     // G = sum_{b,t} dy P^T;  d scale_param = res_scale * <W, G>  (= res_scale * sum dy . (W @ P));  dW = s * G
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((C + 63) / 64, (F + 63) / 64, S), dim3(256), 0, s, dy, P, (float*)ws, 1.f, 0, B, C, F, T, np_.TC);
+    wv::launch_gemm_nt(s, dy, P, (float*)ws, 1.f, 0, B, C, F, T, S, np_.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws, h->dW, S, n);
     if (d_scale_param) hipLaunchKernelGGL(wv::dot_small_kernel, dim3(1), dim3(256), 0, s, h->w, h->dW, n, res_scale, d_scale_param);
     hipLaunchKernelGGL(wv::scale_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dW, n, scale_param, res_scale);
@@ -1170,7 +1222,7 @@ int wv_train_convpost_backward(wv_train_convpost* h, const float* x, const float
     wv::launch_dw_bwd(s, dZ, dZ, h->junk, (float*)nullptr, partial, D, B, T, T, 1, 1, 0, 0);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((D * 2 + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)D * 2);
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((D + 255) / 256), dim3(256), 0, s, h->dwdb, h->junk, db, D, 1, 1.f);
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((D + 63) / 64, (C + 63) / 64, S), dim3(256), 0, s, dZ, H, parts, 1.f, 0, B, D, C, T, np_.TC);
+    wv::launch_gemm_nt(s, dZ, H, parts, 1.f, 0, B, D, C, T, S, np_.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)D * C + 255) / 256)), dim3(256), 0, s, parts, h->dW, S, (size_t)D * C);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(D), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, C);
     T_LAUNCH(hipGetLastError());
@@ -1288,7 +1340,7 @@ int wv_train_head_backward(wv_train_head* h, const float* z, const float* w_rev,
     hipLaunchKernelGGL(wv::time_to_frames_kernel, dim3((unsigned)((hn + 255) / 256), B * nb), dim3(256), 0, s, dlogits, dlq, T, hop, N);
     // last layer: dw_last[k][o] = sum dlq[k] . q[o] over (b, j, n);  db_last[k] = sum dlogits
     const int S2 = np2.S;
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((nb + 63) / 64, (O + 63) / 64, S2), dim3(256), 0, s, dlq, q, parts, 1.f, 0, B, nb, O, (int)hn, np2.TC);
+    wv::launch_gemm_nt(s, dlq, q, parts, 1.f, 0, B, nb, O, (int)hn, S2, np2.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)nb * O + 255) / 256)), dim3(256), 0, s, parts, dw_last, S2, (size_t)nb * O);
     wv::launch_dw_bwd(s, dlq, dlq, h->junk, (float*)nullptr, partial, nb, B, (int)hn, (int)hn, 1, 1, 0, 0);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((nb * 2 + 255) / 256), dim3(256), 0, s, partial, h->scr, B, (size_t)nb * 2);
@@ -1302,7 +1354,7 @@ int wv_train_head_backward(wv_train_head* h, const float* z, const float* w_rev,
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((O * 2 + 255) / 256), dim3(256), 0, s, partial, h->scr, B, (size_t)O * 2);
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((O + 255) / 256), dim3(256), 0, s, h->scr, h->junk, db_rev, O, 1, 1.f);
     const int S1 = np1.S;
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((D + 63) / 64, (OH + 63) / 64, S1), dim3(256), 0, s, z, dq, parts, 1.f, 0, B, D, OH, N, np1.TC);
+    wv::launch_gemm_nt(s, z, dq, parts, 1.f, 0, B, D, OH, N, S1, np1.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)D * OH + 255) / 256)), dim3(256), 0, s, parts, dw_rev, S1, (size_t)D * OH);
     hipLaunchKernelGGL(wv::pack_wt_kernel, dim3((unsigned)(((size_t)D * OH + 255) / 256)), dim3(256), 0, s, w_rev, h->wt_dz, D, OH, wv::round_up(D, wv::M_ALIGN), 0);
     T_LAUNCH(hipGetLastError());
@@ -1395,7 +1447,7 @@ int wv_train_up_backward(wv_train_up* h, const float* x, const float* g_ct, cons
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((M * 2 + 255) / 256), dim3(256), 0, s, partial, h->scr, B, (size_t)M * 2);
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((M + 255) / 256), dim3(256), 0, s, h->scr, h->junk, db, M, 1, 1.f);
     const NtPlan np_ = nt_plan(B, Tout, M, K);
-    hipLaunchKernelGGL(wv::gemm_nt_kernel, dim3((M + 63) / 64, (K + 63) / 64, np_.S), dim3(256), 0, s, dy, U, parts, 1.f, 0, B, M, K, Tout, np_.TC);
+    wv::launch_gemm_nt(s, dy, U, parts, 1.f, 0, B, M, K, Tout, np_.S, np_.TC);
     hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)M * K + 255) / 256)), dim3(256), 0, s, parts, h->dW, np_.S, (size_t)M * K);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(M), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, K);
     T_LAUNCH(hipGetLastError());
