@@ -138,10 +138,54 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// The ResnetBlock stencil (ks = 5, stride 1, T % 4 == 0) four samples per thread: two 16-byte loads of dy give the 8 values dh[t..t+3]
+// needs, two of h the 8 values the tap sums need.
+__global__ __launch_bounds__(256) void dw_bwd51_vec_kernel(const float* __restrict__ dy, const float* __restrict__ h, const float* __restrict__ w,
+                                                            float* __restrict__ dh, float* __restrict__ partial, int M, int T) {
+    __shared__ float red[4][6];
+    const int m = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const size_t row = ((size_t)b * M + m) * T;
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy + row);
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + row);
+    const float w0 = w[m * 5], w1 = w[m * 5 + 1], w2 = w[m * 5 + 2], w3 = w[m * 5 + 3], w4 = w[m * 5 + 4];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, ab = 0.f;
+    const int n4 = T / 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int q = tid; q < n4; q += 256) {
+        const f32x4 d0 = dy4[q], d1 = q + 1 < n4 ? dy4[q + 1] : zero;       // dy[t .. t+7]
+        const f32x4 hm = q > 0 ? h4[q - 1] : zero, h0 = h4[q];                // h[t-4 .. t+3]
+        const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        const float hv[8] = {hm.x, hm.y, hm.z, hm.w, h0.x, h0.y, h0.z, h0.w};
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)                                          // dh[t+e] = sum_i w[i] dy[t+e+4-i]
+            g[e] = fmaf(w0, d[e + 4], fmaf(w1, d[e + 3], fmaf(w2, d[e + 2], fmaf(w3, d[e + 1], w4 * d[e]))));
+        reinterpret_cast<f32x4*>(dh + row)[q] = g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                        // dw[i] += dy[n] h[n-4+i], n = t+e
+            const float dn = d[e];
+            a0 = fmaf(dn, hv[e], a0); a1 = fmaf(dn, hv[e + 1], a1); a2 = fmaf(dn, hv[e + 2], a2); a3 = fmaf(dn, hv[e + 3], a3);
+            a4 = fmaf(dn, hv[e + 4], a4); ab += dn;
+        }
+    }
+    float acc[6] = {a0, a1, a2, a3, a4, ab};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float v = acc[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((tid & 63) == 0) red[tid >> 6][i] = v;
+    }
+    __syncthreads();
+    if (tid < 6) partial[((size_t)b * M + m) * 6 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 static void launch_dw_bwd(hipStream_t s, const float* dy, const float* h, const float* w, float* dh, float* partial, int M, int B, int Tin,
                           int Tout, int ks, int stride, int pad, int h_shared) {
 #define WV_DWB(K, S) hipLaunchKernelGGL((dw_bwd_kernel<K, S>), dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tin, Tout, ks, stride, pad, h_shared)
-    if (ks == 5 && stride == 1) WV_DWB(5, 1);
+    const bool al16 = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(dh)) & 15) == 0;
+    if (ks == 5 && stride == 1 && pad == 4 && dh && !h_shared && Tin == Tout && (Tin & 3) == 0 && al16)
+        hipLaunchKernelGGL(dw_bwd51_vec_kernel, dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tin);
+    else if (ks == 5 && stride == 1) WV_DWB(5, 1);
     else if (ks == 1 && stride == 1) WV_DWB(1, 1);
     else if (ks == 4 && stride == 2) WV_DWB(4, 2);
     else if (ks == 8 && stride == 4) WV_DWB(8, 4);
@@ -783,8 +827,8 @@ static NtPlan nt_plan(int B, int T, int M, int K) {
     const long long tiles = (long long)((M + te - 1) / te) * ((K + te - 1) / te);
     const int TC = 512;
     const long long items = (long long)B * ((T + TC - 1) / TC);
-    long long S = std::min<long long>(items, std::max<long long>(1, 2048 / tiles));
-    while (S > 1 && S * M * K > (16LL << 20)) S /= 2;
+    long long S = std::min<long long>(items, std::max<long long>(1, 1024 / tiles));
+    while (S > 1 && S * M * K > (4LL << 20)) S /= 2;
     return NtPlan{(int)S, TC};
 }
 static int t_out(const wv_train_unit* h, int Tin) { return (Tin + h->stride - 1) / h->stride; }
