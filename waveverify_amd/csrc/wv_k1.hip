@@ -666,10 +666,9 @@ hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
     (void)need;
     // Flattened (clip, time) tiling for the k5 stencil with a DMA'd operand (see k1_kernel): taken when it computes
     // at least 2 % fewer columns than per-clip tiles, rows are whole tiles and one tensor stays below 2 GB (32-bit
-    // buffer offsets).  WV_K1_FLAT=0 switches it off (A/B runs).
-    static const int flat_on = getenv("WV_K1_FLAT") ? atoi(getenv("WV_K1_FLAT")) : 1;
+    // buffer offsets).
     a.flat = 0;
-    if (flat_on && k5 && a.B > 1 && (a.Tout & 3) == 0) {
+    if (k5 && a.B > 1 && (a.Tout & 3) == 0) {
         int bm = 128, best = (a.pw.M + 127) / 128 * 128;
         for (int cand : {96, 64}) { const int pd = (a.pw.M + cand - 1) / cand * cand; if (pd < best) { best = pd; bm = cand; } }
         const long long Tv = a.Tout + 4;                    // the H window runs over OUTPUT times (= input times for stride 1)
@@ -1141,11 +1140,10 @@ static hipError_t rb_run(RbArgs a, hipStream_t s) {
 
 hipError_t launch_resblock(const RbArgs& a, hipStream_t s) {
     if (!rb_supported(a)) return hipErrorNotSupported;
-    static const int wide = getenv("WV_RB_WIDE") ? atoi(getenv("WV_RB_WIDE")) : 0;   // tuning knob (tools only)
-    switch (a.C) {
-        case 64: return wide ? rb_run<RB<64, 4>>(a, s) : rb_run<RB<64, 2>>(a, s);
-        case 96: return wide ? rb_run<RB<96, 4>>(a, s) : rb_run<RB<96, 2>>(a, s);
-        case 128: return wide ? rb_run<RB<128, 4>>(a, s) : rb_run<RB<128, 2>>(a, s);
+    switch (a.C) {                                                // 64-column windows: the measured better width for every C
+        case 64: return rb_run<RB<64, 2>>(a, s);
+        case 96: return rb_run<RB<96, 2>>(a, s);
+        case 128: return rb_run<RB<128, 2>>(a, s);
         default: return rb_run<RB<192, 2>>(a, s);
     }
 }

@@ -1253,9 +1253,8 @@ hipError_t launch_stft_logmag(const StftArgs& a_in, hipStream_t s) {
     a.c0 = -a.mean * a.inv_std;
     if (a.Mp % M_ALIGN || a.Mp < a.n_fft || a.n_fft < 4 || (a.n_fft & 1) || a.F != a.n_fft / 2 + 1 || !a.side)
         return hipErrorInvalidValue;
-    static const bool use_k1 = []{ const char* e = getenv("WV_STFT_K1"); return !e || atoi(e) != 0; }();
-    if (use_k1) {
-        const hipError_t e = launch_stft_k1(a, s);
+    {
+        const hipError_t e = launch_stft_k1(a, s);                 // the LDS-DMA core; not supported: <= 64 or odd frame counts
         if (e != hipErrorNotSupported) return e;
     }
     if (a.Tf <= 64) return run_stft<Tile<128, 64, 2, 2>>(a, s);

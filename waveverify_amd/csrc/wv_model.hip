@@ -484,14 +484,8 @@ WsLayout layout(const wv_model* m, int B, int T) {
 // Does a ResnetBlock of C channels want its input pre-activated by the producer (second output, one more HBM
 // write pass) or does its first unit apply scale -> ELU itself while staging through registers?  Narrow layers
 // (one m-tile: no redundant activation work, and they are bandwidth-bound) activate themselves.
-static int g_act_copy_min_c = -1;
-inline bool wants_act_copy(int C) {
-    if (g_act_copy_min_c < 0) {
-        const char* e = getenv("WV_ACT_COPY_MIN_C");
-        g_act_copy_min_c = e ? atoi(e) : 129;
-    }
-    return C >= g_act_copy_min_c;
-}
+// Measured (one box, interleaved): self-activation wins up to C = 128 (-1.8 ms/step), the producer-side copy from C = 129 up.
+inline bool wants_act_copy(int C) { return C >= 129; }
 
 struct Stream {
     float* r[2]; float* a[2]; float* u;
