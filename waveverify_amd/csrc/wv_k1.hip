@@ -310,6 +310,33 @@ struct K1Epi {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        } else if constexpr (EPI == 5) {
+            // ks = 10, stride = 5, dil = 1 (the net's r = 5 downsample): the strip form with compile-time taps -- three 16-byte reads
+            // of the row's taps and one of (bias, gamma, beta) instead of a run-time tap loop with a table read per tap
+            float* Hw = strips + wave * (4 * HLD);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* strip = Hw + (r & 1) * 2 * HLD;
+                ovec hv;
+#pragma unroll
+                for (int e = 0; e < NT; ++e) hv[e] = acc[e][r];
+                *reinterpret_cast<ovec*>(strip + half * HLD + NT * q) = hv;
+                const int row = row_of(r), gm = m0 + row;
+                const float* wt = Wl + row * WLD;
+                const f32x4 ta = *reinterpret_cast<const f32x4*>(wt), tb = *reinterpret_cast<const f32x4*>(wt + 4);
+                const f32x4 tc = *reinterpret_cast<const f32x4*>(wt + 8), td = *reinterpret_cast<const f32x4*>(wt + 16);
+                if (gm < M && q < p.tto && to0 + q < p.Tout) {
+                    const float* hp = strip + half * HLD + p.off + q * 5;
+                    float y = td.x;
+                    y = fmaf(ta.x, hp[0], y); y = fmaf(ta.y, hp[1], y); y = fmaf(ta.z, hp[2], y); y = fmaf(ta.w, hp[3], y);
+                    y = fmaf(tb.x, hp[4], y); y = fmaf(tb.y, hp[5], y); y = fmaf(tb.z, hp[6], y); y = fmaf(tb.w, hp[7], y);
+                    y = fmaf(tc.x, hp[8], y); y = fmaf(tc.y, hp[9], y);
+                    y = fmaf(y, td.y, td.z);
+                    const size_t ro = (size_t)gm * p.Tout + to0 + q;
+                    if (Yb) Yb[ro] = y;
+                    if (Ab) Ab[ro] = elu1(y * p.act_scale);
+                }
+            }
         } else if constexpr (EPI >= 2) {
             // Downsample stencil (ks = 2R, stride R, pad R; R = EPI in {2, 4, 8}; seanet.py:733-772) + FiLM, from
             // the accumulators: a lane holds H columns 4q..4q+3, the rest of an output's 2R taps sits in the
@@ -645,6 +672,7 @@ static hipError_t k1_pick_epi(const PwDwArgs& a, hipStream_t s, bool k5) {
             if (a.stride == 4) return k1_pick_ldr<C, 4, false>(a, s);
             if (a.stride == 8) return k1_pick_ldr<C, 8, false>(a, s);
         }
+        if (!res && !a.ct_w && a.dil == 1 && a.ks == 10 && a.stride == 5 && a.tto <= 32) return k1_pick_ldr<C, 5, false>(a, s);
     }
     return res ? k1_pick_ldr<C, 1, true>(a, s) : k1_pick_ldr<C, 1, false>(a, s);
 }
