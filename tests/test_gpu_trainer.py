@@ -301,3 +301,38 @@ def test_watermark_training_learns():
     assert bool(torch.isfinite(a.G.arena).all() and torch.isfinite(a.D.arena).all() and torch.isfinite(a.L.arena).all())
     first, last = np.mean(la[:3], axis=0), np.mean(la[-3:], axis=0)
     assert last[0] < first[0] and last[1] < first[1], (first, last)
+
+
+def test_watermark_step_with_effect_scheduler():
+    """The adaptive effect scheduler inside the step (watermarking.py:521-612,697-752): effects are selected for the first clips with
+    the reference's RNG call, a caller-supplied straight-through effect runs, per-clip BER / mIoU are fed back; an unsupported effect
+    without a callable is refused."""
+    from waveverify_amd.effect_scheduler import EffectScheduler
+    from waveverify_amd.metrics import BER, MIOU
+    from waveverify_amd.train import WatermarkTrainer
+    cfgs = [default_config(k) for k in ("generator", "detector", "locator")]
+    sds = [random_state_dict(c, 0, parametrized=True) for c in cfgs]
+    rng = np.random.default_rng(3)
+    x = (0.1 * rng.standard_normal((4, 1, 16000))).astype(np.float32)
+    msg = rng.integers(0, 2, (4, 16)).astype(np.float32)
+    calls = []
+
+    def halve(name, params, audio, mask):
+        calls.append((name, dict(params)))
+        return audio * params["factor"], mask
+
+    sched = EffectScheduler({"identity": {}, "amplitude_scaling": {"factor": {"choices": [0.5, 0.8]}}})
+    tr = WatermarkTrainer(cfgs[0], sds[0], cfgs[1], sds[1], cfgs[2], sds[2], effect_scheduler=sched, apply_effect=halve)
+    np.random.seed(1); torch.manual_seed(1)
+    out = tr.step(_cu(x), _cu(msg))
+    applied = out["stats"]["selected_effects"]
+    assert len(applied) == 2 and tr.effect_update_count == 2             # capped at the number of known effects (watermarking.py:537 quirk)
+    assert [c[0] for c in calls] == [str(n) for n, _ in applied if str(n) != "identity"]
+    st = sched.get_effect_statistics()
+    assert sum(v["selection_count"] for v in st.values()) == 2
+    for name, _ in applied:
+        assert st[str(name)]["ema_ber"] is not None and 0.0 <= st[str(name)]["ema_ber"] <= 1.0 and 0.0 <= st[str(name)]["ema_miou"] <= 1.0
+    assert np.isfinite(float(out["loss"].item()))
+    bad = WatermarkTrainer(cfgs[0], sds[0], cfgs[1], sds[1], cfgs[2], sds[2], effect_scheduler=EffectScheduler({"lowpass_filter": {"cutoff_freq": 3000}}))
+    with pytest.raises(NotImplementedError, match="lowpass_filter"):
+        bad.step(_cu(x), _cu(msg))

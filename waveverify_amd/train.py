@@ -981,13 +981,47 @@ class WatermarkTrainer:
     LAMBDAS = {"waveform/loss": 1000.0, "loc/loss": 100.0, "dec/loss": 10000.0}
 
     def __init__(self, cfgG, sdG, cfgD, sdD, cfgL, sdL, lr: float = 1e-4, max_norm: float = 1000.0, sample_rate: int = 16000,
-                 window_duration: float = 0.1, device="cuda"):
+                 window_duration: float = 0.1, device="cuda", effect_scheduler=None, apply_effect=None):
+        """effect_scheduler: a waveverify_amd.effect_scheduler.EffectScheduler (watermarking.py:266-271); every step then selects
+        effects as `_apply_adaptive_effects` does (watermarking.py:537: select_effects(batch size), i.e. at most one per known effect,
+        applied to the FIRST clips of the batch) and feeds per-clip BER / mIoU back (`_update_effect_metrics`, watermarking.py:697-752).
+        apply_effect(name, params, audio [1,1,T], mask [1,1,T]) -> (audio, mask) runs the non-identity effects (PyTorch side; their
+        gradient is the straight-through identity of effect_augmentation.py:462-500); without it only 'identity' can be scheduled."""
         from .augment import TemporalAugmenter
+        from .metrics import BER, MIOU
         self.G = GeneratorTrainer(cfgG, sdG, lr, max_norm, device)
         self.D = EncoderNetTrainer(cfgD, sdD, lr, max_norm, device)
         self.L = EncoderNetTrainer(cfgL, sdL, lr, max_norm, device)
         self.aug = TemporalAugmenter(sample_rate, window_duration)
         self.lambdas = dict(self.LAMBDAS)
+        self.effect_scheduler, self.apply_effect = effect_scheduler, apply_effect
+        self.ber_calculator, self.miou_calculator = BER(threshold=0.5), MIOU()
+        self.effect_update_count = 0
+
+    def _effects(self, wm_aug, mask):
+        """-> (audio, mask, effects_applied): the straight-through effects on the first clips (watermarking.py:521-612)."""
+        applied = self.effect_scheduler.select_effects(wm_aug.shape[0])
+        out = wm_aug
+        for i, (name, params) in enumerate(applied):
+            if str(name) == "identity":
+                continue
+            if self.apply_effect is None:
+                raise NotImplementedError(f"effect '{name}' was scheduled but no apply_effect callable is attached (only 'identity' runs here)")
+            if out is wm_aug:
+                out, mask = wm_aug.clone(), mask.clone()
+            a_i, m_i = self.apply_effect(str(name), params, wm_aug[i:i + 1], mask[i:i + 1])
+            if a_i.shape != wm_aug[i:i + 1].shape:
+                raise RuntimeError("apply_effect must keep the clip length (the reference adjusts lengths back, effect_augmentation.py:118-232)")
+            out[i:i + 1], mask[i:i + 1] = a_i, m_i
+        return out, mask, applied
+
+    def _update_effect_metrics(self, logits_d, logits_l, msg, mask, applied) -> None:
+        loc_bin = (logits_l > 0.5).float()                       # the RAW locator output at 0.5, as the reference does (watermarking.py:717)
+        for i, (name, params) in enumerate(applied):
+            ber = self.ber_calculator(logits_d[i:i + 1], msg[i:i + 1], mask[i:i + 1])
+            miou = self.miou_calculator(loc_bin[i:i + 1], mask[i:i + 1])
+            self.effect_scheduler.update_effect_metrics(name, params, float(ber), float(miou))
+            self.effect_update_count += 1
 
     def step(self, x: torch.Tensor, msg: torch.Tensor, extra_d_wm: Optional[torch.Tensor] = None, augment: bool = True):
         from .parallel import allreduce_mean_flat_
@@ -999,10 +1033,18 @@ class WatermarkTrainer:
             wm_aug = sig.audio_data
         else:
             wm_aug, mask, stats = wm, torch.ones_like(wm), {}
-        dec, dzD = bce_logits(self.D.forward(wm_aug), mask, msg, grad_scale=lam["dec/loss"])
+        applied = []
+        if self.effect_scheduler is not None:
+            wm_aug, mask, applied = self._effects(wm_aug, mask)
+        logits_d = self.D.forward(wm_aug)
+        dec, dzD = bce_logits(logits_d, mask, msg, grad_scale=lam["dec/loss"])
         d_aug = self.D.backward(dzD, need_dx=True)
-        loc, dzL = bce_logits(self.L.forward(wm_aug), mask, None, grad_scale=lam["loc/loss"])
+        logits_l = self.L.forward(wm_aug)
+        loc, dzL = bce_logits(logits_l, mask, None, grad_scale=lam["loc/loss"])
         d_aug = d_aug + self.L.backward(dzL, need_dx=True)
+        if applied:
+            self._update_effect_metrics(logits_d, logits_l, msg, mask, applied)
+            stats = dict(stats, selected_effects=applied)
         d_wm = self.aug.backward(d_aug) if augment else d_aug
         wav, d_wav = l1_loss(wm, x, grad_scale=lam["waveform/loss"])
         d_wm = d_wm + d_wav
