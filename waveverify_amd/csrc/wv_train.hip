@@ -1,20 +1,25 @@
-// First slice of the training step: forward AND backward of one SEANetResnetBlock
-// half with LIVE weight normalisation, on the GPU.
+// The training step on the GPU: forward AND backward of every unit of the Generator, Detector and Locator with
+// LIVE weight normalisation (modules/conv.py:47-88: g v / ||v|| recomputed every forward while training), the BCE and waveform
+// losses, gradient clipping + AdamW, behind the wv_train_* C ABI (include/waveverify_hip.h).  waveverify_amd/train.py composes the
+// units into the nets and the reference's generator-update step (model/watermarking.py:340-421, scripts/train.py:1296-1358).
 //
-//     a = ELU(s * x);  W = g_pw * v_pw / ||v_pw||;  h = W @ a                         (1x1, no bias)
-//     w = g_dw * v_dw / ||v_dw||;  y[m,t] = b[m] + sum_i w[m,i] * h[m, t - 4 + i]     (causal depth-wise k = 5)
-// Reference: modules/seanet.py:39-116 (dws_conv_block), modules/conv.py:47-88 (weight norm, recomputed every
-// forward while training), scripts/train.py:1421-1480 (where the step runs).
-//
-// What is new here (the inference library folds weight norm once on the host):
-//   * wn_fold_kernel -- the fold on the device, re-run every step: one workgroup per output channel reduces
-//     ||v||, scales, and writes the weight straight into the layouts the kernels read (the LDS-DMA core's
-//     wq[k/4][m][4] for W, the same for W^T, the row table of the stencil) plus 1/||v|| for the backward pass.
-//   * the backward pass: dh = corr(dy, w) with the bias / tap reductions (dw_bwd_kernel, deterministic two-stage
-//     sums), da = W^T @ dh on the SAME K1 kernel as the forward GEMM (W^T packed by the fold), dx = da * ELU'(sx) * s,
-//     dW = sum_{b,t} dh a^T (gemm_nt_kernel: both operands contract over their contiguous time axis; f32 MFMA, LDS
-//     staged, split over clips with a fixed-order final sum), and the weight-norm backward (wn_bwd_kernel).
-// Gradient parity against the reference's autograd: tests/test_gpu_train.py (fixtures tests/golden/grads_half_*).
+// Units (each: create / [workspace_bytes] / forward / backward; device pointers only; every reduction two-stage with a fixed order):
+//   unit      y = DW_{ks,stride}(W(g,v) @ act(s x)) + b      ResnetBlock half, encoder Downsample unit, decoder input   seanet.py:39-116,733-772
+//   block     y = x + s (half2 . half1)(pre x)               SEANetResnetBlock incl. res_scale_param                     seanet.py:245-281
+//   convpre   causal conv 1 -> C on the scaled waveform (+ dL/dx)                                                        seanet.py:657-664
+//   spec      y = x + s W @ P  (P = log-magnitude STFT features; dP for the gradient towards the audio)                  seanet.py:463-511
+//   convpost  ELU -> DW conv -> 1x1 + bias -> L2Norm                                                                     seanet.py:795-822,288-318
+//   head      ConvTranspose(k = s = hop) -> trim -> 1x1, in frame layout                                                 detector.py:209-218,304-310
+//   up        ELU -> DW ConvTranspose(2r, r) -> 1x1 + bias   decoder upsample unit                                      seanet.py:1110-1135
+//   tail      ELU -> conv C -> 1 -> wav_std -> tanh, trimmed                                                             seanet.py:1166-1204
+//   film      message MLP + FiLM heads, and the modulation on the activations                                            seanet.py:518-550,831-846,928-966
+//   bce / l1 / sumsq / adamw                                                                                            loss.py:947-1099, train.py:1322,1346-1358
+// How they are built: the forward of a unit IS the inference kernel (K1 on the LDS-DMA core, the round-1 core at ragged lengths) fed
+// by wn_fold_kernel, which folds g v / ||v|| on the device straight into the kernels' weight layouts (k-inner and K-major packs of W and
+// of W^T) and keeps 1 / ||v||.  Backward recomputes what forward did not keep, runs W^T @ dy on the same K1 kernel, the weight gradient
+// dW = sum_{b,t} dy a^T as a time-contracting MFMA GEMM (gemm_nt_kernel), the stencils' transposes as per-row kernels, and the
+// weight-norm backward (wn_bwd_kernel).  A first correct version: recompute-based and unfused.
+// Gradient parity against the reference's autograd: tests/test_gpu_train.py (units) and tests/test_gpu_trainer.py (whole nets).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
