@@ -190,6 +190,32 @@ def test_pw_dw_flat_clip_time_tiling(ops, B, C, T, mode):
     close(got, ref, what="flat tiling")
 
 
+@pytest.mark.parametrize("B,K,M,Tin", [(7, 64, 128, 400), (5, 96, 512, 400), (3, 512, 1024, 400), (16, 64, 256, 56), (2, 64, 128, 8), (9, 64, 128, 1000)])
+@pytest.mark.parametrize("mode", ["plain", "film+act"])
+def test_downsample_r8_flat_tiling(ops, B, K, M, Tin, mode):
+    """The r = 8 downsample unit (1x1 -> depth-wise k16 / stride 8 -> FiLM) with flat tiles over the padded input axis: tiles span
+    clip boundaries, every clip's junk output (the one straddling the next clip's pad) is dropped, FiLM scalars come per lane."""
+    rng = np.random.default_rng(B + K + M + Tin)
+    X = rnd(rng, B, K, Tin)
+    w_pw = rnd(rng, M, K, 1, scale=K ** -0.5)
+    w_dw = rnd(rng, M, 1, 16, scale=0.25)
+    b_dw = rnd(rng, M, scale=0.1)
+    ref = O.sconv1d(O.sconv1d(X, w_pw, None), w_dw, b_dw, stride=8, groups=M)
+    kw = {}
+    if "film" in mode:
+        film = rnd(rng, B, 4, 2)
+        bw = M // 4
+        ref = ref * np.repeat(film[:, :, 0], bw, 1)[:, :, None] + np.repeat(film[:, :, 1], bw, 1)[:, :, None]
+        kw.update(film=cu(film), bands=4)
+    ref = ref.astype(np.float32)
+    if "act" in mode:
+        got, gact = ops.pw_dw(cu(X), w_pw, w_dw, b_dw, stride=8, pre_elu=False, act_scale=0.7071, **kw)
+        close(gact, O.elu(ref * np.float32(0.7071)), what="r8 flat (activated copy)")
+    else:
+        got = ops.pw_dw(cu(X), w_pw, w_dw, b_dw, stride=8, pre_elu=False, **kw)
+    close(got, ref, what="r8 flat")
+
+
 def test_pw_dw_no_prologue_no_bias(ops):
     """decoder head: 1x1 (128->1536, no bias) -> DW k5 (seanet.py:1070-1091)."""
     rng = np.random.default_rng(5)

@@ -152,6 +152,7 @@ struct K1Epi {
     bool act_lane, vec;
     const float* Rb; float* Yb; float* Ab; float* Wl;
     int voff0, nrec;                                             // EPI 0: lane's first byte offset (or an out-of-range marker), buffer size
+    float fgam, fbet;                                            // EPI 8, flat tiling: this lane's FiLM scalars
 
     __device__ __forceinline__ int row_of(int r) const { return 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half; }
     __device__ __forceinline__ ovec load_res(const PwDwArgs& p, int r) const {
@@ -218,8 +219,24 @@ struct K1Epi {
             nrec = (int)((long long)p.B * M * p.Tout * 4);
             voff0 = ok ? (int)((((long long)bo2 * M + m0 + 32 * wave + 4 * half) * p.Tout + t) * 4) : (int)0x80000000u;
         }
+        if (EPI == 8 && p.flat) {
+            // this lane's output: flat index gflat / 8 + q / 2 -> (clip, frame); FiLM scalars of that clip (the tile lies in one band)
+            const int TvO = p.Tv >> 3;
+            const long long go = gflat / 8 + (q >> 1);
+            const int bo2 = (int)(go / TvO), n = (int)(go - (long long)bo2 * TvO);
+            const bool ok = (q & 1) == 0 && (q >> 1) < p.tto && bo2 < p.B && n < p.Tout;
+            Yb = p.Y; Ab = p.Yact;
+            nrec = (int)((long long)p.B * M * p.Tout * 4);
+            voff0 = ok ? (int)((((long long)bo2 * M + m0 + 32 * wave + 4 * half) * p.Tout + n) * 4) : (int)0x80000000u;
+            fgam = 1.f; fbet = 0.f;
+            if (p.film) {
+                const float* fl = p.film + (size_t)min(bo2, p.B - 1) * p.film_stride + 2 * (m0 / (M / p.bands));
+                fgam = fl[0]; fbet = fl[1];
+            }
+        }
+        const bool lane_film = EPI == 8 && p.flat;                   // flat tiles span clips: FiLM comes per lane, the table holds (1, 0)
         const int bw = p.film ? (M / p.bands) : 1;
-        const float* filmb = p.film ? p.film + (size_t)b * p.film_stride : nullptr;
+        const float* filmb = (p.film && !lane_film) ? p.film + (size_t)b * p.film_stride : nullptr;
         for (int m = tid; m < C::BM; m += C::NTHREADS) {
             const int gm = m0 + m;
             float* row = Wl + m * WLD;
@@ -345,13 +362,14 @@ struct K1Epi {
             // the generic path (bit-identical).  Addressing and masking as in EPI 0 (range-checked buffers).
             static_assert(NT == 4 && !RES, "strided DPP epilogue: 128-column windows, no residual");
             constexpr int R = EPI;
-            const int clip_bytes = M * p.Tout * 4;
+            const bool flat = R == 8 && p.flat;
+            const int clip_bytes = flat ? nrec : M * p.Tout * 4;
             const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(Yb ? Yb : p.Yact, 0, Yb ? clip_bytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(Ab ? Ab : p.Yact, 0, Ab ? clip_bytes : 0, 0x00020000);
             const int row_bytes = p.Tout * 4;
             const int o0 = R == 2 ? 2 * q : (R == 4 ? q : q >> 1);       // first output of this lane inside the tile
             const bool lane_ok = (R != 8 || (q & 1) == 0) && o0 + (R == 2 ? 1 : 0) < p.tto && to0 + o0 + (R == 2 ? 1 : 0) < p.Tout;
-            const int voff = lane_ok ? ((m0 + 32 * wave + 4 * half) * p.Tout + to0 + o0) * 4 : 0x7f000000;
+            const int voff = flat ? voff0 : (lane_ok ? ((m0 + 32 * wave + 4 * half) * p.Tout + to0 + o0) * 4 : 0x7f000000);
             const float* Wrow = Wl + (32 * wave + 4 * half) * WLD;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -383,6 +401,7 @@ struct K1Epi {
 #pragma unroll
                     for (int i = 0; i < 2 * R; ++i) v = fmaf(w[i], hh[base + i], v);
                     y[j] = fmaf(v, bgb.y, bgb.z);
+                    if (R == 8 && flat) y[j] = fmaf(y[j], fgam, fbet);       // table holds (1, 0) then: same rounding as the one fma
                 }
                 if constexpr (R == 2) {
                     typedef unsigned u2 __attribute__((ext_vector_type(2)));
@@ -454,14 +473,17 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
     // Tv = T + pad, a multiple of 4) and tiles of tto = BN - 4 outputs run straight across the clip boundaries, so
     // the only columns computed twice are the 4 halo columns per tile and the 4 pad columns per clip: 4 % instead
     // of 9 % (T = 2000) or 12 % (T = 400, which also moves from 64- to 128-column windows).
+    // The r = 8 downsample (EPI 8; 50 outputs per clip = 3.3 tiles of 15) is flattened the same way over its INPUT axis: period
+    // Tv = Tin + 8, a multiple of 8, so a clip contributes Tv / 8 flat outputs, the last of which straddles the next clip's pad and is dropped.
+    constexpr bool FLAT_OK = EPI == 0 || EPI == 8;
     TileId tile = decode_tile(p);
-    if (EPI == 0 && p.flat) {
+    if (FLAT_OK && p.flat) {
         const unsigned L = blockIdx.x, j = L >> 3;
         tile.m_tile = j % p.num_m; tile.t_tile = (j / p.num_m) * 8 + (L & 7); tile.b = 0;
         tile.valid = tile.t_tile < p.num_t;                    // num_t = flat tile count
     }
     if (!tile.valid) return;
-    const long long gflat = (long long)tile.t_tile * p.tto;      // flat tiling: first global column of this tile
+    const long long gflat = (long long)tile.t_tile * p.tto * p.stride;      // flat tiling: first global (input) column of this tile
     f32x4* S4 = reinterpret_cast<f32x4*>(smem);
     float* table = smem + NS * C::STAGE4 * 4;
     static_assert(NS == 2 || (NS == 3 && LDR == 0), "three stages: DMA path only");
@@ -485,7 +507,7 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
     LB lb{};
     float raw[REG ? C::B_PER : 1][REG ? LB::NRAW : 1];
     if constexpr (LDR == 0) {
-        if (EPI == 0 && p.flat) db.init_flat(p.X, K, p.Tin, p.B, p.Tv, p.pad, gflat, lane);
+        if (FLAT_OK && p.flat) db.init_flat(p.X, K, p.Tin, p.B, p.Tv, p.pad, gflat, lane);
         else db.init(Xb, K, p.Tin, ti0, wave, lane);
     }
     else {
@@ -623,8 +645,8 @@ static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
     a.stagger = 0; a.first_gen = 0;
     long long n_act = (long long)a.num_t * a.B;
     if (a.flat) {                                            // flat tiles over the padded (clip, time) axis
-        if (!(EPI == 0 && C::NT == 4)) return hipErrorInvalidValue;
-        n_act = ((long long)a.B * a.Tv - a.pad + a.tto - 1) / a.tto;
+        if (!(C::NT == 4 && (EPI == 0 || (EPI == 8 && LDR == 0)))) return hipErrorInvalidValue;
+        n_act = EPI == 8 ? ((long long)a.B * (a.Tv / 8) + a.tto - 1) / a.tto : ((long long)a.B * a.Tv - a.pad + a.tto - 1) / a.tto;
         if (n_act > 0x7fffffffLL) return hipErrorInvalidValue;
         a.num_t = (int)n_act;
     }
@@ -656,7 +678,7 @@ static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
     const char* base = a.spec_add ? "spec_add" : (EPI == 0 ? (RES ? "pw_dw_k5" : "pw_dw_k5_nr") : (EPI == 1 ? "pw_dw" : "pw_dw_s"));
     if (a.pre_elu || a.pre_scale != 1.f) return k1_run<C, EPI, 1, RES>(a, s, base);
     if constexpr (C::NT == 4 && C::BM == 128) {
-        if (a.pw.K >= 256) return k1_run<C, EPI, 0, RES, 3>(a, s, base);       // matrix-bound: deeper DMA pipeline
+        if (a.pw.K >= 256) return k1_run<C, EPI, 0, RES, 3>(a, s, base);       // matrix-bound: deeper DMA pipeline (K = 128 strided stages: measured slower)
     }
     return k1_run<C, EPI, 0, RES>(a, s, base);
 }
@@ -711,6 +733,14 @@ hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
         }
     }
     if (!pw_dw_geometry(a, narrow ? 64 : 128)) return hipErrorNotSupported;
+    // the r = 8 downsample on the DMA path: flat tiles over the input axis (see k1_kernel) when that computes >= 2 % fewer columns
+    if (!narrow && !a.flat && !a.resid && !a.ct_w && a.ks == 16 && a.stride == 8 && a.dil == 1 && a.pad == 8 && a.off == 0 && a.B > 1 &&
+        a.Tin % 8 == 0 && a.Tout * 8 == a.Tin && a.pw.M % 128 == 0 && (!a.film || (a.pw.M / a.bands) % 128 == 0) && !a.pre_elu && a.pre_scale == 1.f &&
+        (long long)a.B * a.pw.M * a.Tout * 4 < 0x7fffffffLL && (long long)a.B * a.pw.K * a.Tin * 4 < 0x7fffffffLL) {
+        const long long flat_tiles = ((long long)a.B * ((a.Tin + 8) / 8) + a.tto - 1) / a.tto;
+        const long long clip_tiles = (long long)a.B * ((a.Tout + a.tto - 1) / a.tto);
+        if (flat_tiles * 100 < clip_tiles * 98) { a.flat = 1; a.Tv = a.Tin + 8; }
+    }
     // every tile's window must start on a multiple of 4 samples (16-byte DMA source addresses)
     if ((a.tto * a.stride) % 4 != 0 || (a.pad + a.off) % 4 != 0) return hipErrorNotSupported;
     // tile height: the one that pads the channel count least (128 on a tie): 192 -> 2 x 96, 64 -> 64, 130 -> 2 x 96
