@@ -144,7 +144,10 @@ struct DmaA {                           // A = packed weights wq[kq][Mp] (f32x4)
 template <class C, int EPI, bool RES>
 struct K1Epi {
     static constexpr int NT = C::NT, HLD = C::HLD;
-    static constexpr int WLD = EPI == 0 ? 8 : 20;                // row table: taps, bias, FiLM gamma, beta
+    // row table: taps (padded to a multiple of 4), then bias, FiLM gamma, beta.  The r = 2 / r = 4 stencils keep it at 8 / 12 floats per
+    // row instead of 20: with it the K <= 128 downsample stages fit a fourth workgroup per CU (36-38 KB instead of 42)
+    static constexpr int NTAP = EPI == 0 ? 5 : (EPI == 2 ? 4 : (EPI == 4 ? 8 : 16));
+    static constexpr int WLD = EPI == 0 ? 8 : NTAP + 4;
     static constexpr int TABLE_FLOATS = C::BM * WLD;
     static constexpr int RP = RES ? 4 : 0;                       // residual rows in flight per lane
     typedef typename NVec<NT>::type ovec;
@@ -240,14 +243,13 @@ struct K1Epi {
         for (int m = tid; m < C::BM; m += C::NTHREADS) {
             const int gm = m0 + m;
             float* row = Wl + m * WLD;
-            constexpr int NTAP = EPI == 0 ? 5 : 16;
 #pragma unroll
             for (int i = 0; i < NTAP; ++i) row[i] = (gm < M && i < p.ks) ? p.dw_w[(size_t)gm * p.ks + i] : 0.f;
             float gam = 1.f, bet = 0.f;
             if (filmb && gm < M) { const int band = gm / bw; gam = filmb[2 * band]; bet = filmb[2 * band + 1]; }
             row[NTAP] = (gm < M && p.dw_b) ? p.dw_b[gm] : 0.f;
             row[NTAP + 1] = gam; row[NTAP + 2] = bet;
-            if (EPI != 0) row[19] = 0.f;
+            if (EPI != 0) row[WLD - 1] = 0.f;
         }
     }
 
@@ -390,7 +392,7 @@ struct K1Epi {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(wt + i);
                     w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
                 }
-                const f32x4 bgb = *reinterpret_cast<const f32x4*>(wt + 16);   // bias, gamma, beta
+                const f32x4 bgb = *reinterpret_cast<const f32x4*>(wt + NTAP);   // bias, gamma, beta
                 const int off = voff + cr * row_bytes;
                 constexpr int NO = R == 2 ? 2 : 1;
                 float y[NO];
