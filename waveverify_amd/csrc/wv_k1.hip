@@ -680,7 +680,9 @@ static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
     const char* base = a.spec_add ? "spec_add" : (EPI == 0 ? (RES ? "pw_dw_k5" : "pw_dw_k5_nr") : (EPI == 1 ? "pw_dw" : "pw_dw_s"));
     if (a.pre_elu || a.pre_scale != 1.f) return k1_run<C, EPI, 1, RES>(a, s, base);
     if constexpr (C::NT == 4 && C::BM == 128) {
-        if (a.pw.K >= 256) return k1_run<C, EPI, 0, RES, 3>(a, s, base);       // matrix-bound: deeper DMA pipeline (K = 128 strided stages: measured slower)
+        // matrix-bound k5 units: deeper DMA pipeline.  Not the strided units: their 8-10 KB row table makes the third stage cost a resident
+        // workgroup (58 KB -> 2 per CU instead of 3 at 42 KB); measured r = 5: 1289 vs 1425 us, r = 8 (flat): 945 vs 1010 us with two stages
+        if (EPI == 0 && a.pw.K >= 256) return k1_run<C, EPI, 0, RES, 3>(a, s, base);
     }
     return k1_run<C, EPI, 0, RES>(a, s, base);
 }
