@@ -414,6 +414,17 @@ int wv_aug_backward(const float* d_out, const int* plan, int nseg, int seg_len, 
 int wv_aug_sequence(const float* in0, const float* in1, const float* in2, float* out0, float* out1, float* out2,
                     int seq_mode, int seq_a, int seq_b, int seq_c, const int* perm, int rows, int T, int T_out, void* stream);
 
+/* ---- sinc-filter / resample effects -------------------------------------------------------------
+ * A FIR filter bank over a padded signal (device pointers):  y[row][f][n] = sum_j taps[f][j] * xpad[n*stride + j], n < Tout =
+ * (T + pad_l + pad_r - L) / stride + 1; replicate = 1 pads with the edge samples (julius' filters), 0 with zeros (the polyphase resampler);
+ * interleave = 1 stores y[row][n*n_filters + f].  n_filters <= 8.  The taps are built on the host the way julius 0.2.7 / torchaudio
+ * publish them (waveverify_amd/effects.py) -- third-party arithmetic that is not in this image: parity with the libraries is UNPINNED. */
+int wv_fx_fir_bank(const float* x, const float* taps, float* y, int rows, int T, int n_filters, int L, int stride, int pad_l, int pad_r,
+                   int replicate, int interleave, void* stream);
+/* polyphase sinc resampling by orig : nw (both already divided by their gcd), torchaudio's formulation: kernels [nw][L], L = 2*width + orig;
+ * y[row][m] = sum_j kernels[m % nw][j] * xz[(m / nw)*orig + j - width] for m < Tout = ceil(nw * T / orig), xz zero outside [0,T). */
+int wv_fx_resample(const float* x, const float* kernels, float* y, int rows, int T, int orig, int nw, int L, int width, int Tout, void* stream);
+
 /* ---- measurement hook (bench.py's roofline figures) ---------------------------------------
  * When enabled, every kernel launch is bracketed by a hipEvent pair on the launch stream and
  * aggregated by "<kernel>|<role>" together with its ALGORITHMIC flops and bytes (the per-unit

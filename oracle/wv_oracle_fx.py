@@ -1,0 +1,67 @@
+"""Independent float64 restatement of the sinc-filter / resample arithmetic -- TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: julius and torchaudio are not in this image and the reference holds none of their outputs, so this file cannot be
+checked against the libraries; it restates their published algorithms a second time, differently (explicit loops / closed forms in
+float64), so that a transcription slip in waveverify_amd/effects.py or an indexing error in csrc/wv_fx.hip shows up.
+
+    julius 0.2.7 lowpass.py (LowPassFilters, lowpass_filter), filters.py (HighPassFilters, BandPassFilter)
+    torchaudio functional/functional.py (_get_sinc_resample_kernel, _apply_sinc_resample_kernel; sinc_interp_hann, width 6, rolloff 0.99)"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def lowpass_filter_taps(cutoff: float, half: int) -> np.ndarray:
+    t = np.arange(-half, half + 1, dtype=np.float64)
+    n = 2 * half + 1
+    window = 0.5 - 0.5 * np.cos(2 * math.pi * np.arange(n) / (n - 1))          # symmetric Hann (periodic=False)
+    x = 2 * cutoff * math.pi * t
+    sinc = np.ones_like(x)
+    nz = x != 0
+    sinc[nz] = np.sin(x[nz]) / x[nz]
+    f = 2 * cutoff * window * sinc
+    return f / f.sum()
+
+
+def lowpass(x: np.ndarray, cutoff: float, half=None, zeros: float = 8) -> np.ndarray:
+    half = int(zeros / cutoff / 2) if half is None else half
+    taps = lowpass_filter_taps(cutoff, half)
+    xp = np.concatenate([np.repeat(x[..., :1], half, -1), x.astype(np.float64), np.repeat(x[..., -1:], half, -1)], -1)   # replicate padding
+    T = x.shape[-1]
+    out = np.zeros(x.shape, np.float64)
+    for j in range(2 * half + 1):
+        out += taps[j] * xp[..., j:j + T]
+    return out
+
+
+def highpass(x, cutoff):
+    return x.astype(np.float64) - lowpass(x, cutoff)
+
+
+def bandpass(x, lo, hi, zeros: float = 8):
+    half = int(zeros / lo / 2)
+    return lowpass(x, hi, half) - lowpass(x, lo, half)
+
+
+def resample(x: np.ndarray, orig_freq: int, new_freq: int, width_param: int = 6, rolloff: float = 0.99) -> np.ndarray:
+    g = math.gcd(orig_freq, new_freq)
+    orig, new = orig_freq // g, new_freq // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(width_param * orig / base)
+    T = x.shape[-1]
+    t_out = int(math.ceil(new * T / orig))
+    xz = np.concatenate([np.zeros(x.shape[:-1] + (width,)), x.astype(np.float64), np.zeros(x.shape[:-1] + (width + orig,))], -1)
+    out = np.zeros(x.shape[:-1] + (t_out,), np.float64)
+    scale = base / orig
+    for m in range(t_out):
+        n, f = divmod(m, new)
+        j = np.arange(2 * width + orig)
+        # time of input sample (n*orig - width + j) relative to output m, in units of 1 / base
+        tt = np.clip((-f / new + (j - width) / orig) * base, -width_param, width_param)
+        window = np.cos(tt * math.pi / width_param / 2) ** 2
+        a = tt * math.pi
+        k = np.where(a == 0, 1.0, np.sin(a) / np.where(a == 0, 1.0, a)) * window * scale
+        out[..., m] = (xz[..., n * orig:n * orig + 2 * width + orig] * k).sum(-1)
+    return out

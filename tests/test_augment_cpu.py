@@ -160,3 +160,33 @@ def test_effect_scheduler_errors_and_edges():
     lines = []
     s.log_adaptive_behavior(lines.append)
     assert any("EFFECT SCHEDULER ADAPTIVE BEHAVIOR" in ln for ln in lines)
+
+
+# ---- sinc-filter / resample taps (host side; parity with julius / torchaudio themselves is UNPINNED: see waveverify_amd/effects.py) ----
+def test_filter_taps_and_resample_kernels_vs_second_restatement():
+    import math
+    from oracle import wv_oracle_fx as OF
+    from waveverify_amd import effects as E
+    for cutoff in (0.375, 0.0625, 0.0125):
+        taps, half = E.lowpass_taps([cutoff])
+        assert half == int(8 / cutoff / 2) and taps.shape == (1, 2 * half + 1)
+        assert np.abs(taps[0] - OF.lowpass_filter_taps(cutoff, half)).max() <= 2e-7
+        assert abs(float(taps[0].astype(np.float64).sum()) - 1.0) <= 1e-5
+    taps, half = E.lowpass_taps([0.05, 0.4])                        # band-pass bank: the lower cutoff sets the width
+    assert half == 80 and taps.shape == (2, 161)
+    with pytest.raises(ValueError, match="above 0.5"):
+        E.lowpass_taps([0.6])
+    for orig, new in ((16000, 8000), (8000, 16000), (44100, 16000), (16000, 12000)):
+        k, width, o, n = E.resample_kernels(orig, new)
+        g = math.gcd(orig, new)
+        assert (o, n) == (orig // g, new // g) and k.shape == (n, 2 * width + o)
+        assert width == math.ceil(6 * o / (min(o, n) * 0.99))
+        # an impulse through the oracle's per-output formula reads the same taps back
+        T = 4 * o
+        x = np.zeros((1, T)); x[0, 2 * o] = 1.0
+        y = OF.resample(x, orig, new)[0]
+        m = 2 * n + (n // 2)                                         # output whose window covers the impulse
+        nn, f = divmod(m, n)
+        j = 2 * o - (nn * o - width)
+        assert 0 <= j < k.shape[1] and abs(y[m] - k[f, j]) <= 2e-7
+    assert E.AudioEffects._cutoff(3000, 16000) == 0.375 and E.AudioEffects._cutoff(9000, 16000) == (8000 - 1e-5) / 8000

@@ -120,3 +120,21 @@ def test_forward_captures_into_a_hip_graph(wv):
     torch.cuda.synchronize()
     assert torch.equal(wm1, wm0) and torch.equal(p1, p0)
     assert torch.isfinite(big).all() and len(junk) == 8
+
+
+def test_load_audio_resamples_on_the_gpu(tmp_path, wv):
+    """A 44.1 kHz stereo WAV goes through the native reader, the mono mix-down and the GPU polyphase resampler (441 : 160) and comes
+    out as the float64 restatement of torchaudio's algorithm predicts (parity with the library itself is unpinned); embed() then runs."""
+    from oracle import wv_oracle_fx as OF
+    rng = np.random.default_rng(0)
+    t = np.arange(44100) / 44100.0
+    st = np.stack([0.3 * np.sin(2 * np.pi * 440 * t), 0.2 * np.sin(2 * np.pi * 1000 * t)]).astype(np.float32) + (0.01 * rng.standard_normal((2, 44100))).astype(np.float32)
+    src = str(tmp_path / "in44.wav")
+    save_audio(torch.from_numpy(st), src, 44100)
+    wav, sr = load_audio(src)
+    assert sr == 16000 and tuple(wav.shape) == (1, 16000)
+    written = np.clip(st, -1, 1).mean(0, keepdims=True)                       # float32 WAV: exact samples
+    ref = OF.resample(written, 44100, 16000)
+    assert float(np.abs(wav.numpy() - ref).max()) <= 2e-5
+    audio, sr2, _ = wv.embed(src, "1010101010101010")
+    assert sr2 == 16000 and audio.shape[-1] == 16000

@@ -336,3 +336,23 @@ def test_watermark_step_with_effect_scheduler():
     bad = WatermarkTrainer(cfgs[0], sds[0], cfgs[1], sds[1], cfgs[2], sds[2], effect_scheduler=EffectScheduler({"lowpass_filter": {"cutoff_freq": 3000}}))
     with pytest.raises(NotImplementedError, match="lowpass_filter"):
         bad.step(_cu(x), _cu(msg))
+
+
+def test_watermark_step_with_gpu_effects():
+    """The scheduler's sinc-filter / resample effects run on the GPU inside the step (waveverify_amd.effects.apply_effect as the hook)."""
+    from waveverify_amd.effect_scheduler import EffectScheduler
+    from waveverify_amd.effects import apply_effect
+    from waveverify_amd.train import WatermarkTrainer
+    cfgs = [default_config(k) for k in ("generator", "detector", "locator")]
+    sds = [random_state_dict(c, 0, parametrized=True) for c in cfgs]
+    rng = np.random.default_rng(6)
+    x = (0.1 * rng.standard_normal((4, 1, 16000))).astype(np.float32)
+    msg = rng.integers(0, 2, (4, 16)).astype(np.float32)
+    grid = {"identity": {}, "lowpass_filter": {"cutoff_freq": {"choices": [3000, 2000]}}, "highpass_filter": {"cutoff_freq": {"choices": [100, 500]}},
+            "resample": {"new_sample_rate": {"choices": [8000, 12000]}}}
+    sched = EffectScheduler(grid)
+    tr = WatermarkTrainer(cfgs[0], sds[0], cfgs[1], sds[1], cfgs[2], sds[2], effect_scheduler=sched, apply_effect=apply_effect)
+    np.random.seed(2); torch.manual_seed(2)
+    outs = [tr.step(_cu(x), _cu(msg)) for _ in range(2)]
+    assert all(np.isfinite(float(o["loss"].item())) for o in outs)
+    assert tr.effect_update_count == 8 and sum(v["selection_count"] for v in sched.get_effect_statistics().values()) == 8

@@ -123,6 +123,8 @@ SIGNATURES = {
     "wv_aug_backward": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "wv_aug_sequence": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP,
                                   C.c_int, C.c_int, C.c_int, _VP]),
+    "wv_fx_resample": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
+    "wv_fx_fir_bank": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "wv_profile_enable": (C.c_int, [C.c_int]),
     "wv_profile_reset": (C.c_int, []),
     "wv_profile_collect": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libwaveverify_hip.so")
-SOURCES = ["wv_kernels.hip", "wv_k1.hip", "wv_model.hip", "wv_ops.hip", "wv_train.hip", "wv_aug.hip"]
+SOURCES = ["wv_kernels.hip", "wv_k1.hip", "wv_model.hip", "wv_ops.hip", "wv_train.hip", "wv_aug.hip", "wv_fx.hip"]
 HEADERS = [os.path.join(CSRC, "wv_kernels.h"), os.path.join(CSRC, "wv_dev.h"),
            os.path.join(os.path.dirname(HERE), "include", "waveverify_hip.h")]
 ARCH = "gfx950"

@@ -4,8 +4,9 @@ Mirrors /root/reference/waveverify/utils.py:170-412 (load_audio, save_audio, mes
 tensor_to_message) in names, argument meaning and error behaviour.  The reference delegates file
 decoding and resampling to torchaudio, which is not part of this image: RIFF/WAV (PCM 8/16/24/32
 and IEEE float32) is read and written natively here; when torchaudio is importable it is used
-for every other container and for resampling.  Resampling arithmetic is torchaudio's (un-vendored
-third party) -> "parity unpinned" for non-16 kHz inputs; feed 16 kHz mono to avoid it.
+for every other container.  Resampling runs on the GPU (waveverify_amd/effects.py: torchaudio's
+published polyphase-sinc algorithm restated; the library itself is absent, so parity with it is
+UNPINNED for non-16 kHz inputs -- feed 16 kHz mono to stay on pinned ground).
 """
 from __future__ import annotations
 
@@ -84,8 +85,8 @@ def load_audio(audio_path: Union[str, Path], target_sr: int = DEFAULT_SAMPLE_RAT
         waveform = torch.mean(waveform, dim=0, keepdim=True)
     if sr != target_sr:
         try:
-            import torchaudio
-            waveform = torchaudio.transforms.Resample(sr, target_sr)(waveform)
+            from .effects import resample_waveform             # torchaudio.transforms.Resample's algorithm on the GPU
+            waveform = resample_waveform(waveform.float().cuda(), int(sr), int(target_sr)).cpu()
             sr = target_sr
         except Exception as e:
             raise RuntimeError(f"Cannot resample audio: {str(e)}")
