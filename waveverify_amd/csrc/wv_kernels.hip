@@ -849,6 +849,63 @@ __global__ __launch_bounds__(NT_) void tail_kernel(const float* __restrict__ H,
     }
 }
 
+// The same tail for ks = 5 and 16-byte aligned rows: a lane loads FOUR consecutive samples per channel (1 KB per wave and row instead
+// of 256 B), the four older ones come from the previous lane; a wave makes 252 outputs, a workgroup 1008.  Taps are summed in the order of
+// tail_kernel (newest sample first), so results are bit-identical.
+__global__ __launch_bounds__(NT_) void tail5_vec_kernel(const float* __restrict__ H, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ x, float* __restrict__ out, int C, int Tin, int T,
+                                                        float pre_scale, float out_scale) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int base = (blockIdx.x * 4 + wave) * 252;                  // first output time of this wave
+    const int c0 = base - 4 + 4 * lane;                              // this lane's four input times c0 .. c0 + 3 (lane 0: the halo)
+    const bool inb = c0 >= 0 && c0 + 3 < Tin;
+    const float* hb = H + (size_t)b * C * Tin + (inb ? c0 : 0);
+    float y[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ch0 = 0; ch0 < C; ch0 += 4) {                           // 4 channel rows in flight per lane
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(hb + (size_t)min(ch0 + u, C - 1) * Tin);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = ch0 + u;
+            if (c >= C) break;
+            float e[8];                                              // e[0..3] = previous lane's samples, e[4..7] = own
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float ev = 0.f;
+                if (inb) ev = elu1(v[u][k] * pre_scale);
+                else if (c0 + k >= 0 && c0 + k < Tin) ev = elu1(H[((size_t)b * C + c) * Tin + c0 + k] * pre_scale);
+                e[4 + k] = ev;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = __shfl_up(e[4 + k], 1);
+            const float* wc = w + c * 5;
+            const float w0 = wc[0], w1 = wc[1], w2 = wc[2], w3 = wc[3], w4 = wc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                            // output at time c0 + j: e[j+4] newest ... e[j] oldest
+                y[j] = fmaf(w4, e[j + 4], y[j]);
+                y[j] = fmaf(w3, e[j + 3], y[j]);
+                y[j] = fmaf(w2, e[j + 2], y[j]);
+                y[j] = fmaf(w1, e[j + 1], y[j]);
+                y[j] = fmaf(w0, e[j], y[j]);
+            }
+        }
+    }
+    if (lane >= 1) {
+        const float bv = bias ? bias[0] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = c0 + j;
+            if (t < T) {
+                float v = tanhf((y[j] + bv) * out_scale);
+                if (x) v += x[(size_t)b * T + t];
+                out[(size_t)b * T + t] = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K6  detector / locator head.  The reference's ConvTranspose1d(k = s = hop) -> trim ->
 // Conv1d(O -> nb, 1) is one GEMM per frame against the composed weight wc[D][nb*hop].
@@ -1277,6 +1334,11 @@ hipError_t launch_tail(const float* H, const float* w, const float* bias, const 
                        float* out, int B, int C, int Tin, int T, int ks, float pre_scale,
                        float out_scale, hipStream_t s) {
     if (ks < 1 || ks > 32 || T > Tin) return hipErrorInvalidValue;
+    if (ks == 5 && (Tin & 3) == 0 && (reinterpret_cast<uintptr_t>(H) & 15) == 0) {
+        prof::Scope ps(s, "tail", 2.0 * B * C * ks * (double)T, 4.0 * B * ((double)C * Tin + 2.0 * T));
+        hipLaunchKernelGGL(tail5_vec_kernel, dim3((T + 1007) / 1008, B), dim3(NT_), 0, s, H, w, bias, x, out, C, Tin, T, pre_scale, out_scale);
+        return hipGetLastError();
+    }
     const int per_block = 4 * (64 - (ks - 1));
     dim3 grid((T + per_block - 1) / per_block, B);
     prof::Scope ps(s, "tail", 2.0 * B * C * ks * (double)T, 4.0 * B * ((double)C * Tin + 2.0 * T));
