@@ -200,13 +200,29 @@ static void launch_dw_bwd(hipStream_t s, const float* dy, const float* h, const 
 #undef WV_DWB
 }
 
-// out[j] = sum_{s < S} part[s][j], fixed order (deterministic)
-__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int S, size_t n) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
+// out[j] = sum_{s < S} part[s][j], fixed order (deterministic): workgroup = 64 outputs x 16 waves, wave w adds the splits
+// w, w + 16, ... (eight loads in flight), then the 16 wave sums are added in wave order
+constexpr int SP_WAVES = 16;
+__global__ __launch_bounds__(64 * SP_WAVES) void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int S, size_t n) {
+    __shared__ float red[SP_WAVES][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t j = (size_t)blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int i = 0; i < S; ++i) s += part[(size_t)i * n + j];
-    out[j] = s;
+    if (j < n) {
+#pragma unroll 8
+        for (int i = w; i < S; i += SP_WAVES) s += part[(size_t)i * n + j];
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && j < n) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int k = 1; k < SP_WAVES; ++k) t += red[k][lane];
+        out[j] = t;
+    }
+}
+static void launch_sum_parts(hipStream_t st, const float* part, float* out, int S, size_t n) {
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SP_WAVES), 0, st, part, out, S, n);
 }
 
 // tap / bias gradient rows: dwdb[m][0..ks] -> dw_dw[m][ks] and db[m]
@@ -243,16 +259,19 @@ __global__ void elu_bwd_tail_kernel(const float* da, const float* x, float* dx, 
 // consecutive rows -- hit 32 banks) from 16-byte global loads that are issued one step ahead of the matrix work; the activation of
 // the second operand is applied on the way in.  (clip, time chunk) items are dealt round-robin to the gridDim.z splits;
 // part[split][M][K] partial sums, a fixed-order pass adds the splits.
-template <int RB>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ dh, const float* __restrict__ x,
-                                                      float* __restrict__ part, float s, int elu, int B, int M, int K, int T, int TC) {
+// VEC (T % 4 == 0, 16-byte aligned operands): the fetch has no branches -- rows past M / K are clamped (they only feed accumulator
+// rows that are never stored), a time overrun is clamped and the dh operand zeroed at the commit -- so the eight loads of a step
+// issue back to back with one wait at the commit (with per-load bounds branches the compiler waited between the loads: 0.8x).
+template <int RB, bool VEC>
+__device__ __forceinline__ void gemm_nt_body(const float* __restrict__ dh, const float* __restrict__ x, float* __restrict__ part, float s, int elu,
+                                             int B, int M, int K, int T, int TC) {
     constexpr int TS = 32, LD = TS + 1, ROWS = 64 * RB, NV = ROWS * TS / 4 / 256;      // float4 loads per thread and operand
     __shared__ float As[ROWS * LD], Bs[ROWS * LD];
     const int m0 = blockIdx.x * ROWS, k0 = blockIdx.y * ROWS, split = blockIdx.z, S = gridDim.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wk = wave & 1;
     const int i31 = lane & 31, hh = lane >> 5;
-    const bool vec = (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    const int r0 = tid >> 3, tq = (tid & 7) * 4;               // this thread's row (+ 32 v) and first sample within a step
     f32x16 acc[RB][RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i)
@@ -260,35 +279,42 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
         for (int j = 0; j < RB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    f32x4 ra[NV], rb[NV];
-    auto fetch = [&](const float* dhb, const float* xb, int t0, int te) {
+    unsigned offa[NV], offb[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int idx = tid + v * 256, row = idx / (TS / 4), t = t0 + (idx % (TS / 4)) * 4;
-            f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
-            if (vec && t + 3 < te) {
-                if (m0 + row < M) a4 = *reinterpret_cast<const f32x4*>(dhb + (size_t)(m0 + row) * T + t);
-                if (k0 + row < K) b4 = *reinterpret_cast<const f32x4*>(xb + (size_t)(k0 + row) * T + t);
-            } else {
+    for (int v = 0; v < NV; ++v) {
+        offa[v] = (unsigned)min(m0 + r0 + 32 * v, M - 1) * (unsigned)T;
+        offb[v] = (unsigned)min(k0 + r0 + 32 * v, K - 1) * (unsigned)T;
+    }
+    f32x4 ra[NV], rb[NV];
+    auto fetch = [&](const float* dhb, const float* xb, int t0, int tb, int te) {
+        if (VEC) {
+            const int t = t0 + tq, tc = t < te ? t : tb;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                ra[v] = *reinterpret_cast<const f32x4*>(dhb + offa[v] + tc);
+                rb[v] = *reinterpret_cast<const f32x4*>(xb + offb[v] + tc);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (t + e < te) {
-                        if (m0 + row < M) a4[e] = dhb[(size_t)(m0 + row) * T + t + e];
-                        if (k0 + row < K) b4[e] = xb[(size_t)(k0 + row) * T + t + e];
-                    }
+                    if (t0 + tq + e < te) { a4[e] = dhb[offa[v] + t0 + tq + e]; b4[e] = xb[offb[v] + t0 + tq + e]; }
+                ra[v] = a4; rb[v] = b4;
             }
-            ra[v] = a4; rb[v] = b4;
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int t0, int te) {
+        const float keep = (!VEC || t0 + tq < te) ? 1.f : 0.f;   // VEC: te - t0 is a multiple of 4, a float4 is all in or all out
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int idx = tid + v * 256, row = idx / (TS / 4), c = (idx % (TS / 4)) * 4;
+            const int row = r0 + 32 * v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                As[row * LD + c + e] = ra[v][e];
+                As[row * LD + tq + e] = VEC ? ra[v][e] * keep : ra[v][e];
                 const float xv = rb[v][e] * s;
-                Bs[row * LD + c + e] = (!elu || xv > 0.f) ? xv : (__expf(xv) - 1.f);     // act(0) = 0 keeps the padding neutral
+                Bs[row * LD + tq + e] = (!elu || xv > 0.f) ? xv : (__expf(xv) - 1.f);     // act(0) = 0 keeps the padding neutral
             }
         }
     };
@@ -297,12 +323,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
         const int b = item / nch, tb = (item - b * nch) * TC, te = min(T, tb + TC);
         const float* dhb = dh + (size_t)b * M * T;
         const float* xb = x + (size_t)b * K * T;
-        fetch(dhb, xb, tb, te);
+        fetch(dhb, xb, tb, tb, te);
         for (int t0 = tb; t0 < te; t0 += TS) {
             __syncthreads();                                       // the previous step's fragments have been read
-            commit();
+            commit(t0, te);
             __syncthreads();
-            if (t0 + TS < te) fetch(dhb, xb, t0 + TS, te);          // next step's loads fly under this step's MFMAs
+            if (t0 + TS < te) fetch(dhb, xb, t0 + TS, tb, te);      // next step's loads fly under this step's MFMAs
 #pragma unroll
             for (int kk = 0; kk < TS; kk += 2) {
                 float av[RB], bv[RB];
@@ -328,14 +354,33 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
                 if (m < M && k < K) P[(size_t)m * K + k] = acc[i][j][r];
             }
 }
+// four waves per SIMD (128 registers): measured 0.85x the time of the compiler's own choice (184 registers, two waves per SIMD)
+template <int RB, bool VEC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                                                                float* __restrict__ part, float s, int elu, int B, int M,
+                                                                                                int K, int T, int TC) {
+    gemm_nt_body<RB, VEC>(dh, x, part, s, elu, B, M, K, T, TC);
+}
 
-// tile edge: 128 when both dimensions fill it, else 64
-static int nt_tile(int M, int K) { return (M > 64 && K > 64) ? 128 : 64; }
-static void launch_gemm_nt(hipStream_t st, const float* dh, const float* x, float* part, float s, int elu, int B, int M, int K, int T, int S, int TC) {
-    if (nt_tile(M, K) == 128)
-        hipLaunchKernelGGL((gemm_nt_kernel<2>), dim3((M + 127) / 128, (K + 127) / 128, S), dim3(256), 0, st, dh, x, part, s, elu, B, M, K, T, TC);
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<1>), dim3((M + 63) / 64, (K + 63) / 64, S), dim3(256), 0, st, dh, x, part, s, elu, B, M, K, T, TC);
+// tile edge: 128 (two 32 x 32 blocks per wave each way) unless it pads the matrix much more than 64 does (192-row matrices: 1.8x)
+static int nt_tile(int M, int K) {
+    if (M <= 64 || K <= 64) return 64;
+    const long long p128 = (long long)((M + 127) / 128) * ((K + 127) / 128) * 128 * 128, p64 = (long long)((M + 63) / 64) * ((K + 63) / 64) * 64 * 64;
+    return p128 * 100 <= p64 * 115 ? 128 : 64;
+}
+static hipError_t launch_gemm_nt(hipStream_t st, const float* dh, const float* x, float* part, float s, int elu, int B, int M, int K, int T, int S, int TC) {
+    const bool vec = (T & 3) == 0 && (TC & 3) == 0 && ((reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    if ((long long)std::max(M, K) * T >= (1LL << 32)) return hipErrorInvalidValue;     // 32-bit row offsets within one clip
+    const int R = nt_tile(M, K);
+    const dim3 g((M + R - 1) / R, (K + R - 1) / R, S);
+    if (R == 128) {
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<2, true>), g, dim3(256), 0, st, dh, x, part, s, elu, B, M, K, T, TC);
+        else hipLaunchKernelGGL((gemm_nt_kernel<2, false>), g, dim3(256), 0, st, dh, x, part, s, elu, B, M, K, T, TC);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<1, true>), g, dim3(256), 0, st, dh, x, part, s, elu, B, M, K, T, TC);
+        else hipLaunchKernelGGL((gemm_nt_kernel<1, false>), g, dim3(256), 0, st, dh, x, part, s, elu, B, M, K, T, TC);
+    }
+    return hipGetLastError();
 }
 
 // ---- residual block glue: y = x + s * v;  dv = s * dy and sum(dy * v);  dx += dy ---------------------------------
@@ -828,12 +873,13 @@ void wv_train_half_destroy(wv_train_unit* h) { delete h; }
 // a 64 MB scratch; a function of the shapes only, so the summation order -- and the result -- is reproducible
 struct NtPlan { int S, TC; };
 static NtPlan nt_plan(int B, int T, int M, int K) {
-    const int te = (M > 64 && K > 64) ? 128 : 64;
+    const int te = wv::nt_tile(M, K);
     const long long tiles = (long long)((M + te - 1) / te) * ((K + te - 1) / te);
     const int TC = 512;
     const long long items = (long long)B * ((T + TC - 1) / TC);
     long long S = std::min<long long>(items, std::max<long long>(1, 1024 / tiles));
-    while (S > 1 && S * M * K > (4LL << 20)) S /= 2;
+    static const long long cap = [] { const char* e = getenv("WV_NT_CAP"); return (long long)(e ? atoi(e) : 32) << 20; }();
+    while (S > 1 && S * M * K > cap) S /= 2;
     return NtPlan{(int)S, TC};
 }
 static int t_out(const wv_train_unit* h, int Tin) { return (Tin + h->stride - 1) / h->stride; }
@@ -907,7 +953,7 @@ int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, 
     T_LAUNCH(wv::launch_pw_dw(a, s));
     // dh, and the per-clip partial sums of the tap / bias gradients
     wv::launch_dw_bwd(s, dy, H, h->w_dw, DH, partial, M, B, Tin, Tout, ks, h->stride, h->pad, 0);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((M * (ks + 1) + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)M * (ks + 1));
+    wv::launch_sum_parts(s, partial, h->dwdb, B, (size_t)M * (ks + 1));
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((M + 255) / 256), dim3(256), 0, s, h->dwdb, h->dw_taps, db, M, ks);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(M), dim3(256), 0, s, g_dw, v_dw, h->inv_dw, h->dw_taps, dg_dw, dv_dw, ks);
     T_LAUNCH(hipGetLastError());
@@ -927,8 +973,8 @@ int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, 
     // dW = sum dh a^T, then the weight-norm backward
     const NtPlan np_ = nt_plan(B, Tin, M, K);
     const int S = np_.S;
-    wv::launch_gemm_nt(s, DH, x, parts, pre_scale, pre_elu, B, M, K, Tin, S, np_.TC);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)M * K + 255) / 256)), dim3(256), 0, s, parts, h->dW, S, (size_t)M * K);
+    T_LAUNCH(wv::launch_gemm_nt(s, DH, x, parts, pre_scale, pre_elu, B, M, K, Tin, S, np_.TC));
+    wv::launch_sum_parts(s, parts, h->dW, S, (size_t)M * K);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(M), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, K);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
@@ -1081,7 +1127,7 @@ int wv_train_convpre_backward(wv_train_convpre* h, const float* x, const float* 
                        (const float*)nullptr, 1.f);
     // per-clip partial sums of dW[c][i] = sum_t dy[c][t] x[t - (ks-1) + i] and of db, then the fixed-order sum over clips
     wv::launch_dw_bwd(s, dy, x, h->w, (float*)nullptr, (float*)ws, C, B, T, T, ks, 1, ks - 1, 1);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((C * (ks + 1) + 255) / 256), dim3(256), 0, s, (const float*)ws, h->dwdb, B, (size_t)C * (ks + 1));
+    wv::launch_sum_parts(s, (const float*)ws, h->dwdb, B, (size_t)C * (ks + 1));
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((C + 255) / 256), dim3(256), 0, s, h->dwdb, h->taps, db, C, ks, in_scale);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g, v, h->inv, h->taps, dg, dv, ks);
     if (dx) hipLaunchKernelGGL(wv::convpre_dx_kernel, dim3((T + 255) / 256, B), dim3(256), (size_t)C * ks * 4, s, dy, h->w, dx, C, T, ks, in_scale);
@@ -1163,8 +1209,8 @@ int wv_train_spec_backward(wv_train_spec* h, const float* P, const float* g, con
         T_LAUNCH(wv::launch_pw_dw(t, s));
     }
     // G = sum_{b,t} dy P^T;  d scale_param = res_scale * <W, G>  (= res_scale * sum dy . (W @ P));  dW = s * G
-    wv::launch_gemm_nt(s, dy, P, (float*)ws, 1.f, 0, B, C, F, T, S, np_.TC);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws, h->dW, S, n);
+    T_LAUNCH(wv::launch_gemm_nt(s, dy, P, (float*)ws, 1.f, 0, B, C, F, T, S, np_.TC));
+    wv::launch_sum_parts(s, (const float*)ws, h->dW, S, n);
     if (d_scale_param) hipLaunchKernelGGL(wv::dot_small_kernel, dim3(1), dim3(256), 0, s, h->w, h->dW, n, res_scale, d_scale_param);
     hipLaunchKernelGGL(wv::scale_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dW, n, scale_param, res_scale);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g, v, h->inv, h->dW, dg, dv, F);
@@ -1269,10 +1315,10 @@ int wv_train_convpost_backward(wv_train_convpost* h, const float* x, const float
     }
     // db = sum dz (the bias slot of the row-sum kernel with one tap), dW = sum dz h^T
     wv::launch_dw_bwd(s, dZ, dZ, h->junk, (float*)nullptr, partial, D, B, T, T, 1, 1, 0, 0);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((D * 2 + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)D * 2);
+    wv::launch_sum_parts(s, partial, h->dwdb, B, (size_t)D * 2);
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((D + 255) / 256), dim3(256), 0, s, h->dwdb, h->junk, db, D, 1, 1.f);
-    wv::launch_gemm_nt(s, dZ, H, parts, 1.f, 0, B, D, C, T, S, np_.TC);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)D * C + 255) / 256)), dim3(256), 0, s, parts, h->dW, S, (size_t)D * C);
+    T_LAUNCH(wv::launch_gemm_nt(s, dZ, H, parts, 1.f, 0, B, D, C, T, S, np_.TC));
+    wv::launch_sum_parts(s, parts, h->dW, S, (size_t)D * C);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(D), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, C);
     T_LAUNCH(hipGetLastError());
     // dh = W^T dz
@@ -1283,7 +1329,7 @@ int wv_train_convpost_backward(wv_train_convpost* h, const float* x, const float
     T_LAUNCH(wv::launch_pw_dw(t, s));
     // through the depth-wise conv (da into the H buffer) and the ELU
     wv::launch_dw_bwd(s, DH, A, h->w_dw, H, partial, C, B, T, T, ks, 1, ks - 1, 0);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((C * (ks + 1) + 255) / 256), dim3(256), 0, s, partial, h->dwdb, B, (size_t)C * (ks + 1));
+    wv::launch_sum_parts(s, partial, h->dwdb, B, (size_t)C * (ks + 1));
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((C + 255) / 256), dim3(256), 0, s, h->dwdb, h->taps, h->junk, C, ks, 1.f);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g_dw, v_dw, h->inv_dw, h->taps, dg_dw, dv_dw, ks);
     const size_t n = (size_t)B * C * T, n4 = n / 4;
@@ -1389,10 +1435,10 @@ int wv_train_head_backward(wv_train_head* h, const float* z, const float* w_rev,
     hipLaunchKernelGGL(wv::time_to_frames_kernel, dim3((unsigned)((hn + 255) / 256), B * nb), dim3(256), 0, s, dlogits, dlq, T, hop, N);
     // last layer: dw_last[k][o] = sum dlq[k] . q[o] over (b, j, n);  db_last[k] = sum dlogits
     const int S2 = np2.S;
-    wv::launch_gemm_nt(s, dlq, q, parts, 1.f, 0, B, nb, O, (int)hn, S2, np2.TC);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)nb * O + 255) / 256)), dim3(256), 0, s, parts, dw_last, S2, (size_t)nb * O);
+    T_LAUNCH(wv::launch_gemm_nt(s, dlq, q, parts, 1.f, 0, B, nb, O, (int)hn, S2, np2.TC));
+    wv::launch_sum_parts(s, parts, dw_last, S2, (size_t)nb * O);
     wv::launch_dw_bwd(s, dlq, dlq, h->junk, (float*)nullptr, partial, nb, B, (int)hn, (int)hn, 1, 1, 0, 0);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((nb * 2 + 255) / 256), dim3(256), 0, s, partial, h->scr, B, (size_t)nb * 2);
+    wv::launch_sum_parts(s, partial, h->scr, B, (size_t)nb * 2);
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, h->scr, h->junk, db_last, nb, 1, 1.f);
     // dq = w_last^T @ dlq
     hipLaunchKernelGGL(wv::pack_wt_kernel, dim3((unsigned)(((size_t)O * nb + 255) / 256)), dim3(256), 0, s, w_last, h->wt_lT, O, nb, wv::round_up(O, wv::M_ALIGN), 1);
@@ -1400,11 +1446,11 @@ int wv_train_head_backward(wv_train_head* h, const float* z, const float* w_rev,
     T_LAUNCH(head_gemm(dlq, head_pw(O, nb, h->wt_lT), nullptr, dq, B, (int)hn, s));
     // db_rev[o] = sum dq[o];  dw_rev[d][(o,j)] = sum_{b,n} z[d][n] dq[(o,j)][n];  dz = w_rev @ dq
     wv::launch_dw_bwd(s, dq, dq, h->junk, (float*)nullptr, partial, O, B, (int)hn, (int)hn, 1, 1, 0, 0);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((O * 2 + 255) / 256), dim3(256), 0, s, partial, h->scr, B, (size_t)O * 2);
+    wv::launch_sum_parts(s, partial, h->scr, B, (size_t)O * 2);
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((O + 255) / 256), dim3(256), 0, s, h->scr, h->junk, db_rev, O, 1, 1.f);
     const int S1 = np1.S;
-    wv::launch_gemm_nt(s, z, dq, parts, 1.f, 0, B, D, OH, N, S1, np1.TC);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)D * OH + 255) / 256)), dim3(256), 0, s, parts, dw_rev, S1, (size_t)D * OH);
+    T_LAUNCH(wv::launch_gemm_nt(s, z, dq, parts, 1.f, 0, B, D, OH, N, S1, np1.TC));
+    wv::launch_sum_parts(s, parts, dw_rev, S1, (size_t)D * OH);
     hipLaunchKernelGGL(wv::pack_wt_kernel, dim3((unsigned)(((size_t)D * OH + 255) / 256)), dim3(256), 0, s, w_rev, h->wt_dz, D, OH, wv::round_up(D, wv::M_ALIGN), 0);
     T_LAUNCH(hipGetLastError());
     T_LAUNCH(head_gemm(dq, head_pw(D, OH, h->wt_dz), nullptr, dz, B, N, s));
@@ -1493,11 +1539,11 @@ int wv_train_up_backward(wv_train_up* h, const float* x, const float* g_ct, cons
     hipLaunchKernelGGL(wv::convtr_fwd_kernel, dim3(K, B), dim3(256), 0, s, x, h->w_ct, U, K, Tin, r, pre_scale, pre_elu);
     // db = sum dy;  dW = sum dy u^T
     wv::launch_dw_bwd(s, dy, dy, h->junk, (float*)nullptr, partial, M, B, Tout, Tout, 1, 1, 0, 0);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((M * 2 + 255) / 256), dim3(256), 0, s, partial, h->scr, B, (size_t)M * 2);
+    wv::launch_sum_parts(s, partial, h->scr, B, (size_t)M * 2);
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((M + 255) / 256), dim3(256), 0, s, h->scr, h->junk, db, M, 1, 1.f);
     const NtPlan np_ = nt_plan(B, Tout, M, K);
-    wv::launch_gemm_nt(s, dy, U, parts, 1.f, 0, B, M, K, Tout, np_.S, np_.TC);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)(((size_t)M * K + 255) / 256)), dim3(256), 0, s, parts, h->dW, np_.S, (size_t)M * K);
+    T_LAUNCH(wv::launch_gemm_nt(s, dy, U, parts, 1.f, 0, B, M, K, Tout, np_.S, np_.TC));
+    wv::launch_sum_parts(s, parts, h->dW, np_.S, (size_t)M * K);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(M), dim3(256), 0, s, g_pw, v_pw, h->inv_pw, h->dW, dg_pw, dv_pw, K);
     T_LAUNCH(hipGetLastError());
     // du = W^T dy
@@ -1509,7 +1555,7 @@ int wv_train_up_backward(wv_train_up* h, const float* x, const float* g_ct, cons
     T_LAUNCH(wv::launch_pw_dw(t, s));
     // through the transposed conv and the activation
     hipLaunchKernelGGL(wv::convtr_bwd_kernel, dim3(K, B), dim3(256), 0, s, DU, x, h->w_ct, dx, partial, K, Tin, r, pre_scale, pre_elu);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((K * ks + 255) / 256), dim3(256), 0, s, partial, h->taps, B, (size_t)K * ks);
+    wv::launch_sum_parts(s, partial, h->taps, B, (size_t)K * ks);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(K), dim3(256), 0, s, g_ct, v_ct, h->inv_ct, h->taps, dg_ct, dv_ct, ks);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
@@ -1562,7 +1608,7 @@ int wv_train_tail_backward(wv_train_tail* h, const float* x, const float* g, con
     hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(1), dim3(256), 0, s, g, v, h->w, h->inv, (float*)nullptr, (float*)nullptr, 1, C * ks, 0, 0,
                        (const float*)nullptr, 1.f, (float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(wv::tail_bwd_kernel, dim3(C, B), dim3(256), 0, s, x, h->w, delta, d_delta, dx, (float*)ws, C, Tin, T, ks, post, wav_std);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((C * (ks + 1) + 255) / 256), dim3(256), 0, s, (const float*)ws, h->dwdb, B, (size_t)C * (ks + 1));
+    wv::launch_sum_parts(s, (const float*)ws, h->dwdb, B, (size_t)C * (ks + 1));
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((C + 255) / 256), dim3(256), 0, s, h->dwdb, h->taps, h->dbv, C, ks, 1.f);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(1), dim3(256), 0, s, g, v, h->inv, h->taps, dg, dv, C * ks);
     T_LAUNCH(hipGetLastError());
@@ -1602,7 +1648,7 @@ int wv_train_film_backward(const float* msg, const float* params, const float* d
     float* acts = (float*)ws;
     float* gpart = (float*)((char*)ws + al256((size_t)B * (layers + 1) * E * 4));
     hipLaunchKernelGGL(wv::msg_film_bwd_kernel, dim3(B), dim3(256), 0, s, msg, params, acts, dfilm, gpart, msg_dim, E, layers, n_scales * bands * 2, np);
-    hipLaunchKernelGGL(wv::sum_parts_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, gpart, dparams, B, np);
+    wv::launch_sum_parts(s, gpart, dparams, B, np);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }
