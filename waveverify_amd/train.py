@@ -29,6 +29,20 @@ def _f(t: torch.Tensor) -> torch.Tensor:
     return t.float().contiguous()
 
 
+def _dst(into, key, like_shape, device):
+    """Gradient destination: the caller's contiguous float32 view of the same size (a slice of a flat gradient arena -- the kernels then
+    write it in place, no copy afterwards), else a fresh tensor."""
+    t = None if into is None else into.get(key)
+    if t is None:
+        return torch.empty(like_shape, device=device)
+    n = 1
+    for d in like_shape:
+        n *= int(d)
+    if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n or t.device != torch.device(device):
+        raise ValueError(f"gradient destination {key}: need a contiguous float32 tensor of {n} elements on {device}")
+    return t
+
+
 class TrainHalf:
     def __init__(self, channels: int):
         self._lib = _lib.load()
@@ -109,12 +123,13 @@ class TrainUnit:
             raise RuntimeError(f"wv_train_unit_forward: {self._lib.wv_train_last_error().decode()}")
         return y
 
-    def backward(self, x, p, pre_scale: float, dy, pre_elu: bool = True, need_dx: bool = True):
+    def backward(self, x, p, pre_scale: float, dy, pre_elu: bool = True, need_dx: bool = True, into=None):
         x, dy = _f(x), _f(dy)
         B, _, T = x.shape
         g_pw, v_pw, g_dw, v_dw, _ = self._p(p)
-        out = dict(dx=torch.empty_like(x) if need_dx else None, dg_pw=torch.empty_like(g_pw), dv_pw=torch.empty_like(v_pw),
-                   dg_dw=torch.empty_like(g_dw), dv_dw=torch.empty_like(v_dw), db_dw=torch.empty_like(g_dw))
+        dev = x.device
+        out = dict(dx=torch.empty_like(x) if need_dx else None, dg_pw=_dst(into, "dg_pw", g_pw.shape, dev), dv_pw=_dst(into, "dv_pw", v_pw.shape, dev),
+                   dg_dw=_dst(into, "dg_dw", g_dw.shape, dev), dv_dw=_dst(into, "dv_dw", v_dw.shape, dev), db_dw=_dst(into, "db_dw", g_dw.shape, dev))
         ws = torch.empty(int(self._lib.wv_train_unit_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=x.device)
         rc = self._lib.wv_train_unit_backward(
             self._h, x.data_ptr(), g_pw.data_ptr(), v_pw.data_ptr(), g_dw.data_ptr(), v_dw.data_ptr(), float(pre_scale), int(pre_elu),
@@ -237,12 +252,13 @@ class TrainSpecAdd(_Handle):
                                                     TrainHalf._stream()), "wv_train_spec_forward")
         return y
 
-    def backward(self, P, p, scale_param, res_scale: float, dy, need_dP: bool = False):
+    def backward(self, P, p, scale_param, res_scale: float, dy, need_dP: bool = False, into=None):
         P, dy = _f(P), _f(dy)
         B, _, T = dy.shape
         g, v = _f(p["g"]).reshape(self.C), _f(p["v"]).reshape(self.C, self.F)
         sp = None if scale_param is None else _f(scale_param).reshape(1)
-        out = dict(dg=torch.empty_like(g), dv=torch.empty_like(v), d_scale_param=None if sp is None else torch.empty(1, device=dy.device),
+        out = dict(dg=_dst(into, "dg", g.shape, dy.device), dv=_dst(into, "dv", v.shape, dy.device),
+                   d_scale_param=None if sp is None else _dst(into, "d_scale_param", (1,), dy.device),
                    dP=torch.empty_like(P) if need_dP else None)
         ws = torch.empty(int(self._lib.wv_train_spec_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=dy.device)
         self._check(self._lib.wv_train_spec_backward(
@@ -440,7 +456,8 @@ class TrainBlock:
             raise RuntimeError(f"wv_train_block_forward: {self._lib.wv_train_last_error().decode()}")
         return y, saved
 
-    def backward(self, x, ps, res_scale_param, pre_scale: float, res_scale: float, dy, saved):
+    def backward(self, x, ps, res_scale_param, pre_scale: float, res_scale: float, dy, saved, into=None):
+        """into: optional dict(halves=[{dg_pw, dv_pw, dg_dw, dv_dw, db_dw} x 2], d_res_scale_param) of destinations (see _dst)."""
         x, dy = _f(x), _f(dy)
         B, _, T = x.shape
         arr, keep = self._params(ps)
@@ -448,12 +465,13 @@ class TrainBlock:
         dev = x.device
         grads, garr = [], (_HalfGrads * 2)()
         for i in range(2):
-            g = dict(dg_pw=torch.empty(self.C, device=dev), dv_pw=torch.empty(self.C, self.C, device=dev), dg_dw=torch.empty(self.C, device=dev),
-                     dv_dw=torch.empty(self.C, 5, device=dev), db_dw=torch.empty(self.C, device=dev))
+            hi = None if into is None else into["halves"][i]
+            g = dict(dg_pw=_dst(hi, "dg_pw", (self.C,), dev), dv_pw=_dst(hi, "dv_pw", (self.C, self.C), dev), dg_dw=_dst(hi, "dg_dw", (self.C,), dev),
+                     dv_dw=_dst(hi, "dv_dw", (self.C, 5), dev), db_dw=_dst(hi, "db_dw", (self.C,), dev))
             grads.append(g)
             garr[i] = _HalfGrads(g["dg_pw"].data_ptr(), g["dv_pw"].data_ptr(), g["dg_dw"].data_ptr(), g["dv_dw"].data_ptr(), g["db_dw"].data_ptr())
         dx = torch.empty_like(x)
-        drsp = None if rsp is None else torch.empty(1, device=dev)
+        drsp = None if rsp is None else _dst(into, "d_res_scale_param", (1,), dev)
         ws = torch.empty(int(self._lib.wv_train_block_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=dev)
         rc = self._lib.wv_train_block_backward(
             self._h, x.data_ptr(), arr, None if rsp is None else rsp.data_ptr(), float(pre_scale), float(res_scale), dy.data_ptr(),
@@ -712,6 +730,12 @@ class _NetTrainer:
         self._put(f"{pre}.{dw}", g["dg_dw"], g["dv_dw"])
         self.gviews[f"{pre}.{dw}.conv.conv.bias"].copy_(g["db_dw"])
 
+    def _into_half(self, pre, pw, dw):
+        """Gradient-arena views of one 1x1 -> depth-wise unit: the kernels write them in place."""
+        a, b = f"{pre}.{pw}.conv.conv.parametrizations.weight.", f"{pre}.{dw}.conv.conv.parametrizations.weight."
+        return dict(dg_pw=self.gviews[a + "original0"], dv_pw=self.gviews[a + "original1"], dg_dw=self.gviews[b + "original0"],
+                    dv_dw=self.gviews[b + "original1"], db_dw=self.gviews[f"{pre}.{dw}.conv.conv.bias"])
+
     def _spec_p(self, pre):
         g, v = self._wn(pre + ".layer")
         return dict(g=g, v=v), self.params.get(pre + ".scale_param")
@@ -730,12 +754,10 @@ class _NetTrainer:
         h_in, saved, pre_scale = rec
         ps = [self._half(pre + ".block", 1, 2), self._half(pre + ".block", 4, 5)]
         rsp = self.params.get(pre + ".res_scale_param")
-        gb = blk.backward(h_in, ps, rsp, pre_scale, rs, dh, saved)
-        self._put_half(pre + ".block", 1, 2, gb["halves"][0])
-        self._put_half(pre + ".block", 4, 5, gb["halves"][1])
+        into = dict(halves=[self._into_half(pre + ".block", 1, 2), self._into_half(pre + ".block", 4, 5)])
         if rsp is not None:
-            self.gviews[pre + ".res_scale_param"].copy_(gb["d_res_scale_param"])
-        return gb["dx"]
+            into["d_res_scale_param"] = self.gviews[pre + ".res_scale_param"]
+        return blk.backward(h_in, ps, rsp, pre_scale, rs, dh, saved, into)["dx"]
 
     # ---- the encoder -----------------------------------------------------------------------------------------------------------------
     def encoder_forward(self, x: torch.Tensor, msg: Optional[torch.Tensor]) -> torch.Tensor:
@@ -785,10 +807,11 @@ class _NetTrainer:
 
         def spec_back(unit, stft, pre, P, dy):
             sp, scp = self._spec_p(pre)
-            gs = unit.backward(P, sp, scp, rs, dy, need_dx)
-            self._put(pre + ".layer", gs["dg"], gs["dv"])
+            b = pre + ".layer.conv.conv.parametrizations.weight."
+            into = dict(dg=self.gviews[b + "original0"], dv=self.gviews[b + "original1"])
             if scp is not None:
-                self.gviews[pre + ".scale_param"].copy_(gs["d_scale_param"])
+                into["d_scale_param"] = self.gviews[pre + ".scale_param"]
+            gs = unit.backward(P, sp, scp, rs, dy, need_dx, into)
             if need_dx:
                 stft.backward(sv["x"], gs["dP"], dx_spec, True)
         spec_back(self.spec_post, self.stft_post, "encoder.spec_post", sv["P_post"], dh)
@@ -797,8 +820,8 @@ class _NetTrainer:
             sc, rec = self.scales[s], sv["scales"][s]
             if self.with_msg:
                 dh = self.film.apply_backward(rec["film_in"], sv["film"], dh, dfilm, s)
-            gd = sc["down"].backward(rec["down_in"], self._half(f"encoder.downsample.{s}", 2, 3), self.down_scale, dh, True, True)
-            self._put_half(f"encoder.downsample.{s}", 2, 3, gd)
+            gd = sc["down"].backward(rec["down_in"], self._half(f"encoder.downsample.{s}", 2, 3), self.down_scale, dh, True, True,
+                                     self._into_half(f"encoder.downsample.{s}", 2, 3))
             dh = gd["dx"]
             spec_back(sc["spec"], sc["stft"], f"encoder.spec_blocks.{s}", rec["P"], dh)          # the add passes dh through unchanged
             for j in reversed(range(len(sc["blocks"]))):
