@@ -184,12 +184,77 @@ __global__ __launch_bounds__(256) void dw_bwd51_vec_kernel(const float* __restri
     if (tid < 6) partial[((size_t)b * M + m) * 6 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
+// The downsample stencils (ks = 2 r, stride r, pad = r, Tin = r Tout: seanet.py:724-741) one output frame q per thread: the r samples
+// h[q r .. q r + r - 1] meet exactly two frames, dy[q] (taps p + r) and dy[q + 1] (taps p):
+//   dh[q r + p] = w[p] dy[q + 1] + w[p + r] dy[q],   dw[p + r] += dy[q] h[q r + p],   dw[p] += dy[q + 1] h[q r + p]
+// -- r + 2 loads (16-byte ones when r % 4 == 0), r stores and 4 r FMAs per thread instead of 2 r tap tests per sample.
+template <int R>
+__global__ __launch_bounds__(256) void dw_bwd_down_kernel(const float* __restrict__ dy, const float* __restrict__ h, const float* __restrict__ w,
+                                                          float* __restrict__ dh, float* __restrict__ partial, int M, int Tout) {
+    constexpr int KS = 2 * R;
+    __shared__ float red[4][KS + 1];
+    const int m = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const size_t row_y = ((size_t)b * M + m) * Tout, row_h = row_y * R;
+    const float* dyr = dy + row_y;
+    const float* hr = h + row_h;
+    float* dhr = dh + row_h;
+    float wt[KS], acc[KS + 1];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) { wt[i] = w[m * KS + i]; acc[i] = 0.f; }
+    acc[KS] = 0.f;
+    for (int q = tid; q < Tout; q += 256) {
+        const float d0 = dyr[q], d1 = q + 1 < Tout ? dyr[q + 1] : 0.f;
+        float hv[R], g[R];
+        if constexpr (R % 4 == 0) {
+#pragma unroll
+            for (int c = 0; c < R / 4; ++c) {
+                const f32x4 v = reinterpret_cast<const f32x4*>(hr)[q * (R / 4) + c];
+                hv[4 * c] = v[0]; hv[4 * c + 1] = v[1]; hv[4 * c + 2] = v[2]; hv[4 * c + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < R; ++p) hv[p] = hr[q * R + p];
+        }
+#pragma unroll
+        for (int p = 0; p < R; ++p) {
+            g[p] = fmaf(wt[p + R], d0, wt[p] * d1);
+            acc[p + R] = fmaf(d0, hv[p], acc[p + R]);
+            acc[p] = fmaf(d1, hv[p], acc[p]);
+        }
+        acc[KS] += d0;
+        if constexpr (R % 4 == 0) {
+#pragma unroll
+            for (int c = 0; c < R / 4; ++c) {
+                const f32x4 v = {g[4 * c], g[4 * c + 1], g[4 * c + 2], g[4 * c + 3]};
+                reinterpret_cast<f32x4*>(dhr)[q * (R / 4) + c] = v;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < R; ++p) dhr[q * R + p] = g[p];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i <= KS; ++i) {
+        float v = acc[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((tid & 63) == 0) red[tid >> 6][i] = v;
+    }
+    __syncthreads();
+    if (tid <= KS) partial[((size_t)b * M + m) * (KS + 1) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 static void launch_dw_bwd(hipStream_t s, const float* dy, const float* h, const float* w, float* dh, float* partial, int M, int B, int Tin,
                           int Tout, int ks, int stride, int pad, int h_shared) {
 #define WV_DWB(K, S) hipLaunchKernelGGL((dw_bwd_kernel<K, S>), dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tin, Tout, ks, stride, pad, h_shared)
     const bool al16 = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(dh)) & 15) == 0;
     if (ks == 5 && stride == 1 && pad == 4 && dh && !h_shared && Tin == Tout && (Tin & 3) == 0 && al16)
         hipLaunchKernelGGL(dw_bwd51_vec_kernel, dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tin);
+    else if (dh && !h_shared && ks == 2 * stride && pad == stride && (long long)Tout * stride == Tin && (stride % 4 != 0 || al16) &&
+             (stride == 2 || stride == 4 || stride == 5 || stride == 8)) {
+#define WV_DWD(R) hipLaunchKernelGGL((dw_bwd_down_kernel<R>), dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tout)
+        if (stride == 2) WV_DWD(2); else if (stride == 4) WV_DWD(4); else if (stride == 5) WV_DWD(5); else WV_DWD(8);
+#undef WV_DWD
+    }
     else if (ks == 5 && stride == 1) WV_DWB(5, 1);
     else if (ks == 1 && stride == 1) WV_DWB(1, 1);
     else if (ks == 4 && stride == 2) WV_DWB(4, 2);
@@ -420,11 +485,20 @@ __global__ __launch_bounds__(256) void scale_dot_kernel(const float4* __restrict
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-__global__ void finish_sum_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
-    if (threadIdx.x || blockIdx.x) return;
+// one wave: lane l adds its contiguous run of the partials in double, lane 0 adds the 64 lane sums in lane order (fixed order, 64
+// threads required)
+__global__ __launch_bounds__(64) void finish_sum_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
+    __shared__ double red[64];
+    const int lane = threadIdx.x, per = (n + 63) / 64;
     double a = 0.0;
-    for (int i = 0; i < n; ++i) a += (double)partial[i];
-    out[0] = (float)(a * (double)scale);
+    for (int i = lane * per, e = min(n, (lane + 1) * per); i < e; ++i) a += (double)partial[i];
+    red[lane] = a;
+    __syncthreads();
+    if (lane == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 64; ++k) t += red[k];
+        out[0] = (float)(t * (double)scale);
+    }
 }
 
 __global__ __launch_bounds__(256) void add_inplace_kernel(float4* __restrict__ dx, const float4* __restrict__ dy, size_t n4) {
