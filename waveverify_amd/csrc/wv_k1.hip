@@ -141,7 +141,7 @@ struct DmaA {                           // A = packed weights wq[kq][Mp] (f32x4)
 // EPI 1: any (ks <= 16, stride, dilation): rows go through a wave-private LDS strip (one 16/8-byte
 //        write per lane and row) and the taps are gathered from there.
 // begin() runs before the GEMM (row table, first residual rows), finish() after it.
-template <class C, int EPI, bool RES>
+template <class C, int EPI, int RES>
 struct K1Epi {
     static constexpr int NT = C::NT, HLD = C::HLD;
     // row table: taps (padded to a multiple of 4), then bias, FiLM gamma, beta.  The r = 2 / r = 4 stencils keep it at 8 / 12 floats per
@@ -318,7 +318,12 @@ struct K1Epi {
                     const ovec rr = res4[r & 3];
                     if (r + 4 < 16) res4[r & 3] = buf_load(rR, voff + (((r + 4) & 3) + 8 * ((r + 4) >> 2)) * row_bytes);
 #pragma unroll
-                    for (int e = 0; e < NT; ++e) y[e] = fmaf(y[e], p.out_scale, rr[e]);
+                    for (int e = 0; e < NT; ++e) {
+                        if constexpr (RES == 2) {                // training: dx = da * ELU'(s x) * s, the residual operand is x, out_scale = s
+                            const float z = p.out_scale * rr[e];
+                            y[e] = y[e] * (z > 0.f ? 1.f : __expf(z)) * p.out_scale;
+                        } else y[e] = fmaf(y[e], p.out_scale, rr[e]);
+                    }
                 }
                 if (Yb) buf_store(rY, off, y);
                 if (Ab) {
@@ -440,7 +445,7 @@ struct K1Epi {
                     float y = bias;
                     for (int i = 0; i < ks; ++i) y = fmaf(wt[i], hp[i * p.dil], y);
                     y = fmaf(y, gam, bet);
-                    if (RES && Rb) y = fmaf(y, p.out_scale, Rb[ro + oo]);
+                    if (RES == 1 && Rb) y = fmaf(y, p.out_scale, Rb[ro + oo]);
                     if (Yb) Yb[ro + oo] = y;
                     if (Ab) Ab[ro + oo] = elu1(y * p.act_scale);
                 }
@@ -463,7 +468,7 @@ template <> struct LdrSel<5> { typedef ConvTrPair<0> type; };
 // cycles at the 2.05 GHz the chip holds under this load, profiles/r02_k1_sq_counters.txt -- and the second
 // set of per-tile state cost the fourth resident wave per SIMD, which short-K layers need to hide the DMA
 // latency.)
-template <class C, int EPI, int LDR, bool RES, int NS>
+template <class C, int EPI, int LDR, int RES, int NS>
 __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4) void k1_kernel(PwDwArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool REG = LDR != 0;
@@ -638,7 +643,7 @@ bool k1_supported(const PwDwArgs& a) {
     return true;
 }
 
-template <class C, int EPI, int LDR, bool RES, int NS = 2>
+template <class C, int EPI, int LDR, int RES, int NS = 2>
 static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
     const size_t smem = NS * (size_t)C::STAGE4 * 16 + (size_t)K1Epi<C, EPI, RES>::TABLE_FLOATS * sizeof(float);
     static_assert(C::WM * 4 * C::HLD <= 2 * C::STAGE4 * 4, "strips alias the stages");
@@ -667,7 +672,7 @@ static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
 
 bool pw_dw_geometry(PwDwArgs& a, int BN);                     // wv_kernels.hip
 
-template <class C, int EPI, bool RES>
+template <class C, int EPI, int RES>
 static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
     if (a.ct_w) {
         if constexpr (EPI == 0 && !RES) {
@@ -677,7 +682,7 @@ static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
         }
         return hipErrorInvalidValue;
     }
-    const char* base = a.spec_add ? "spec_add" : (EPI == 0 ? (RES ? "pw_dw_k5" : "pw_dw_k5_nr") : (EPI == 1 ? "pw_dw" : "pw_dw_s"));
+    const char* base = a.spec_add ? "spec_add" : (EPI == 0 ? (RES == 2 ? "pw_dw_k5_dact" : RES ? "pw_dw_k5" : "pw_dw_k5_nr") : (EPI == 1 ? "pw_dw" : "pw_dw_s"));
     if (a.pre_elu || a.pre_scale != 1.f) return k1_run<C, EPI, 1, RES>(a, s, base);
     if constexpr (C::NT == 4 && C::BM == 128) {
         // matrix-bound k5 units: deeper DMA pipeline.  Not the strided units: their 8-10 KB row table makes the third stage cost a resident
@@ -690,6 +695,10 @@ static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
 template <class C>
 static hipError_t k1_pick_epi(const PwDwArgs& a, hipStream_t s, bool k5) {
     const bool res = a.resid != nullptr;
+    if (a.res_mode == 2) {                                   // ELU-derivative epilogue (training): the k5 DPP epilogue only
+        if (!k5 || !res) return hipErrorNotSupported;
+        return k1_pick_ldr<C, 0, 2>(a, s);
+    }
     if (k5) return res ? k1_pick_ldr<C, 0, true>(a, s) : k1_pick_ldr<C, 0, false>(a, s);
     if constexpr (C::NT == 4) {                              // the net's downsample stencils: ks = 2r, stride r, pad r
         if (!res && !a.ct_w && a.dil == 1 && a.ks == 2 * a.stride && a.pad == a.stride &&

@@ -31,6 +31,7 @@ struct PwDwArgs {
     const float* dw_b;    // [M] or null
     const float* film;    // [B, film_stride] (gamma,beta interleaved per band) or null
     const float* resid;   // [B, M, Tout] or null
+    int res_mode;         // 0: y = resid + out_scale * y;  2 (training, LDS-DMA core only): y = y * ELU'(out_scale * resid) * out_scale
     float* Y;             // [B, M, Tout]
     int B, Tin, Tout, ks, stride, dil, pad;
     float pre_scale;

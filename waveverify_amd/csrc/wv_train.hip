@@ -1037,11 +1037,22 @@ int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, 
         t.X = DH; t.pw = pack_of(h, true); t.dw_w = h->id_taps; t.dw_b = nullptr; t.Y = pre_elu ? DA : dx;
         t.B = B; t.Tin = Tin; t.Tout = Tin; t.ks = 5; t.stride = 1; t.dil = 1; t.pad = 4;
         t.pre_scale = pre_elu ? 1.f : pre_scale; t.pre_elu = 0; t.out_scale = 1.f; t.bands = 1; t.film_stride = 2;   // no ELU: dx = s W^T dh
-        T_LAUNCH(wv::launch_pw_dw(t, s));
+        bool fused = false;
         if (pre_elu) {
-            const size_t n = (size_t)B * K * Tin, n4 = n / 4;
-            if (n4) hipLaunchKernelGGL(wv::elu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, DA, x, dx, pre_scale, n4);
-            if (n % 4) hipLaunchKernelGGL(wv::elu_bwd_tail_kernel, dim3(1), dim3(256), 0, s, DA, x, dx, pre_scale, n4 * 4, n);
+            // the activation's derivative in the GEMM's epilogue (x rides in as the residual operand): no da round trip through HBM
+            wv::PwDwArgs f = t;
+            f.Y = dx; f.resid = x; f.res_mode = 2; f.out_scale = pre_scale;
+            const hipError_t e = wv::launch_pw_dw(f, s);
+            if (e == hipSuccess) fused = true;
+            else if (e != hipErrorNotSupported) T_LAUNCH(e);
+        }
+        if (!fused) {
+            T_LAUNCH(wv::launch_pw_dw(t, s));
+            if (pre_elu) {
+                const size_t n = (size_t)B * K * Tin, n4 = n / 4;
+                if (n4) hipLaunchKernelGGL(wv::elu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, DA, x, dx, pre_scale, n4);
+                if (n % 4) hipLaunchKernelGGL(wv::elu_bwd_tail_kernel, dim3(1), dim3(256), 0, s, DA, x, dx, pre_scale, n4 * 4, n);
+            }
         }
     }
     // dW = sum dh a^T, then the weight-norm backward
