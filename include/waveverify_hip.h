@@ -250,7 +250,8 @@ int wv_train_unit_backward(wv_train_unit* u, const float* x, const float* g_pw, 
 
 /* Whole SEANetResnetBlock with live weight norm (modules/seanet.py:245-281, identity shortcut):
  *     y = x + s * half2(half1(pre_scale * x)),   s = res_scale * res_scale_param[0]  (res_scale_param may be NULL: s = res_scale)
- * forward keeps the two intermediate activations in `saved` (wv_train_block_saved_bytes) for backward, which returns
+ * forward keeps the two intermediate activations and the two 1x1 outputs in `saved` (wv_train_block_saved_bytes: four activation-sized
+ * tensors; the forward kernels store the 1x1 outputs themselves, backward then has no GEMM to recompute) for backward, which returns
  * dx, both halves' parameter gradients and d(res_scale_param).  Same shape limits as the half. */
 typedef struct wv_train_block wv_train_block;
 typedef struct { const float *g_pw, *v_pw, *g_dw, *v_dw, *bias; } wv_half_params;     /* device pointers */

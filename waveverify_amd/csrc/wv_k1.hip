@@ -149,11 +149,15 @@ struct K1Epi {
     static constexpr int NTAP = EPI == 0 ? 5 : (EPI == 2 ? 4 : (EPI == 4 ? 8 : 16));
     static constexpr int WLD = EPI == 0 ? 8 : NTAP + 4;
     static constexpr int TABLE_FLOATS = C::BM * WLD;
-    static constexpr int RP = RES ? 4 : 0;                       // residual rows in flight per lane
+    // RES: 0 none, 1 y = resid + out_scale y, 2 (training) y = y ELU'(out_scale resid) out_scale [+ resid2], 4 (training) no residual,
+    // the raw 1x1 output H is stored next to y (p.Yraw)
+    static constexpr bool HASR = RES == 1 || RES == 2;
+    static constexpr int RP = HASR ? 4 : 0;                      // residual rows in flight per lane
     typedef typename NVec<NT>::type ovec;
     int M, m0, b, to0, lane, wave, half, q, o, to;
     bool act_lane, vec;
     const float* Rb; float* Yb; float* Ab; float* Wl;
+    const float* Rb2; float* Hb;                                 // RES 2: addend; RES 4: raw 1x1 output
     int voff0, nrec;                                             // EPI 0: lane's first byte offset (or an out-of-range marker), buffer size
     float fgam, fbet;                                            // EPI 8, flat tiling: this lane's FiLM scalars
 
@@ -206,7 +210,9 @@ struct K1Epi {
         const size_t bo = (size_t)b * M * p.Tout;
         Yb = p.Y ? p.Y + bo : nullptr;
         Ab = p.Yact ? p.Yact + bo : nullptr;
-        Rb = (RES && p.resid) ? p.resid + bo : nullptr;
+        Rb = (HASR && p.resid) ? p.resid + bo : nullptr;
+        Rb2 = (RES == 2 && p.resid2) ? p.resid2 + bo : nullptr;
+        Hb = (RES == 4 && p.Yraw) ? p.Yraw + bo : nullptr;
         o = NT * q; to = to0 + o;
         act_lane = o < p.tto && to < p.Tout;
         vec = act_lane && to + NT - 1 < p.Tout && o + NT - 1 < p.tto && (p.Tout % NT) == 0;
@@ -218,7 +224,7 @@ struct K1Epi {
             const long long gc = gflat + p.pad + o;
             const int bo2 = (int)(gc / p.Tv), t = (int)(gc - (long long)bo2 * p.Tv) - p.pad;
             const bool ok = o < p.tto && bo2 < p.B && t >= 0;
-            Yb = p.Y; Ab = p.Yact; Rb = RES ? p.resid : nullptr;
+            Yb = p.Y; Ab = p.Yact; Rb = HASR ? p.resid : nullptr; Rb2 = RES == 2 ? p.resid2 : nullptr; Hb = RES == 4 ? p.Yraw : nullptr;
             nrec = (int)((long long)p.B * M * p.Tout * 4);
             voff0 = ok ? (int)((((long long)bo2 * M + m0 + 32 * wave + 4 * half) * p.Tout + t) * 4) : (int)0x80000000u;
         }
@@ -278,10 +284,17 @@ struct K1Epi {
             const int row_bytes = p.Tout * 4;
             const int voff = voff0;
             const float* Wrow = Wl + (32 * wave + 4 * half) * 8;
-            ovec res4[RES ? 4 : 1];                              // RES instantiations always have a residual operand
-            if constexpr (RES) {
+            ovec res4[HASR ? 4 : 1];                             // RES 1 / 2 instantiations always have a residual operand
+            ovec add4[RES == 2 ? 4 : 1];                         // RES 2: the optional addend (a null one reads zeros: zero-record buffer)
+            const __amdgpu_buffer_rsrc_t rR2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Rb2 ? Rb2 : p.X), 0, Rb2 ? clip_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(Hb ? Hb : p.Y, 0, Hb ? clip_bytes : 0, 0x00020000);
+            if constexpr (HASR) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) res4[r] = buf_load(rR, voff + ((r & 3) + 8 * (r >> 2)) * row_bytes);
+            }
+            if constexpr (RES == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) add4[r] = buf_load(rR2, voff + ((r & 3) + 8 * (r >> 2)) * row_bytes);
             }
             // The row table of step r+1 is requested during step r; a scheduling barrier per step keeps the
             // compiler from hoisting all 16 steps' loads to the top (128 live registers, spills).
@@ -314,7 +327,7 @@ struct K1Epi {
                     v = fmaf(w0.w, hh[e + 3], v); v = fmaf(w1.x, hh[e + 4], v);
                     y[e] = v;
                 }
-                if constexpr (RES) {
+                if constexpr (HASR) {
                     const ovec rr = res4[r & 3];
                     if (r + 4 < 16) res4[r & 3] = buf_load(rR, voff + (((r + 4) & 3) + 8 * ((r + 4) >> 2)) * row_bytes);
 #pragma unroll
@@ -324,6 +337,18 @@ struct K1Epi {
                             y[e] = y[e] * (z > 0.f ? 1.f : __expf(z)) * p.out_scale;
                         } else y[e] = fmaf(y[e], p.out_scale, rr[e]);
                     }
+                }
+                if constexpr (RES == 2) {                        // ... + the identity shortcut's gradient
+                    const ovec ad = add4[r & 3];
+                    if (r + 4 < 16) add4[r & 3] = buf_load(rR2, voff + (((r + 4) & 3) + 8 * ((r + 4) >> 2)) * row_bytes);
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) y[e] += ad[e];
+                }
+                if constexpr (RES == 4) {                        // the stencil's input at the output's own time: hh[e + 4] = H[t]
+                    ovec hraw;
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) hraw[e] = hh[e + 4];
+                    buf_store(rH, off, hraw);
                 }
                 if (Yb) buf_store(rY, off, y);
                 if (Ab) {
@@ -367,7 +392,7 @@ struct K1Epi {
             // next 1 (R = 2, 4) or 3 (R = 8) lanes and comes by DPP.  Outputs per lane: R = 2 -> 2q, 2q+1 (one
             // 8-byte store), R = 4 -> q, R = 8 -> q/2 on the even lanes.  Taps are summed in ascending order like
             // the generic path (bit-identical).  Addressing and masking as in EPI 0 (range-checked buffers).
-            static_assert(NT == 4 && !RES, "strided DPP epilogue: 128-column windows, no residual");
+            static_assert(NT == 4 && RES == 0, "strided DPP epilogue: 128-column windows, no residual");
             constexpr int R = EPI;
             const bool flat = R == 8 && p.flat;
             const int clip_bytes = flat ? nrec : M * p.Tout * 4;
@@ -638,6 +663,7 @@ bool k1_supported(const PwDwArgs& a) {
     if (a.Y && !aligned16(a.Y)) return false;
     if (a.Yact && !aligned16(a.Yact)) return false;
     if (a.resid && !aligned16(a.resid)) return false;
+    if ((a.resid2 && !aligned16(a.resid2)) || (a.Yraw && !aligned16(a.Yraw))) return false;
     if (a.ks < 1 || a.ks > 16 || (a.ks - 1) * a.dil + 1 + 3 > 64) return false;
     if (a.ct_w && a.ratio == 1) return false;                // degenerate ratio: rare, round-1 path
     return true;
@@ -675,14 +701,14 @@ bool pw_dw_geometry(PwDwArgs& a, int BN);                     // wv_kernels.hip
 template <class C, int EPI, int RES>
 static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
     if (a.ct_w) {
-        if constexpr (EPI == 0 && !RES) {
+        if constexpr (EPI == 0 && RES == 0) {
             if (a.ratio % 4 == 0) return k1_run<C, 0, 2, false>(a, s, "convtr_pw");
             if (a.ratio == 2) return k1_run<C, 0, 3, false>(a, s, "convtr_pw");
             return k1_run<C, 0, 5, false>(a, s, "convtr_pw");
         }
         return hipErrorInvalidValue;
     }
-    const char* base = a.spec_add ? "spec_add" : (EPI == 0 ? (RES == 2 ? "pw_dw_k5_dact" : RES ? "pw_dw_k5" : "pw_dw_k5_nr") : (EPI == 1 ? "pw_dw" : "pw_dw_s"));
+    const char* base = a.spec_add ? "spec_add" : (EPI == 0 ? (RES == 2 ? "pw_dw_k5_dact" : RES == 4 ? "pw_dw_k5_h" : RES ? "pw_dw_k5" : "pw_dw_k5_nr") : (EPI == 1 ? "pw_dw" : "pw_dw_s"));
     if (a.pre_elu || a.pre_scale != 1.f) return k1_run<C, EPI, 1, RES>(a, s, base);
     if constexpr (C::NT == 4 && C::BM == 128) {
         // matrix-bound k5 units: deeper DMA pipeline.  Not the strided units: their 8-10 KB row table makes the third stage cost a resident
@@ -698,6 +724,10 @@ static hipError_t k1_pick_epi(const PwDwArgs& a, hipStream_t s, bool k5) {
     if (a.res_mode == 2) {                                   // ELU-derivative epilogue (training): the k5 DPP epilogue only
         if (!k5 || !res) return hipErrorNotSupported;
         return k1_pick_ldr<C, 0, 2>(a, s);
+    }
+    if (a.Yraw) {                                            // raw 1x1 output next to y (training forward): the k5 DPP epilogue only
+        if (!k5 || res || a.ct_w) return hipErrorNotSupported;
+        return k1_pick_ldr<C, 0, 4>(a, s);
     }
     if (k5) return res ? k1_pick_ldr<C, 0, true>(a, s) : k1_pick_ldr<C, 0, false>(a, s);
     if constexpr (C::NT == 4) {                              // the net's downsample stencils: ks = 2r, stride r, pad r

@@ -31,6 +31,8 @@ struct PwDwArgs {
     const float* dw_b;    // [M] or null
     const float* film;    // [B, film_stride] (gamma,beta interleaved per band) or null
     const float* resid;   // [B, M, Tout] or null
+    const float* resid2;  // res_mode 2 only: [B, M, Tout] added after the derivative, or null
+    float* Yraw;          // training forward, LDS-DMA core with the ks = 5 stencil only: the 1x1 output H [B, M, Tout] stored next to Y, or null
     int res_mode;         // 0: y = resid + out_scale * y;  2 (training, LDS-DMA core only): y = y * ELU'(out_scale * resid) * out_scale
     float* Y;             // [B, M, Tout]
     int B, Tin, Tout, ks, stride, dil, pad;

@@ -985,8 +985,10 @@ static wv::PwWeight pack_of(const wv_train_unit* h, bool transposed) {
     return p;
 }
 
-int wv_train_unit_forward(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
-                          const float* v_dw, const float* bias, float pre_scale, int pre_elu, float* y, int B, int Tin, void* stream) {
+// h_out (optional, stride-1 units): the 1x1 output H = W act(s x) [B, M, Tin], which the backward otherwise recomputes -- stored by the
+// forward kernel itself next to y where the LDS-DMA core runs the layer, else by one more pass with the identity stencil
+static int unit_forward_impl(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw, const float* v_dw,
+                             const float* bias, float pre_scale, int pre_elu, float* y, float* h_out, int B, int Tin, void* stream) {
     if (!h || !x || !g_pw || !v_pw || !g_dw || !v_dw || !y || B < 1 || Tin < 1) return tfail(WV_EINVAL, "null / bad argument");
     hipStream_t s = (hipStream_t)stream;
     int rc = fold_step(h, g_pw, v_pw, g_dw, v_dw, s);
@@ -995,8 +997,24 @@ int wv_train_unit_forward(wv_train_unit* h, const float* x, const float* g_pw, c
     a.X = x; a.pw = pack_of(h, false); a.dw_w = h->w_dw; a.dw_b = bias; a.Y = y;
     a.B = B; a.Tin = Tin; a.Tout = t_out(h, Tin); a.ks = h->ks; a.stride = h->stride; a.dil = 1; a.pad = h->pad;
     a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
+    if (h_out) {
+        if (h->stride != 1) return tfail(WV_EINVAL, "saved 1x1 output: stride-1 units only");
+        wv::PwDwArgs f = a;
+        f.Yraw = h_out;
+        const hipError_t e = wv::launch_pw_dw(f, s);
+        if (e == hipSuccess) return WV_OK;
+        if (e != hipErrorNotSupported) T_LAUNCH(e);
+        wv::PwDwArgs r = a;                                   // ragged / narrow layers: H by the identity stencil, as the backward used to
+        r.dw_w = h->id_taps; r.dw_b = nullptr; r.Y = h_out; r.Tout = Tin; r.ks = 5; r.stride = 1; r.pad = 4;
+        T_LAUNCH(wv::launch_pw_dw(r, s));
+    }
     T_LAUNCH(wv::launch_pw_dw(a, s));
     return WV_OK;
+}
+
+int wv_train_unit_forward(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
+                          const float* v_dw, const float* bias, float pre_scale, int pre_elu, float* y, int B, int Tin, void* stream) {
+    return unit_forward_impl(h, x, g_pw, v_pw, g_dw, v_dw, bias, pre_scale, pre_elu, y, nullptr, B, Tin, stream);
 }
 
 int wv_train_half_forward(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
@@ -1004,9 +1022,25 @@ int wv_train_half_forward(wv_train_unit* h, const float* x, const float* g_pw, c
     return wv_train_unit_forward(h, x, g_pw, v_pw, g_dw, v_dw, bias, pre_scale, 1, y, B, T, stream);
 }
 
+// h_saved (optional): the forward's 1x1 output (unit_forward_impl), else it is recomputed here.  dx_add (optional, with pre_elu): a
+// tensor added to dx (the ResnetBlock's identity shortcut); *added reports whether the dx kernel's epilogue took it.
+static int unit_backward_impl(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
+                              const float* v_dw, float pre_scale, int pre_elu, const float* dy, float* dx, float* dg_pw, float* dv_pw,
+                              float* dg_dw, float* dv_dw, float* db, int B, int Tin, void* ws, size_t ws_bytes, void* stream,
+                              const float* h_saved, const float* dx_add, bool* added);
+
 int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
                            const float* v_dw, float pre_scale, int pre_elu, const float* dy, float* dx, float* dg_pw, float* dv_pw,
                            float* dg_dw, float* dv_dw, float* db, int B, int Tin, void* ws, size_t ws_bytes, void* stream) {
+    return unit_backward_impl(h, x, g_pw, v_pw, g_dw, v_dw, pre_scale, pre_elu, dy, dx, dg_pw, dv_pw, dg_dw, dv_dw, db, B, Tin, ws, ws_bytes, stream,
+                              nullptr, nullptr, nullptr);
+}
+
+static int unit_backward_impl(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
+                              const float* v_dw, float pre_scale, int pre_elu, const float* dy, float* dx, float* dg_pw, float* dv_pw,
+                              float* dg_dw, float* dv_dw, float* db, int B, int Tin, void* ws, size_t ws_bytes, void* stream,
+                              const float* h_saved, const float* dx_add, bool* added) {
+    if (added) *added = false;
     if (!h || !x || !g_pw || !v_pw || !g_dw || !v_dw || !dy || !dg_pw || !dv_pw || !dg_dw || !dv_dw || !db)
         return tfail(WV_EINVAL, "null argument");
     if (B < 1 || Tin < 1 || !ws || ws_bytes < wv_train_unit_workspace_bytes(h, B, Tin)) return tfail(WV_ENOMEM, "workspace too small");
@@ -1014,17 +1048,20 @@ int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, 
     const int M = h->M, K = h->K, ks = h->ks, Tout = t_out(h, Tin);
     const size_t am = al256((size_t)B * M * Tin * 4), ak = al256((size_t)B * K * Tin * 4);
     char* w = (char*)ws;
-    float* H = (float*)w; float* DH = (float*)(w + am); float* DA = (float*)(w + 2 * am);
+    float* Hws = (float*)w; float* DH = (float*)(w + am); float* DA = (float*)(w + 2 * am);
+    const float* H = h_saved ? h_saved : Hws;
     float* partial = (float*)(w + 2 * am + ak);
     float* parts = (float*)(w + 2 * am + ak + al256((size_t)B * M * (ks + 1) * 4));
     int rc = fold_step(h, g_pw, v_pw, g_dw, v_dw, s);                          // the step's weights (forward ran the same fold)
     if (rc) return rc;
-    // h = W @ act(s x), recomputed (forward keeps no activations): K1 with the identity stencil
-    wv::PwDwArgs a{};
-    a.X = x; a.pw = pack_of(h, false); a.dw_w = h->id_taps; a.dw_b = nullptr; a.Y = H;
-    a.B = B; a.Tin = Tin; a.Tout = Tin; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
-    a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
-    T_LAUNCH(wv::launch_pw_dw(a, s));
+    if (!h_saved) {
+        // h = W @ act(s x), recomputed (this forward kept no activations): K1 with the identity stencil
+        wv::PwDwArgs a{};
+        a.X = x; a.pw = pack_of(h, false); a.dw_w = h->id_taps; a.dw_b = nullptr; a.Y = Hws;
+        a.B = B; a.Tin = Tin; a.Tout = Tin; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
+        a.pre_scale = pre_scale; a.pre_elu = pre_elu; a.out_scale = 1.f; a.bands = 1; a.film_stride = 2;
+        T_LAUNCH(wv::launch_pw_dw(a, s));
+    }
     // dh, and the per-clip partial sums of the tap / bias gradients
     wv::launch_dw_bwd(s, dy, H, h->w_dw, DH, partial, M, B, Tin, Tout, ks, h->stride, h->pad, 0);
     wv::launch_sum_parts(s, partial, h->dwdb, B, (size_t)M * (ks + 1));
@@ -1041,9 +1078,9 @@ int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, 
         if (pre_elu) {
             // the activation's derivative in the GEMM's epilogue (x rides in as the residual operand): no da round trip through HBM
             wv::PwDwArgs f = t;
-            f.Y = dx; f.resid = x; f.res_mode = 2; f.out_scale = pre_scale;
+            f.Y = dx; f.resid = x; f.res_mode = 2; f.out_scale = pre_scale; f.resid2 = dx_add;
             const hipError_t e = wv::launch_pw_dw(f, s);
-            if (e == hipSuccess) fused = true;
+            if (e == hipSuccess) { fused = true; if (added && dx_add) *added = true; }
             else if (e != hipErrorNotSupported) T_LAUNCH(e);
         }
         if (!fused) {
@@ -1093,7 +1130,7 @@ int wv_train_block_create(int C, wv_train_block** out) {
 void wv_train_block_destroy(wv_train_block* b) { delete b; }
 
 size_t wv_train_block_saved_bytes(const wv_train_block* b, int B, int T) {
-    return (b && B > 0 && T > 0) ? 2 * al256((size_t)B * b->h[0]->M * T * 4) : 0;
+    return (b && B > 0 && T > 0) ? 4 * al256((size_t)B * b->h[0]->M * T * 4) : 0;       // u, v and the two 1x1 outputs
 }
 
 size_t wv_train_block_workspace_bytes(const wv_train_block* b, int B, int T) {
@@ -1108,8 +1145,9 @@ int wv_train_block_forward(wv_train_block* b, const float* x, const wv_half_para
     hipStream_t s = (hipStream_t)stream;
     const size_t act = al256((size_t)B * b->h[0]->M * T * 4);
     float* u = (float*)saved; float* v = (float*)((char*)saved + act);
-    int rc = wv_train_half_forward(b->h[0], x, p[0].g_pw, p[0].v_pw, p[0].g_dw, p[0].v_dw, p[0].bias, pre_scale, u, B, T, stream);
-    if (!rc) rc = wv_train_half_forward(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, p[1].bias, 1.f, v, B, T, stream);
+    float* H0 = (float*)((char*)saved + 2 * act); float* H1 = (float*)((char*)saved + 3 * act);
+    int rc = unit_forward_impl(b->h[0], x, p[0].g_pw, p[0].v_pw, p[0].g_dw, p[0].v_dw, p[0].bias, pre_scale, 1, u, H0, B, T, stream);
+    if (!rc) rc = unit_forward_impl(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, p[1].bias, 1.f, 1, v, H1, B, T, stream);
     if (rc) return rc;
     const size_t n4 = (size_t)B * b->h[0]->M * T / 4;
     hipLaunchKernelGGL(wv::axpy_res_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float4*)x, (const float4*)v, (float4*)y,
@@ -1128,6 +1166,7 @@ int wv_train_block_backward(wv_train_block* b, const float* x, const wv_half_par
     const int C = b->h[0]->M;
     const size_t act = al256((size_t)B * C * T * 4), n4 = (size_t)B * C * T / 4;
     const float* u = (const float*)saved; const float* v = (const float*)((const char*)saved + act);
+    const float* H0 = (const float*)((const char*)saved + 2 * act); const float* H1 = (const float*)((const char*)saved + 3 * act);
     float* DV = (float*)ws; float* DU = (float*)((char*)ws + act);
     void* hws = (char*)ws + 2 * act;
     const size_t hws_bytes = ws_bytes - 2 * act;
@@ -1136,12 +1175,13 @@ int wv_train_block_backward(wv_train_block* b, const float* x, const wv_half_par
                        res_scale_param, res_scale, b->partial, n4);
     if (d_res_scale_param) hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, b->partial, wv::RED_BLOCKS, res_scale, d_res_scale_param);
     T_LAUNCH(hipGetLastError());
-    int rc = wv_train_half_backward(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, 1.f, DV, DU, g[1].dg_pw, g[1].dv_pw,
-                                    g[1].dg_dw, g[1].dv_dw, g[1].db, B, T, hws, hws_bytes, stream);
-    if (!rc) rc = wv_train_half_backward(b->h[0], x, p[0].g_pw, p[0].v_pw, p[0].g_dw, p[0].v_dw, pre_scale, DU, dx, g[0].dg_pw, g[0].dv_pw,
-                                         g[0].dg_dw, g[0].dv_dw, g[0].db, B, T, hws, hws_bytes, stream);
+    bool added = false;
+    int rc = unit_backward_impl(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, 1.f, 1, DV, DU, g[1].dg_pw, g[1].dv_pw,
+                                g[1].dg_dw, g[1].dv_dw, g[1].db, B, T, hws, hws_bytes, stream, H1, nullptr, nullptr);
+    if (!rc) rc = unit_backward_impl(b->h[0], x, p[0].g_pw, p[0].v_pw, p[0].g_dw, p[0].v_dw, pre_scale, 1, DU, dx, g[0].dg_pw, g[0].dv_pw,
+                                     g[0].dg_dw, g[0].dv_dw, g[0].db, B, T, hws, hws_bytes, stream, H0, dy, &added);      // + the identity shortcut
     if (rc) return rc;
-    hipLaunchKernelGGL(wv::add_inplace_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (float4*)dx, (const float4*)dy, n4);   // the identity shortcut
+    if (!added) hipLaunchKernelGGL(wv::add_inplace_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (float4*)dx, (const float4*)dy, n4);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }
