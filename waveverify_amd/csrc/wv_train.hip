@@ -290,6 +290,34 @@ static void launch_sum_parts(hipStream_t st, const float* part, float* out, int 
     hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SP_WAVES), 0, st, part, out, S, n);
 }
 
+// The depth-wise stencil's parameter gradients of one channel row in one launch: the per-clip partial sums partial[b][m][0..ks] added
+// over the clips (eight clip groups, fixed order), then db[m] = the bias column and the weight-norm backward of the ks taps
+// (same formulas as wn_bwd_kernel).  Replaces sum_parts + split_dwdb + wn_bwd (three ~5 us launches per unit).
+__global__ __launch_bounds__(256) void dw_param_grads_kernel(const float* __restrict__ partial, const float* __restrict__ g, const float* __restrict__ v,
+                                                              const float* __restrict__ inv_norm, float* __restrict__ dg, float* __restrict__ dv,
+                                                              float* __restrict__ db, int B, int M, int ks) {
+    __shared__ float red[8][32];
+    __shared__ float col[32];
+    const int m = blockIdx.x, tid = threadIdx.x, c = tid & 31, grp = tid >> 5;
+    float a = 0.f;
+    if (c <= ks)
+        for (int b = grp; b < B; b += 8) a += partial[((size_t)b * M + m) * (ks + 1) + c];
+    red[grp][c] = a;
+    __syncthreads();
+    if (tid <= ks) col[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
+    __syncthreads();
+    if (tid == 0) {
+        const float* vr = v + (size_t)m * ks;
+        float dot = 0.f;
+        for (int i = 0; i < ks; ++i) dot = fmaf(col[i], vr[i], dot);
+        const float inv = inv_norm[m];
+        dg[m] = dot * inv;
+        const float aa = g[m] * inv, cc = dot * inv * inv;
+        for (int i = 0; i < ks; ++i) dv[(size_t)m * ks + i] = aa * (col[i] - cc * vr[i]);
+        db[m] = col[ks];
+    }
+}
+
 // tap / bias gradient rows: dwdb[m][0..ks] -> dw_dw[m][ks] and db[m]
 __global__ void split_dwdb_kernel(const float* __restrict__ dwdb, float* __restrict__ dw, float* __restrict__ db, int M, int ks,
                                   float tap_scale = 1.f) {
@@ -1052,7 +1080,9 @@ static int unit_backward_impl(wv_train_unit* h, const float* x, const float* g_p
     const float* H = h_saved ? h_saved : Hws;
     float* partial = (float*)(w + 2 * am + ak);
     float* parts = (float*)(w + 2 * am + ak + al256((size_t)B * M * (ks + 1) * 4));
-    int rc = fold_step(h, g_pw, v_pw, g_dw, v_dw, s);                          // the step's weights (forward ran the same fold)
+    // the step's weights: folded here unless this call continues a forward that kept its 1x1 output (the block's forward folded the
+    // same parameters into the same buffers moments ago)
+    int rc = h_saved ? WV_OK : fold_step(h, g_pw, v_pw, g_dw, v_dw, s);
     if (rc) return rc;
     if (!h_saved) {
         // h = W @ act(s x), recomputed (this forward kept no activations): K1 with the identity stencil
@@ -1064,9 +1094,7 @@ static int unit_backward_impl(wv_train_unit* h, const float* x, const float* g_p
     }
     // dh, and the per-clip partial sums of the tap / bias gradients
     wv::launch_dw_bwd(s, dy, H, h->w_dw, DH, partial, M, B, Tin, Tout, ks, h->stride, h->pad, 0);
-    wv::launch_sum_parts(s, partial, h->dwdb, B, (size_t)M * (ks + 1));
-    hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((M + 255) / 256), dim3(256), 0, s, h->dwdb, h->dw_taps, db, M, ks);
-    hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(M), dim3(256), 0, s, g_dw, v_dw, h->inv_dw, h->dw_taps, dg_dw, dv_dw, ks);
+    hipLaunchKernelGGL(wv::dw_param_grads_kernel, dim3(M), dim3(256), 0, s, partial, g_dw, v_dw, h->inv_dw, dg_dw, dv_dw, db, B, M, ks);
     T_LAUNCH(hipGetLastError());
     if (dx) {
         // da = W^T @ dh on the forward's GEMM kernel, then through the activation
