@@ -155,6 +155,16 @@ struct ConvTrPair {
 };
 
 
+// Buffer descriptor whose words are forced into scalar registers.  The base pointers below are the same for every lane of a workgroup
+// (clip base or tensor base), but the compiler cannot always prove it and then wraps EVERY buffer load / store in a "waterfall" loop
+// (4 v_readfirstlane + 2 v_cmp + exec juggling + a branch; 32-64 of them per K1 epilogue).  Only for wave-uniform arguments.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, int bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 // XCD-aware tile mapping for K1.  Workgroup ids are dealt round-robin over the 8 XCDs (private
 // L2 each), so ids L, L+8, L+16, ... share an L2.  We enumerate, per XCD, the m-tiles of ONE
 // activation tile back to back: the X window is fetched into that L2 once and reused by all

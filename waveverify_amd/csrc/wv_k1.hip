@@ -278,16 +278,16 @@ struct K1Epi {
         if constexpr (EPI == 0) {
             constexpr int NSH = 4 / NT;                          // lane shifts that bring 4 more columns
             const int clip_bytes = nrec;
-            const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(Yb ? Yb : p.Yact, 0, Yb ? clip_bytes : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(Ab ? Ab : p.Yact, 0, Ab ? clip_bytes : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Rb ? Rb : p.X), 0, Rb ? clip_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(Yb ? Yb : p.Yact, Yb ? clip_bytes : 0);
+            const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(Ab ? Ab : p.Yact, Ab ? clip_bytes : 0);
+            const __amdgpu_buffer_rsrc_t rR = uniform_rsrc(Rb ? Rb : p.X, Rb ? clip_bytes : 0);
             const int row_bytes = p.Tout * 4;
             const int voff = voff0;
             const float* Wrow = Wl + (32 * wave + 4 * half) * 8;
             ovec res4[HASR ? 4 : 1];                             // RES 1 / 2 instantiations always have a residual operand
             ovec add4[RES == 2 ? 4 : 1];                         // RES 2: the optional addend (a null one reads zeros: zero-record buffer)
-            const __amdgpu_buffer_rsrc_t rR2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Rb2 ? Rb2 : p.X), 0, Rb2 ? clip_bytes : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(Hb ? Hb : p.Y, 0, Hb ? clip_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rR2 = uniform_rsrc(Rb2 ? Rb2 : p.X, Rb2 ? clip_bytes : 0);
+            const __amdgpu_buffer_rsrc_t rH = uniform_rsrc(Hb ? Hb : p.Y, Hb ? clip_bytes : 0);
             if constexpr (HASR) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) res4[r] = buf_load(rR, voff + ((r & 3) + 8 * (r >> 2)) * row_bytes);
@@ -396,8 +396,8 @@ struct K1Epi {
             constexpr int R = EPI;
             const bool flat = R == 8 && p.flat;
             const int clip_bytes = flat ? nrec : M * p.Tout * 4;
-            const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(Yb ? Yb : p.Yact, 0, Yb ? clip_bytes : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(Ab ? Ab : p.Yact, 0, Ab ? clip_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(Yb ? Yb : p.Yact, Yb ? clip_bytes : 0);
+            const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(Ab ? Ab : p.Yact, Ab ? clip_bytes : 0);
             const int row_bytes = p.Tout * 4;
             const int o0 = R == 2 ? 2 * q : (R == 4 ? q : q >> 1);       // first output of this lane inside the tile
             const bool lane_ok = (R != 8 || (q & 1) == 0) && o0 + (R == 2 ? 1 : 0) < p.tto && to0 + o0 + (R == 2 ? 1 : 0) < p.Tout;
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::B_PER > 1 ? 3 : 4) void stft_k1_ker
     }
     constexpr int NSLOT = C::NTHREADS / C::CG;
     const int clip_bytes = p.F * p.Tf * 4;
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(p.P + (size_t)b * p.F * p.Tf, 0, clip_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = uniform_rsrc(p.P + (size_t)b * p.F * p.Tf, clip_bytes);
     const int tq = t0 + C::NT * i31;                            // Tf % NT == 0: the lane's frames are all in or all out
     const bool lane_ok = tq < p.Tf;
     auto logmag = [&](float re, float im) { return stft_logmag(re, im, p.c1, p.c0); };
