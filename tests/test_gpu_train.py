@@ -135,6 +135,53 @@ def test_block_gradients_vs_oracle(B, C, T, with_param):
         assert abs(float(g["d_res_scale_param"].item()) - ref["d_res_scale_param"]) <= 1e-4 * max(1.0, abs(ref["d_res_scale_param"]))
 
 
+@pytest.mark.parametrize("B,C,T", [(3, 128, 2000), (2, 40, 52)])
+def test_block_backward_paths_agree(B, C, T):
+    """The block keeps its 1x1 outputs from the forward kernel, takes ELU' and the identity shortcut in the dx GEMM's epilogue and writes
+    parameter gradients into caller-provided arena views; the standalone half recomputes the 1x1 output and runs those steps as
+    separate kernels.  Both routes must give the same numbers (wide layer: the LDS-DMA core; narrow ragged one: the round-1 core,
+    where the block falls back to the unfused steps)."""
+    from waveverify_amd.train import TrainBlock, TrainHalf
+    rng = np.random.default_rng(C + T)
+    x, dy = (_cu(rng.standard_normal((B, C, T)).astype(np.float32)) for _ in range(2))
+    ps = [dict(g_pw=_cu((0.5 + np.abs(rng.standard_normal((C, 1, 1)))).astype(np.float32)),
+               v_pw=_cu((rng.standard_normal((C, C, 1)) * C ** -0.5).astype(np.float32)),
+               g_dw=_cu((0.5 + np.abs(rng.standard_normal((C, 1, 1)))).astype(np.float32)),
+               v_dw=_cu((rng.standard_normal((C, 1, 5)) * 0.45).astype(np.float32)),
+               b_dw=_cu((rng.standard_normal(C) * 0.1).astype(np.float32))) for _ in range(2)]
+    pre, rs = 0.8164966, 0.5773503
+    blk = TrainBlock(C)
+    y, saved = blk.forward(x, ps, None, pre, rs)
+    g = blk.backward(x, ps, None, pre, rs, dy, saved)
+    # the same block with destinations inside one flat arena, at offsets that are not multiples of 4 floats
+    sizes = dict(dg_pw=C, dv_pw=C * C, dg_dw=C, dv_dw=C * 5, db_dw=C)
+    arena = torch.full((2 * sum(sizes.values()) + 16,), float("nan"), device="cuda")
+    off, into = 3, dict(halves=[{}, {}])
+    for i in (0, 1):
+        for k, n in sizes.items():
+            into["halves"][i][k] = arena[off:off + n]
+            off += n + 1
+    g_in = blk.backward(x, ps, None, pre, rs, dy, saved, into)
+    assert torch.equal(g_in["dx"], g["dx"])
+    for i in (0, 1):
+        for k in sizes:
+            assert g_in["halves"][i][k].data_ptr() == into["halves"][i][k].data_ptr()
+            assert torch.equal(into["halves"][i][k].reshape(-1), g["halves"][i][k].reshape(-1)), (i, k)
+    # the two halves on their own (recompute route) + the residual arithmetic in torch
+    h1, h2 = TrainHalf(C), TrainHalf(C)
+    u = h1.forward(x, ps[0], pre)
+    v = h2.forward(u, ps[1], 1.0)
+    assert torch.equal(y, x + rs * v) or float((y - (x + rs * v)).abs().max()) <= 1e-6 * float(y.abs().max())
+    g2 = h2.backward(u, ps[1], 1.0, rs * dy)
+    g1 = h1.backward(x, ps[0], pre, g2["dx"])
+    scale = float(g["dx"].abs().max())
+    assert float((g["dx"] - (g1["dx"] + dy)).abs().max()) <= 2e-6 * scale
+    for i, gh in enumerate((g1, g2)):
+        for k in sizes:
+            ref = gh[k].reshape(-1)
+            assert float((g["halves"][i][k].reshape(-1) - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max())), (i, k)
+
+
 # ---- BCE losses ---------------------------------------------------------------------------------------------------------
 def test_bce_losses_vs_reference_classes(golden_dir):
     from waveverify_amd.train import bce_logits

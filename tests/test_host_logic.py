@@ -307,3 +307,18 @@ def test_shard_bounds_cover_and_balance():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         parallel.shard_bounds(4, 2, 2)
+
+
+def test_gradient_destination_views_are_checked():
+    """train._dst: kernels write parameter gradients straight into the caller's arena views -- a view of the wrong size, dtype or
+    layout must be refused on the host (the kernel would otherwise write past it), a missing one falls back to a fresh tensor."""
+    from waveverify_amd.train import _dst
+    arena = torch.zeros(64)
+    good = arena[8:8 + 12].view(3, 4, 1)
+    assert _dst(dict(dv=good), "dv", (3, 4), "cpu") is good                       # same element count, any shape
+    fresh = _dst(None, "dv", (3, 4), "cpu")
+    assert fresh.shape == (3, 4) and fresh.dtype == torch.float32
+    assert _dst(dict(other=good), "dv", (3, 4), "cpu").shape == (3, 4)            # key absent -> fresh tensor
+    for bad in (arena[:11], arena[:24:2], arena[:12].double()):
+        with pytest.raises(ValueError):
+            _dst(dict(dv=bad), "dv", (3, 4), "cpu")
