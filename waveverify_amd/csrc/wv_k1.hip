@@ -150,14 +150,15 @@ struct K1Epi {
     static constexpr int WLD = EPI == 0 ? 8 : NTAP + 4;
     static constexpr int TABLE_FLOATS = C::BM * WLD;
     // RES: 0 none, 1 y = resid + out_scale y, 2 (training) y = y ELU'(out_scale resid) out_scale [+ resid2], 4 (training) no residual,
-    // the raw 1x1 output H is stored next to y (p.Yraw)
-    static constexpr bool HASR = RES == 1 || RES == 2;
+    // the raw 1x1 output H is stored next to y (p.Yraw), 5 (training) as 4 plus p.Ysum = resid + s y, s = out_scale * scale_ptr[0]
+    static constexpr bool HASR = RES == 1 || RES == 2 || RES == 5;
+    static constexpr bool RAWH = RES == 4 || RES == 5;
     static constexpr int RP = HASR ? 4 : 0;                      // residual rows in flight per lane
     typedef typename NVec<NT>::type ovec;
     int M, m0, b, to0, lane, wave, half, q, o, to;
     bool act_lane, vec;
     const float* Rb; float* Yb; float* Ab; float* Wl;
-    const float* Rb2; float* Hb;                                 // RES 2: addend; RES 4: raw 1x1 output
+    const float* Rb2; float* Hb; float* Sb;                      // RES 2: addend; RES 4 / 5: raw 1x1 output; RES 5: residual sum
     int voff0, nrec;                                             // EPI 0: lane's first byte offset (or an out-of-range marker), buffer size
     float fgam, fbet;                                            // EPI 8, flat tiling: this lane's FiLM scalars
 
@@ -212,7 +213,8 @@ struct K1Epi {
         Ab = p.Yact ? p.Yact + bo : nullptr;
         Rb = (HASR && p.resid) ? p.resid + bo : nullptr;
         Rb2 = (RES == 2 && p.resid2) ? p.resid2 + bo : nullptr;
-        Hb = (RES == 4 && p.Yraw) ? p.Yraw + bo : nullptr;
+        Hb = (RAWH && p.Yraw) ? p.Yraw + bo : nullptr;
+        Sb = (RES == 5 && p.Ysum) ? p.Ysum + bo : nullptr;
         o = NT * q; to = to0 + o;
         act_lane = o < p.tto && to < p.Tout;
         vec = act_lane && to + NT - 1 < p.Tout && o + NT - 1 < p.tto && (p.Tout % NT) == 0;
@@ -224,7 +226,7 @@ struct K1Epi {
             const long long gc = gflat + p.pad + o;
             const int bo2 = (int)(gc / p.Tv), t = (int)(gc - (long long)bo2 * p.Tv) - p.pad;
             const bool ok = o < p.tto && bo2 < p.B && t >= 0;
-            Yb = p.Y; Ab = p.Yact; Rb = HASR ? p.resid : nullptr; Rb2 = RES == 2 ? p.resid2 : nullptr; Hb = RES == 4 ? p.Yraw : nullptr;
+            Yb = p.Y; Ab = p.Yact; Rb = HASR ? p.resid : nullptr; Rb2 = RES == 2 ? p.resid2 : nullptr; Hb = RAWH ? p.Yraw : nullptr; Sb = RES == 5 ? p.Ysum : nullptr;
             nrec = (int)((long long)p.B * M * p.Tout * 4);
             voff0 = ok ? (int)((((long long)bo2 * M + m0 + 32 * wave + 4 * half) * p.Tout + t) * 4) : (int)0x80000000u;
         }
@@ -288,6 +290,8 @@ struct K1Epi {
             ovec add4[RES == 2 ? 4 : 1];                         // RES 2: the optional addend (a null one reads zeros: zero-record buffer)
             const __amdgpu_buffer_rsrc_t rR2 = uniform_rsrc(Rb2 ? Rb2 : p.X, Rb2 ? clip_bytes : 0);
             const __amdgpu_buffer_rsrc_t rH = uniform_rsrc(Hb ? Hb : p.Y, Hb ? clip_bytes : 0);
+            const __amdgpu_buffer_rsrc_t rS = uniform_rsrc(Sb ? Sb : p.Y, Sb ? clip_bytes : 0);
+            const float sres = (RES == 5 && p.scale_ptr) ? p.out_scale * p.scale_ptr[0] : p.out_scale;
             if constexpr (HASR) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) res4[r] = buf_load(rR, voff + ((r & 3) + 8 * (r >> 2)) * row_bytes);
@@ -329,14 +333,19 @@ struct K1Epi {
                 }
                 if constexpr (HASR) {
                     const ovec rr = res4[r & 3];
+                    ovec rsum;
+                    (void)rsum;
                     if (r + 4 < 16) res4[r & 3] = buf_load(rR, voff + (((r + 4) & 3) + 8 * ((r + 4) >> 2)) * row_bytes);
 #pragma unroll
                     for (int e = 0; e < NT; ++e) {
                         if constexpr (RES == 2) {                // training: dx = da * ELU'(s x) * s, the residual operand is x, out_scale = s
                             const float z = p.out_scale * rr[e];
                             y[e] = y[e] * (z > 0.f ? 1.f : __expf(z)) * p.out_scale;
+                        } else if constexpr (RES == 5) {         // training forward: the branch output y stays, the block output goes to Ysum
+                            rsum[e] = fmaf(y[e], sres, rr[e]);
                         } else y[e] = fmaf(y[e], p.out_scale, rr[e]);
                     }
+                    if constexpr (RES == 5) buf_store(rS, off, rsum);
                 }
                 if constexpr (RES == 2) {                        // ... + the identity shortcut's gradient
                     const ovec ad = add4[r & 3];
@@ -344,7 +353,7 @@ struct K1Epi {
 #pragma unroll
                     for (int e = 0; e < NT; ++e) y[e] += ad[e];
                 }
-                if constexpr (RES == 4) {                        // the stencil's input at the output's own time: hh[e + 4] = H[t]
+                if constexpr (RAWH) {                            // the stencil's input at the output's own time: hh[e + 4] = H[t]
                     ovec hraw;
 #pragma unroll
                     for (int e = 0; e < NT; ++e) hraw[e] = hh[e + 4];
@@ -663,7 +672,7 @@ bool k1_supported(const PwDwArgs& a) {
     if (a.Y && !aligned16(a.Y)) return false;
     if (a.Yact && !aligned16(a.Yact)) return false;
     if (a.resid && !aligned16(a.resid)) return false;
-    if ((a.resid2 && !aligned16(a.resid2)) || (a.Yraw && !aligned16(a.Yraw))) return false;
+    if ((a.resid2 && !aligned16(a.resid2)) || (a.Yraw && !aligned16(a.Yraw)) || (a.Ysum && !aligned16(a.Ysum))) return false;
     if (a.ks < 1 || a.ks > 16 || (a.ks - 1) * a.dil + 1 + 3 > 64) return false;
     if (a.ct_w && a.ratio == 1) return false;                // degenerate ratio: rare, round-1 path
     return true;
@@ -708,7 +717,7 @@ static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
         }
         return hipErrorInvalidValue;
     }
-    const char* base = a.spec_add ? "spec_add" : (EPI == 0 ? (RES == 2 ? "pw_dw_k5_dact" : RES == 4 ? "pw_dw_k5_h" : RES ? "pw_dw_k5" : "pw_dw_k5_nr") : (EPI == 1 ? "pw_dw" : "pw_dw_s"));
+    const char* base = a.spec_add ? "spec_add" : (EPI == 0 ? (RES == 2 ? "pw_dw_k5_dact" : RES == 4 ? "pw_dw_k5_h" : RES == 5 ? "pw_dw_k5_hres" : RES ? "pw_dw_k5" : "pw_dw_k5_nr") : (EPI == 1 ? "pw_dw" : "pw_dw_s"));
     if (a.pre_elu || a.pre_scale != 1.f) return k1_run<C, EPI, 1, RES>(a, s, base);
     if constexpr (C::NT == 4 && C::BM == 128) {
         // matrix-bound k5 units: deeper DMA pipeline.  Not the strided units: their 8-10 KB row table makes the third stage cost a resident
@@ -726,8 +735,8 @@ static hipError_t k1_pick_epi(const PwDwArgs& a, hipStream_t s, bool k5) {
         return k1_pick_ldr<C, 0, 2>(a, s);
     }
     if (a.Yraw) {                                            // raw 1x1 output next to y (training forward): the k5 DPP epilogue only
-        if (!k5 || res || a.ct_w) return hipErrorNotSupported;
-        return k1_pick_ldr<C, 0, 4>(a, s);
+        if (!k5 || a.ct_w || (res != (a.Ysum != nullptr))) return hipErrorNotSupported;
+        return res ? k1_pick_ldr<C, 0, 5>(a, s) : k1_pick_ldr<C, 0, 4>(a, s);
     }
     if (k5) return res ? k1_pick_ldr<C, 0, true>(a, s) : k1_pick_ldr<C, 0, false>(a, s);
     if constexpr (C::NT == 4) {                              // the net's downsample stencils: ks = 2r, stride r, pad r

@@ -33,6 +33,8 @@ struct PwDwArgs {
     const float* resid;   // [B, M, Tout] or null
     const float* resid2;  // res_mode 2 only: [B, M, Tout] added after the derivative, or null
     float* Yraw;          // training forward, LDS-DMA core with the ks = 5 stencil only: the 1x1 output H [B, M, Tout] stored next to Y, or null
+    float* Ysum;          // with Yraw and resid: [B, M, Tout] = resid + out_scale * scale_ptr[0] * y (the ResnetBlock's output), Y keeps y
+    const float* scale_ptr; // device scalar for Ysum, or null (= 1)
     int res_mode;         // 0: y = resid + out_scale * y;  2 (training, LDS-DMA core only): y = y * ELU'(out_scale * resid) * out_scale
     float* Y;             // [B, M, Tout]
     int B, Tin, Tout, ks, stride, dil, pad;

@@ -1222,7 +1222,7 @@ hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s) {
         const hipError_t e = launch_k1(a, s);
         if (e != hipErrorNotSupported) return e;
     }
-    if (a.res_mode || a.Yraw) return hipErrorNotSupported;   // only the LDS-DMA core has the training epilogues: the caller runs them unfused
+    if (a.res_mode || a.Yraw || a.Ysum) return hipErrorNotSupported;   // only the LDS-DMA core has the training epilogues: the caller runs them unfused
     const int need = (a.ks - 1) * a.dil + 1;            // H columns one output needs
     bool narrow = a.Tin + a.pad + 3 <= 64 && need + 3 <= 64;
     if (!narrow && need + 3 <= 64) {

@@ -1015,8 +1015,13 @@ static wv::PwWeight pack_of(const wv_train_unit* h, bool transposed) {
 
 // h_out (optional, stride-1 units): the 1x1 output H = W act(s x) [B, M, Tin], which the backward otherwise recomputes -- stored by the
 // forward kernel itself next to y where the LDS-DMA core runs the layer, else by one more pass with the identity stencil
+// sum_x / sum_scale_ptr / sum_scale / ysum (optional, with h_out): ysum = sum_x + sum_scale * sum_scale_ptr[0] * y from the same
+// epilogue (the ResnetBlock's output); *summed reports whether the kernel took it (else the caller adds it).
 static int unit_forward_impl(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw, const float* v_dw,
-                             const float* bias, float pre_scale, int pre_elu, float* y, float* h_out, int B, int Tin, void* stream) {
+                             const float* bias, float pre_scale, int pre_elu, float* y, float* h_out, int B, int Tin, void* stream,
+                             const float* sum_x = nullptr, const float* sum_scale_ptr = nullptr, float sum_scale = 1.f, float* ysum = nullptr,
+                             bool* summed = nullptr) {
+    if (summed) *summed = false;
     if (!h || !x || !g_pw || !v_pw || !g_dw || !v_dw || !y || B < 1 || Tin < 1) return tfail(WV_EINVAL, "null / bad argument");
     hipStream_t s = (hipStream_t)stream;
     int rc = fold_step(h, g_pw, v_pw, g_dw, v_dw, s);
@@ -1029,8 +1034,9 @@ static int unit_forward_impl(wv_train_unit* h, const float* x, const float* g_pw
         if (h->stride != 1) return tfail(WV_EINVAL, "saved 1x1 output: stride-1 units only");
         wv::PwDwArgs f = a;
         f.Yraw = h_out;
+        if (ysum && sum_x) { f.resid = sum_x; f.Ysum = ysum; f.scale_ptr = sum_scale_ptr; f.out_scale = sum_scale; }
         const hipError_t e = wv::launch_pw_dw(f, s);
-        if (e == hipSuccess) return WV_OK;
+        if (e == hipSuccess) { if (summed && ysum && sum_x) *summed = true; return WV_OK; }
         if (e != hipErrorNotSupported) T_LAUNCH(e);
         wv::PwDwArgs r = a;                                   // ragged / narrow layers: H by the identity stencil, as the backward used to
         r.dw_w = h->id_taps; r.dw_b = nullptr; r.Y = h_out; r.Tout = Tin; r.ks = 5; r.stride = 1; r.pad = 4;
@@ -1175,11 +1181,14 @@ int wv_train_block_forward(wv_train_block* b, const float* x, const wv_half_para
     float* u = (float*)saved; float* v = (float*)((char*)saved + act);
     float* H0 = (float*)((char*)saved + 2 * act); float* H1 = (float*)((char*)saved + 3 * act);
     int rc = unit_forward_impl(b->h[0], x, p[0].g_pw, p[0].v_pw, p[0].g_dw, p[0].v_dw, p[0].bias, pre_scale, 1, u, H0, B, T, stream);
-    if (!rc) rc = unit_forward_impl(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, p[1].bias, 1.f, 1, v, H1, B, T, stream);
+    bool summed = false;                                       // y = x + s v from the second half's own epilogue where the LDS-DMA core runs it
+    if (!rc) rc = unit_forward_impl(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, p[1].bias, 1.f, 1, v, H1, B, T, stream,
+                                    x, res_scale_param, res_scale, y, &summed);
     if (rc) return rc;
     const size_t n4 = (size_t)B * b->h[0]->M * T / 4;
-    hipLaunchKernelGGL(wv::axpy_res_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float4*)x, (const float4*)v, (float4*)y,
-                       res_scale_param, res_scale, n4);
+    if (!summed)
+        hipLaunchKernelGGL(wv::axpy_res_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float4*)x, (const float4*)v, (float4*)y,
+                           res_scale_param, res_scale, n4);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }
