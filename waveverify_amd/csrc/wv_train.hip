@@ -145,9 +145,17 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ d
 
 // The ResnetBlock stencil (ks = 5, stride 1, T % 4 == 0) four samples per thread: two 16-byte loads of dy give the 8 values dh[t..t+3]
 // needs, two of h the 8 values the tap sums need.
+// FUSE (the ResnetBlock's second half): dy arrives unscaled -- the kernel multiplies it by s = dy_scale * dy_scale_ptr[0] on the way in
+// (what scale_dot_kernel used to write out as a tensor) and also leaves sum(dy * dot_v) of its row in dot_partial[b * M + m]
+// (the gradient of res_scale_param, finished by finish_sum_kernel).
+template <bool FUSE>
 __global__ __launch_bounds__(256) void dw_bwd51_vec_kernel(const float* __restrict__ dy, const float* __restrict__ h, const float* __restrict__ w,
-                                                            float* __restrict__ dh, float* __restrict__ partial, int M, int T) {
-    __shared__ float red[4][6];
+                                                            float* __restrict__ dh, float* __restrict__ partial, int M, int T,
+                                                            const float* __restrict__ dy_scale_ptr, float dy_scale, const float* __restrict__ dot_v,
+                                                            float* __restrict__ dot_partial) {
+    __shared__ float red[4][7];
+    const float sc = FUSE ? (dy_scale_ptr ? dy_scale * dy_scale_ptr[0] : dy_scale) : 1.f;
+    float adot = 0.f;
     const int m = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const size_t row = ((size_t)b * M + m) * T;
     const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy + row);
@@ -157,7 +165,13 @@ __global__ __launch_bounds__(256) void dw_bwd51_vec_kernel(const float* __restri
     const int n4 = T / 4;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int q = tid; q < n4; q += 256) {
-        const f32x4 d0 = dy4[q], d1 = q + 1 < n4 ? dy4[q + 1] : zero;       // dy[t .. t+7]
+        f32x4 d0 = dy4[q], d1 = q + 1 < n4 ? dy4[q + 1] : zero;             // dy[t .. t+7]
+        if (FUSE) {
+            const f32x4 vv = reinterpret_cast<const f32x4*>(dot_v + row)[q];
+            adot += (d0.x * vv.x + d0.y * vv.y) + (d0.z * vv.z + d0.w * vv.w);
+            d0 = f32x4{d0.x * sc, d0.y * sc, d0.z * sc, d0.w * sc};
+            d1 = f32x4{d1.x * sc, d1.y * sc, d1.z * sc, d1.w * sc};
+        }
         const f32x4 hm = q > 0 ? h4[q - 1] : zero, h0 = h4[q];                // h[t-4 .. t+3]
         const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
         const float hv[8] = {hm.x, hm.y, hm.z, hm.w, h0.x, h0.y, h0.z, h0.w};
@@ -173,15 +187,16 @@ __global__ __launch_bounds__(256) void dw_bwd51_vec_kernel(const float* __restri
             a4 = fmaf(dn, hv[e + 4], a4); ab += dn;
         }
     }
-    float acc[6] = {a0, a1, a2, a3, a4, ab};
+    float acc[7] = {a0, a1, a2, a3, a4, ab, adot};
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < (FUSE ? 7 : 6); ++i) {
         float v = acc[i];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if ((tid & 63) == 0) red[tid >> 6][i] = v;
     }
     __syncthreads();
     if (tid < 6) partial[((size_t)b * M + m) * 6 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (FUSE && tid == 6) dot_partial[(size_t)b * M + m] = red[0][6] + red[1][6] + red[2][6] + red[3][6];
 }
 
 // The downsample stencils (ks = 2 r, stride r, pad = r, Tin = r Tout: seanet.py:724-741) one output frame q per thread: the r samples
@@ -243,12 +258,21 @@ __global__ __launch_bounds__(256) void dw_bwd_down_kernel(const float* __restric
     if (tid <= KS) partial[((size_t)b * M + m) * (KS + 1) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
+// can the ResnetBlock's second half take its upstream gradient unscaled (dw_bwd51_vec_kernel<true>)?
+static bool dw_bwd_can_fuse_scale(const float* dy, const float* h, const float* dh, const float* v, int T) {
+    return (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+}
+
 static void launch_dw_bwd(hipStream_t s, const float* dy, const float* h, const float* w, float* dh, float* partial, int M, int B, int Tin,
-                          int Tout, int ks, int stride, int pad, int h_shared) {
+                          int Tout, int ks, int stride, int pad, int h_shared, const float* dy_scale_ptr = nullptr, float dy_scale = 1.f,
+                          const float* dot_v = nullptr, float* dot_partial = nullptr) {
 #define WV_DWB(K, S) hipLaunchKernelGGL((dw_bwd_kernel<K, S>), dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tin, Tout, ks, stride, pad, h_shared)
     const bool al16 = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(dh)) & 15) == 0;
-    if (ks == 5 && stride == 1 && pad == 4 && dh && !h_shared && Tin == Tout && (Tin & 3) == 0 && al16)
-        hipLaunchKernelGGL(dw_bwd51_vec_kernel, dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tin);
+    if (dot_partial)                                         // caller checked dw_bwd_can_fuse_scale
+        hipLaunchKernelGGL((dw_bwd51_vec_kernel<true>), dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tin, dy_scale_ptr, dy_scale, dot_v, dot_partial);
+    else if (ks == 5 && stride == 1 && pad == 4 && dh && !h_shared && Tin == Tout && (Tin & 3) == 0 && al16)
+        hipLaunchKernelGGL((dw_bwd51_vec_kernel<false>), dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tin, (const float*)nullptr, 1.f,
+                           (const float*)nullptr, (float*)nullptr);
     else if (dh && !h_shared && ks == 2 * stride && pad == stride && (long long)Tout * stride == Tin && (stride % 4 != 0 || al16) &&
              (stride == 2 || stride == 4 || stride == 5 || stride == 8)) {
 #define WV_DWD(R) hipLaunchKernelGGL((dw_bwd_down_kernel<R>), dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tout)
@@ -1061,7 +1085,8 @@ int wv_train_half_forward(wv_train_unit* h, const float* x, const float* g_pw, c
 static int unit_backward_impl(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
                               const float* v_dw, float pre_scale, int pre_elu, const float* dy, float* dx, float* dg_pw, float* dv_pw,
                               float* dg_dw, float* dv_dw, float* db, int B, int Tin, void* ws, size_t ws_bytes, void* stream,
-                              const float* h_saved, const float* dx_add, bool* added);
+                              const float* h_saved, const float* dx_add, bool* added, const float* dy_scale_ptr = nullptr, float dy_scale = 1.f,
+                              const float* dot_v = nullptr, float* dot_partial = nullptr);
 
 int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
                            const float* v_dw, float pre_scale, int pre_elu, const float* dy, float* dx, float* dg_pw, float* dv_pw,
@@ -1073,7 +1098,8 @@ int wv_train_unit_backward(wv_train_unit* h, const float* x, const float* g_pw, 
 static int unit_backward_impl(wv_train_unit* h, const float* x, const float* g_pw, const float* v_pw, const float* g_dw,
                               const float* v_dw, float pre_scale, int pre_elu, const float* dy, float* dx, float* dg_pw, float* dv_pw,
                               float* dg_dw, float* dv_dw, float* db, int B, int Tin, void* ws, size_t ws_bytes, void* stream,
-                              const float* h_saved, const float* dx_add, bool* added) {
+                              const float* h_saved, const float* dx_add, bool* added, const float* dy_scale_ptr, float dy_scale,
+                              const float* dot_v, float* dot_partial) {
     if (added) *added = false;
     if (!h || !x || !g_pw || !v_pw || !g_dw || !v_dw || !dy || !dg_pw || !dv_pw || !dg_dw || !dv_dw || !db)
         return tfail(WV_EINVAL, "null argument");
@@ -1099,7 +1125,7 @@ static int unit_backward_impl(wv_train_unit* h, const float* x, const float* g_p
         T_LAUNCH(wv::launch_pw_dw(a, s));
     }
     // dh, and the per-clip partial sums of the tap / bias gradients
-    wv::launch_dw_bwd(s, dy, H, h->w_dw, DH, partial, M, B, Tin, Tout, ks, h->stride, h->pad, 0);
+    wv::launch_dw_bwd(s, dy, H, h->w_dw, DH, partial, M, B, Tin, Tout, ks, h->stride, h->pad, 0, dy_scale_ptr, dy_scale, dot_v, dot_partial);
     hipLaunchKernelGGL(wv::dw_param_grads_kernel, dim3(M), dim3(256), 0, s, partial, g_dw, v_dw, h->inv_dw, dg_dw, dv_dw, db, B, M, ks);
     T_LAUNCH(hipGetLastError());
     if (dx) {
@@ -1207,14 +1233,27 @@ int wv_train_block_backward(wv_train_block* b, const float* x, const wv_half_par
     float* DV = (float*)ws; float* DU = (float*)((char*)ws + act);
     void* hws = (char*)ws + 2 * act;
     const size_t hws_bytes = ws_bytes - 2 * act;
-    // dv = s * dy, d(res_scale_param) = res_scale * sum(dy * v)
-    hipLaunchKernelGGL(wv::scale_dot_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, (const float4*)dy, (const float4*)v, (float4*)DV,
-                       res_scale_param, res_scale, b->partial, n4);
-    if (d_res_scale_param) hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, b->partial, wv::RED_BLOCKS, res_scale, d_res_scale_param);
-    T_LAUNCH(hipGetLastError());
-    bool added = false;
-    int rc = unit_backward_impl(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, 1.f, 1, DV, DU, g[1].dg_pw, g[1].dv_pw,
+    // dv = s * dy, d(res_scale_param) = res_scale * sum(dy * v): inside the second half's stencil backward when the operands are 16-byte
+    // aligned (dy is scaled on the way in, the dot leaves one partial per (clip, channel) row in the otherwise unused DV region), else
+    // by a pass of their own
+    const bool fuse = wv::dw_bwd_can_fuse_scale(dy, H1, (const float*)hws, v, T);
+    int rc;
+    if (fuse) {
+        rc = unit_backward_impl(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, 1.f, 1, dy, DU, g[1].dg_pw, g[1].dv_pw,
+                                g[1].dg_dw, g[1].dv_dw, g[1].db, B, T, hws, hws_bytes, stream, H1, nullptr, nullptr, res_scale_param, res_scale, v, DV);
+        if (!rc && d_res_scale_param) {
+            hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, DV, B * C, res_scale, d_res_scale_param);
+            T_LAUNCH(hipGetLastError());
+        }
+    } else {
+        hipLaunchKernelGGL(wv::scale_dot_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, (const float4*)dy, (const float4*)v, (float4*)DV,
+                           res_scale_param, res_scale, b->partial, n4);
+        if (d_res_scale_param) hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, b->partial, wv::RED_BLOCKS, res_scale, d_res_scale_param);
+        T_LAUNCH(hipGetLastError());
+        rc = unit_backward_impl(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, 1.f, 1, DV, DU, g[1].dg_pw, g[1].dv_pw,
                                 g[1].dg_dw, g[1].dv_dw, g[1].db, B, T, hws, hws_bytes, stream, H1, nullptr, nullptr);
+    }
+    bool added = false;
     if (!rc) rc = unit_backward_impl(b->h[0], x, p[0].g_pw, p[0].v_pw, p[0].g_dw, p[0].v_dw, pre_scale, 1, DU, dx, g[0].dg_pw, g[0].dv_pw,
                                      g[0].dg_dw, g[0].dv_dw, g[0].db, B, T, hws, hws_bytes, stream, H0, dy, &added);      // + the identity shortcut
     if (rc) return rc;
