@@ -681,6 +681,78 @@ __global__ __launch_bounds__(256) void convtr_fwd_kernel(const float* __restrict
     }
 }
 
+// The same, one INPUT frame l per thread (R = the ratio at compile time): a[l] is activated once (the per-output form above evaluates two
+// exponentials per output sample), the R outputs u[l R .. l R + R - 1] = a[l] w[0..R) + a[l-1] w[R..2R) leave as 16-byte stores when
+// R % 4 == 0.  Same arithmetic per output (product, then one fma).
+template <int R>
+__global__ __launch_bounds__(256) void convtr_fwd_frame_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ u,
+                                                                int K, int Tin, float s, int elu) {
+    const int k = blockIdx.x, b = blockIdx.y;
+    const float* xr = x + ((size_t)b * K + k) * Tin;
+    float* ur = u + ((size_t)b * K + k) * Tin * R;
+    float wt[2 * R];
+#pragma unroll
+    for (int j = 0; j < 2 * R; ++j) wt[j] = w[(size_t)k * 2 * R + j];
+    for (int l = threadIdx.x; l < Tin; l += 256) {
+        float a0 = s * xr[l], a1 = l > 0 ? s * xr[l - 1] : 0.f;
+        if (elu) { a0 = a0 > 0.f ? a0 : (__expf(a0) - 1.f); a1 = a1 > 0.f ? a1 : (__expf(a1) - 1.f); }
+        float v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = l > 0 ? fmaf(a1, wt[j + R], a0 * wt[j]) : a0 * wt[j];
+        if constexpr (R % 4 == 0) {
+#pragma unroll
+            for (int c = 0; c < R / 4; ++c) reinterpret_cast<f32x4*>(ur)[l * (R / 4) + c] = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) ur[l * R + j] = v[j];
+        }
+    }
+}
+
+// ... and its backward per input frame: the 2R gradients du[l R .. l R + 2R - 1] that meet a[l] are this frame's R samples and the next
+// frame's (zero past the end); one exponential per frame serves both the activation and its derivative.
+template <int R>
+__global__ __launch_bounds__(256) void convtr_bwd_frame_kernel(const float* __restrict__ du, const float* __restrict__ x, const float* __restrict__ w,
+                                                                float* __restrict__ dx, float* __restrict__ partial, int K, int Tin, float s, int elu) {
+    constexpr int KS = 2 * R;
+    __shared__ float red[4][KS];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* dur = du + ((size_t)b * K + k) * Tin * R;
+    const float* xr = x + ((size_t)b * K + k) * Tin;
+    float wt[KS], acc[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) { wt[j] = w[(size_t)k * KS + j]; acc[j] = 0.f; }
+    for (int l = tid; l < Tin; l += 256) {
+        const float z = s * xr[l];
+        const float e = (elu && !(z > 0.f)) ? __expf(z) : 1.f;
+        const float a = (!elu || z > 0.f) ? z : (e - 1.f);
+        float d[KS];
+        if constexpr (R % 4 == 0) {
+#pragma unroll
+            for (int c = 0; c < KS / 4; ++c) {
+                const bool in = c < R / 4 || l + 1 < Tin;
+                const f32x4 v = in ? reinterpret_cast<const f32x4*>(dur)[l * (R / 4) + c] : f32x4{0.f, 0.f, 0.f, 0.f};
+                d[4 * c] = v[0]; d[4 * c + 1] = v[1]; d[4 * c + 2] = v[2]; d[4 * c + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) d[j] = (j < R || l + 1 < Tin) ? dur[l * R + j] : 0.f;
+        }
+        float g = 0.f;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) { g = fmaf(wt[j], d[j], g); acc[j] = fmaf(a, d[j], acc[j]); }
+        if (dx) dx[((size_t)b * K + k) * Tin + l] = g * ((!elu || z > 0.f) ? 1.f : e) * s;
+    }
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        float v = acc[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((tid & 63) == 0) red[tid >> 6][j] = v;
+    }
+    __syncthreads();
+    if (tid < KS) partial[((size_t)b * K + k) * KS + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 // backward: da[l] = sum_{j < 2r, l r + j < Tout} w[j] du[l r + j];  dx[l] = da[l] act'(s x[l]) s;
 // partial[b][k][j] = sum_l a[l] du[l r + j]   (2r <= TRAIN_MAX_KS taps)
 __global__ __launch_bounds__(256) void convtr_bwd_kernel(const float* __restrict__ du, const float* __restrict__ x, const float* __restrict__ w,
@@ -767,6 +839,54 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__
         const int src = tid < ks ? tid : TRAIN_MAX_KS;
         partial[((size_t)b * C + c) * (ks + 1) + tid] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
     }
+}
+
+// The same for ks = 5 (the net's tail), four samples per thread: h[t..t+3] is activated ONCE per sample (the per-tap form above evaluates
+// ks + 1 exponentials per sample) and serves the derivative, and every tap sum takes its term from the sample's side:
+//     dh[t] = post ELU'(z_t) sum_i w[i] dq[t + 4 - i],   dw[i] += dq[t + 4 - i] ELU(z_t),   db += dq[t]   (dq = 0 past T)
+// Needs T % 4 == 0, Tin % 4 == 0 and 16-byte aligned rows.
+__global__ __launch_bounds__(256) void tail_bwd5_vec_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ delta,
+                                                             const float* __restrict__ dd, float* __restrict__ dh, float* __restrict__ partial,
+                                                             int C, int Tin, int T, float post, float wav_std) {
+    __shared__ float red[4][6];
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const size_t row = ((size_t)b * C + c) * Tin;
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + row);
+    const f32x4* dd4 = reinterpret_cast<const f32x4*>(dd + (size_t)b * T);
+    const f32x4* de4 = reinterpret_cast<const f32x4*>(delta + (size_t)b * T);
+    const float w0 = w[c * 5], w1 = w[c * 5 + 1], w2 = w[c * 5 + 2], w3 = w[c * 5 + 3], w4 = w[c * 5 + 4];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n4 = Tin / 4, m4 = T / 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int q = tid; q < n4; q += 256) {
+        const f32x4 hv = h4[q];
+        const f32x4 da = q < m4 ? dd4[q] : zero, db = q + 1 < m4 ? dd4[q + 1] : zero;
+        const f32x4 ea = q < m4 ? de4[q] : zero, eb = q + 1 < m4 ? de4[q + 1] : zero;
+        float dq[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dq[e] = da[e] * (1.f - ea[e] * ea[e]) * wav_std; dq[4 + e] = db[e] * (1.f - eb[e] * eb[e]) * wav_std; }
+        f32x4 g4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float z = post * hv[e];
+            const float ex = z > 0.f ? 1.f : __expf(z), a = z > 0.f ? z : (ex - 1.f);
+            float g = w0 * dq[e + 4];
+            g = fmaf(w1, dq[e + 3], g); g = fmaf(w2, dq[e + 2], g); g = fmaf(w3, dq[e + 1], g); g = fmaf(w4, dq[e], g);
+            g4[e] = g * ex * post;
+            acc[0] = fmaf(dq[e + 4], a, acc[0]); acc[1] = fmaf(dq[e + 3], a, acc[1]); acc[2] = fmaf(dq[e + 2], a, acc[2]);
+            acc[3] = fmaf(dq[e + 1], a, acc[3]); acc[4] = fmaf(dq[e], a, acc[4]);
+            acc[5] += dq[e];
+        }
+        reinterpret_cast<f32x4*>(dh + row)[q] = g4;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float v = acc[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((tid & 63) == 0) red[tid >> 6][i] = v;
+    }
+    __syncthreads();
+    if (tid < 6) partial[((size_t)b * C + c) * 6 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
 // ---- message MLP + FiLM (seanet.py:518-550,831-846,905-966) -------------------------------------------------------------------------
@@ -1737,7 +1857,13 @@ int wv_train_up_backward(wv_train_up* h, const float* x, const float* g_ct, cons
     float* parts = (float*)(w + 2 * au + al256((size_t)B * std::max(K * ks, M * 2) * 4));
     int rc = up_fold(h, g_ct, v_ct, g_pw, v_pw, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(wv::convtr_fwd_kernel, dim3(K, B), dim3(256), 0, s, x, h->w_ct, U, K, Tin, r, pre_scale, pre_elu);
+    {
+        const bool al = (reinterpret_cast<uintptr_t>(U) & 15) == 0;
+#define WV_CTF(R) hipLaunchKernelGGL((wv::convtr_fwd_frame_kernel<R>), dim3(K, B), dim3(256), 0, s, x, h->w_ct, U, K, Tin, pre_scale, pre_elu)
+        if (r == 2) WV_CTF(2); else if (r == 4 && al) WV_CTF(4); else if (r == 5) WV_CTF(5); else if (r == 8 && al) WV_CTF(8);
+        else hipLaunchKernelGGL(wv::convtr_fwd_kernel, dim3(K, B), dim3(256), 0, s, x, h->w_ct, U, K, Tin, r, pre_scale, pre_elu);
+#undef WV_CTF
+    }
     // db = sum dy;  dW = sum dy u^T
     wv::launch_dw_bwd(s, dy, dy, h->junk, (float*)nullptr, partial, M, B, Tout, Tout, 1, 1, 0, 0);
     wv::launch_sum_parts(s, partial, h->scr, B, (size_t)M * 2);
@@ -1755,7 +1881,13 @@ int wv_train_up_backward(wv_train_up* h, const float* x, const float* g_ct, cons
     t.pre_scale = 1.f; t.pre_elu = 0; t.out_scale = 1.f; t.bands = 1; t.film_stride = 2;
     T_LAUNCH(wv::launch_pw_dw(t, s));
     // through the transposed conv and the activation
-    hipLaunchKernelGGL(wv::convtr_bwd_kernel, dim3(K, B), dim3(256), 0, s, DU, x, h->w_ct, dx, partial, K, Tin, r, pre_scale, pre_elu);
+    {
+        const bool al = (reinterpret_cast<uintptr_t>(DU) & 15) == 0;
+#define WV_CTB(R) hipLaunchKernelGGL((wv::convtr_bwd_frame_kernel<R>), dim3(K, B), dim3(256), 0, s, DU, x, h->w_ct, dx, partial, K, Tin, pre_scale, pre_elu)
+        if (r == 2) WV_CTB(2); else if (r == 4 && al) WV_CTB(4); else if (r == 5) WV_CTB(5); else if (r == 8 && al) WV_CTB(8);
+        else hipLaunchKernelGGL(wv::convtr_bwd_kernel, dim3(K, B), dim3(256), 0, s, DU, x, h->w_ct, dx, partial, K, Tin, r, pre_scale, pre_elu);
+#undef WV_CTB
+    }
     wv::launch_sum_parts(s, partial, h->taps, B, (size_t)K * ks);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(K), dim3(256), 0, s, g_ct, v_ct, h->inv_ct, h->taps, dg_ct, dv_ct, ks);
     T_LAUNCH(hipGetLastError());
@@ -1808,7 +1940,11 @@ int wv_train_tail_backward(wv_train_tail* h, const float* x, const float* g, con
     const int C = h->C, ks = h->ks;
     hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(1), dim3(256), 0, s, g, v, h->w, h->inv, (float*)nullptr, (float*)nullptr, 1, C * ks, 0, 0,
                        (const float*)nullptr, 1.f, (float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(wv::tail_bwd_kernel, dim3(C, B), dim3(256), 0, s, x, h->w, delta, d_delta, dx, (float*)ws, C, Tin, T, ks, post, wav_std);
+    if (ks == 5 && (T & 3) == 0 && (Tin & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(delta) | reinterpret_cast<uintptr_t>(d_delta) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0)
+        hipLaunchKernelGGL(wv::tail_bwd5_vec_kernel, dim3(C, B), dim3(256), 0, s, x, h->w, delta, d_delta, dx, (float*)ws, C, Tin, T, post, wav_std);
+    else
+        hipLaunchKernelGGL(wv::tail_bwd_kernel, dim3(C, B), dim3(256), 0, s, x, h->w, delta, d_delta, dx, (float*)ws, C, Tin, T, ks, post, wav_std);
     wv::launch_sum_parts(s, (const float*)ws, h->dwdb, B, (size_t)C * (ks + 1));
     hipLaunchKernelGGL(wv::split_dwdb_kernel, dim3((C + 255) / 256), dim3(256), 0, s, h->dwdb, h->taps, h->dbv, C, ks, 1.f);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(1), dim3(256), 0, s, g, v, h->inv, h->taps, dg, dv, C * ks);
