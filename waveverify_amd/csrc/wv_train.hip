@@ -537,18 +537,18 @@ __global__ __launch_bounds__(256) void scale_dot_kernel(const float4* __restrict
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-// one wave: lane l adds its contiguous run of the partials in double, lane 0 adds the 64 lane sums in lane order (fixed order, 64
-// threads required)
-__global__ __launch_bounds__(64) void finish_sum_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
-    __shared__ double red[64];
-    const int lane = threadIdx.x, per = (n + 63) / 64;
+// 256 threads: thread i adds its contiguous run of the partials in double, thread 0 adds the 256 thread sums in thread order (fixed order)
+constexpr int FIN_T = 256;
+__global__ __launch_bounds__(FIN_T) void finish_sum_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
+    __shared__ double red[FIN_T];
+    const int tid = threadIdx.x, per = (n + FIN_T - 1) / FIN_T;
     double a = 0.0;
-    for (int i = lane * per, e = min(n, (lane + 1) * per); i < e; ++i) a += (double)partial[i];
-    red[lane] = a;
+    for (int i = tid * per, e = min(n, (tid + 1) * per); i < e; ++i) a += (double)partial[i];
+    red[tid] = a;
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
         double t = 0.0;
-        for (int k = 0; k < 64; ++k) t += red[k];
+        for (int k = 0; k < FIN_T; ++k) t += red[k];
         out[0] = (float)(t * (double)scale);
     }
 }
@@ -578,6 +578,14 @@ __global__ __launch_bounds__(256) void convpre_dx_kernel(const float* __restrict
     dx[(size_t)b * T + t] = acc * in_scale;
 }
 
+// partial[block] = sum over the block's grid-stride elements of a[i] * b[i]  (RED_BLOCKS blocks, then finish_sum_kernel: fixed order)
+__global__ __launch_bounds__(256) void dot_parts_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)RED_BLOCKS * 256) acc = fmaf(a[i], b[i], acc);
+    const float t = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
 // out[0] = scale * sum_i a[i] * b[i]  (one workgroup, fixed order);  buf *= res_s(param, res_scale)
 __global__ __launch_bounds__(256) void dot_small_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, float scale,
                                                          float* __restrict__ out) {
@@ -1362,13 +1370,13 @@ int wv_train_block_backward(wv_train_block* b, const float* x, const wv_half_par
         rc = unit_backward_impl(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, 1.f, 1, dy, DU, g[1].dg_pw, g[1].dv_pw,
                                 g[1].dg_dw, g[1].dv_dw, g[1].db, B, T, hws, hws_bytes, stream, H1, nullptr, nullptr, res_scale_param, res_scale, v, DV);
         if (!rc && d_res_scale_param) {
-            hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, DV, B * C, res_scale, d_res_scale_param);
+            hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(wv::FIN_T), 0, s, DV, B * C, res_scale, d_res_scale_param);
             T_LAUNCH(hipGetLastError());
         }
     } else {
         hipLaunchKernelGGL(wv::scale_dot_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, (const float4*)dy, (const float4*)v, (float4*)DV,
                            res_scale_param, res_scale, b->partial, n4);
-        if (d_res_scale_param) hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, b->partial, wv::RED_BLOCKS, res_scale, d_res_scale_param);
+        if (d_res_scale_param) hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(wv::FIN_T), 0, s, b->partial, wv::RED_BLOCKS, res_scale, d_res_scale_param);
         T_LAUNCH(hipGetLastError());
         rc = unit_backward_impl(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, 1.f, 1, DV, DU, g[1].dg_pw, g[1].dv_pw,
                                 g[1].dg_dw, g[1].dv_dw, g[1].db, B, T, hws, hws_bytes, stream, H1, nullptr, nullptr);
@@ -1393,7 +1401,7 @@ int wv_train_bce_logits(const float* logits, const float* mask, const float* msg
     const size_t n = (size_t)B * Cz * T;
     hipLaunchKernelGGL(wv::bce_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, logits, mask, msg, dlogits, (float*)ws,
                        grad_scale / (float)n, Cz, T, n);
-    hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, wv::RED_BLOCKS, 1.f / (float)n, loss);
+    hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(wv::FIN_T), 0, s, (const float*)ws, wv::RED_BLOCKS, 1.f / (float)n, loss);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }
@@ -1532,7 +1540,12 @@ int wv_train_spec_backward(wv_train_spec* h, const float* P, const float* g, con
     // G = sum_{b,t} dy P^T;  d scale_param = res_scale * <W, G>  (= res_scale * sum dy . (W @ P));  dW = s * G
     T_LAUNCH(wv::launch_gemm_nt(s, dy, P, (float*)ws, 1.f, 0, B, C, F, T, S, np_.TC));
     wv::launch_sum_parts(s, (const float*)ws, h->dW, S, n);
-    if (d_scale_param) hipLaunchKernelGGL(wv::dot_small_kernel, dim3(1), dim3(256), 0, s, h->w, h->dW, n, res_scale, d_scale_param);
+    if (d_scale_param) {
+        if (ws_bytes >= wv::RED_BLOCKS * sizeof(float)) {        // the split partials have been summed: their buffer takes the dot's partials
+            hipLaunchKernelGGL(wv::dot_parts_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, h->w, h->dW, n, (float*)ws);
+            hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(wv::FIN_T), 0, s, (const float*)ws, wv::RED_BLOCKS, res_scale, d_scale_param);
+        } else hipLaunchKernelGGL(wv::dot_small_kernel, dim3(1), dim3(256), 0, s, h->w, h->dW, n, res_scale, d_scale_param);
+    }
     hipLaunchKernelGGL(wv::scale_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dW, n, scale_param, res_scale);
     hipLaunchKernelGGL(wv::wn_bwd_kernel, dim3(C), dim3(256), 0, s, g, v, h->inv, h->dW, dg, dv, F);
     T_LAUNCH(hipGetLastError());
@@ -2016,7 +2029,7 @@ int wv_train_l1(const float* a, const float* b, float* loss, float* da, float gr
     if (!ws || ws_bytes < wv_train_bce_workspace_bytes()) return tfail(WV_ENOMEM, "workspace too small");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(wv::l1_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, a, b, da, (float*)ws, grad_scale / (float)n, n);
-    hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, wv::RED_BLOCKS, 1.f / (float)n, loss);
+    hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(wv::FIN_T), 0, s, (const float*)ws, wv::RED_BLOCKS, 1.f / (float)n, loss);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }
@@ -2027,7 +2040,7 @@ int wv_train_sumsq(const float* g, size_t n, float* out, void* ws, size_t ws_byt
     if (!ws || ws_bytes < wv_train_bce_workspace_bytes()) return tfail(WV_ENOMEM, "workspace too small");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(wv::sumsq_kernel, dim3(wv::RED_BLOCKS), dim3(256), 0, s, g, n, (float*)ws);
-    hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, wv::RED_BLOCKS, 1.f, out);
+    hipLaunchKernelGGL(wv::finish_sum_kernel, dim3(1), dim3(wv::FIN_T), 0, s, (const float*)ws, wv::RED_BLOCKS, 1.f, out);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }
