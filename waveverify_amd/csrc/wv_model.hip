@@ -484,7 +484,8 @@ WsLayout layout(const wv_model* m, int B, int T) {
 // Does a ResnetBlock of C channels want its input pre-activated by the producer (second output, one more HBM
 // write pass) or does its first unit apply scale -> ELU itself while staging through registers?  Narrow layers
 // (one m-tile: no redundant activation work, and they are bandwidth-bound) activate themselves.
-// Measured (one box, interleaved): self-activation wins up to C = 128 (-1.8 ms/step), the producer-side copy from C = 129 up.
+// Measured (one box, interleaved): self-activation wins up to C = 128 (-1.8 ms/step), the producer-side copy from C = 129 up;
+// re-measured after the epilogues lost their waterfall loops: thresholds 129 / 97 / 65 / 0 -> 81.2 / 82.1 / 82.5 / 83.7 ms per step.
 inline bool wants_act_copy(int C) { return C >= 129; }
 
 struct Stream {
