@@ -113,7 +113,12 @@ def test_block_gradients_vs_reference_autograd(golden_dir, tag):
         assert abs(float(g["d_res_scale_param"].item()) - ref) <= 1e-4 * max(1.0, abs(ref))
 
 
-@pytest.mark.parametrize("B,C,T,with_param", [(4, 128, 1000, True), (2, 64, 16000, False), (3, 192, 400, True)])
+@pytest.mark.parametrize("B,C,T,with_param", [(4, 128, 1000, True), (2, 64, 16000, False), (3, 192, 400, True),
+                                               # the fused epilogues (saved 1x1 output, residual sum, ELU' + shortcut in the dx GEMM) on every tiling the
+                                               # launcher picks: one clip (per-clip tiles), K >= 256 (three DMA stages), 96-row tiles, a padded
+                                               # 160-channel layer, flat tiles at T = 400 / 2000, a narrow ragged layer on the round-1 core
+                                               (1, 128, 2000, True), (2, 256, 400, True), (5, 96, 2000, False), (2, 160, 1000, True),
+                                               (3, 512, 52, True), (2, 40, 36, False)])
 def test_block_gradients_vs_oracle(B, C, T, with_param):
     rng = np.random.default_rng(B * 77 + C + T)
     x = rng.standard_normal((B, C, T)).astype(np.float32)
