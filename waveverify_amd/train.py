@@ -219,11 +219,12 @@ class TrainConvPre(_Handle):
                                                        y.data_ptr(), B, T, TrainHalf._stream()), "wv_train_convpre_forward")
         return y
 
-    def backward(self, x, p, in_scale: float, dy, need_dx: bool = False):
+    def backward(self, x, p, in_scale: float, dy, need_dx: bool = False, into=None):
         x, dy = _f(x), _f(dy)
         B, _, T = x.shape
         g, v = _f(p["g"]).reshape(self.C), _f(p["v"]).reshape(self.C, self.ks)
-        out = dict(dx=torch.empty_like(x) if need_dx else None, dg=torch.empty_like(g), dv=torch.empty_like(v), db=torch.empty_like(g))
+        d = x.device
+        out = dict(dx=torch.empty_like(x) if need_dx else None, dg=_dst(into, "dg", g.shape, d), dv=_dst(into, "dv", v.shape, d), db=_dst(into, "db", g.shape, d))
         ws = torch.empty(int(self._lib.wv_train_convpre_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=x.device)
         self._check(self._lib.wv_train_convpre_backward(
             self._h, x.data_ptr(), g.data_ptr(), v.data_ptr(), float(in_scale), dy.data_ptr(), out["dx"].data_ptr() if need_dx else None,
@@ -291,12 +292,13 @@ class TrainConvPost(_Handle):
                     "wv_train_convpost_forward")
         return y
 
-    def backward(self, x, p, dy):
+    def backward(self, x, p, dy, into=None):
         x, dy = _f(x), _f(dy)
         B, _, T = x.shape
         g_dw, v_dw, g_pw, v_pw, b = self._p(p)
-        out = dict(dx=torch.empty_like(x), dg_dw=torch.empty_like(g_dw), dv_dw=torch.empty_like(v_dw), dg_pw=torch.empty_like(g_pw),
-                   dv_pw=torch.empty_like(v_pw), db=torch.empty_like(b))
+        d = x.device
+        out = dict(dx=torch.empty_like(x), dg_dw=_dst(into, "dg_dw", g_dw.shape, d), dv_dw=_dst(into, "dv_dw", v_dw.shape, d),
+                   dg_pw=_dst(into, "dg_pw", g_pw.shape, d), dv_pw=_dst(into, "dv_pw", v_pw.shape, d), db=_dst(into, "db", b.shape, d))
         ws = torch.empty(int(self._lib.wv_train_convpost_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=x.device)
         self._check(self._lib.wv_train_convpost_backward(
             self._h, x.data_ptr(), g_dw.data_ptr(), v_dw.data_ptr(), g_pw.data_ptr(), v_pw.data_ptr(), b.data_ptr(), int(self.l2norm), dy.data_ptr(),
@@ -332,12 +334,13 @@ class TrainHead(_Handle):
                     "wv_train_head_forward")
         return logits
 
-    def backward(self, z, p, dlogits):
+    def backward(self, z, p, dlogits, into=None):
         z, dl = _f(z), _f(dlogits)
         B, _, N = z.shape
         w_rev, b_rev, w_last, _ = self._p(p)
-        out = dict(dz=torch.empty_like(z), dw_rev=torch.empty_like(w_rev), db_rev=torch.empty_like(b_rev), dw_last=torch.empty_like(w_last),
-                   db_last=torch.empty(self.nb, device=z.device))
+        d = z.device
+        out = dict(dz=torch.empty_like(z), dw_rev=_dst(into, "dw_rev", w_rev.shape, d), db_rev=_dst(into, "db_rev", b_rev.shape, d),
+                   dw_last=_dst(into, "dw_last", w_last.shape, d), db_last=_dst(into, "db_last", (self.nb,), d))
         ws = self._ws(B, N, z.device)
         self._check(self._lib.wv_train_head_backward(
             self._h, z.data_ptr(), w_rev.data_ptr(), b_rev.data_ptr(), w_last.data_ptr(), dl.data_ptr(), out["dz"].data_ptr(),
@@ -369,12 +372,13 @@ class TrainUp(_Handle):
                     "wv_train_up_forward")
         return y
 
-    def backward(self, x, p, pre_scale: float, dy, pre_elu: bool = True):
+    def backward(self, x, p, pre_scale: float, dy, pre_elu: bool = True, into=None):
         x, dy = _f(x), _f(dy)
         B, _, T = x.shape
         g_ct, v_ct, g_pw, v_pw, b = self._p(p)
-        out = dict(dx=torch.empty_like(x), dg_ct=torch.empty_like(g_ct), dv_ct=torch.empty_like(v_ct), dg_pw=torch.empty_like(g_pw),
-                   dv_pw=torch.empty_like(v_pw), db=torch.empty_like(b))
+        d = x.device
+        out = dict(dx=torch.empty_like(x), dg_ct=_dst(into, "dg_ct", g_ct.shape, d), dv_ct=_dst(into, "dv_ct", v_ct.shape, d),
+                   dg_pw=_dst(into, "dg_pw", g_pw.shape, d), dv_pw=_dst(into, "dv_pw", v_pw.shape, d), db=_dst(into, "db", b.shape, d))
         ws = torch.empty(int(self._lib.wv_train_up_workspace_bytes(self._h, B, T)), dtype=torch.uint8, device=x.device)
         self._check(self._lib.wv_train_up_backward(
             self._h, x.data_ptr(), g_ct.data_ptr(), v_ct.data_ptr(), g_pw.data_ptr(), v_pw.data_ptr(), float(pre_scale), int(pre_elu),
@@ -401,11 +405,12 @@ class TrainTail(_Handle):
                                                     delta.data_ptr(), B, Tin, int(T), TrainHalf._stream()), "wv_train_tail_forward")
         return delta
 
-    def backward(self, x, p, post: float, wav_std: float, delta, d_delta):
+    def backward(self, x, p, post: float, wav_std: float, delta, d_delta, into=None):
         x, delta, dd = _f(x), _f(delta), _f(d_delta)
         B, _, Tin = x.shape
         g, v = _f(p["g"]).reshape(1), _f(p["v"]).reshape(self.C, self.ks)
-        out = dict(dx=torch.empty_like(x), dg=torch.empty_like(g), dv=torch.empty_like(v), db=torch.empty(1, device=x.device))
+        d = x.device
+        out = dict(dx=torch.empty_like(x), dg=_dst(into, "dg", g.shape, d), dv=_dst(into, "dv", v.shape, d), db=_dst(into, "db", (1,), d))
         ws = torch.empty(int(self._lib.wv_train_tail_workspace_bytes(self._h, B)), dtype=torch.uint8, device=x.device)
         self._check(self._lib.wv_train_tail_backward(
             self._h, x.data_ptr(), g.data_ptr(), v.data_ptr(), float(post), float(wav_std), delta.data_ptr(), dd.data_ptr(), out["dx"].data_ptr(),
@@ -631,10 +636,13 @@ class FilmMlp:
         assert flat.numel() == self.np
         return flat
 
-    def forward(self, msg: torch.Tensor, params) -> torch.Tensor:
+    def forward(self, msg: torch.Tensor, params, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """packed: the parameters already laid out in `self.keys` order (a slice of a flat arena), else they are gathered here."""
         msg = _f(msg)
         B = msg.shape[0]
-        self._packed, self._msg = self.pack(params), msg
+        self._packed, self._msg = (self.pack(params) if packed is None else packed), msg
+        if self._packed.numel() != self.np or not self._packed.is_contiguous():
+            raise ValueError("FilmMlp: packed parameter block of the wrong size / layout")
         film = torch.empty(B, self.NF, device=msg.device)
         self._ws = torch.empty(int(self._lib.wv_train_film_workspace_bytes(B, self.Dm, self.E, self.L, self.S, self.bands)), dtype=torch.uint8,
                                device=msg.device)
@@ -661,14 +669,20 @@ class FilmMlp:
             raise RuntimeError(f"wv_train_film_apply_backward: {self._lib.wv_train_last_error().decode()}")
         return dx
 
-    def backward(self, dfilm, gviews) -> None:
+    def backward(self, dfilm, gviews, dp: Optional[torch.Tensor] = None) -> None:
+        """dp: the gradient block in `self.keys` order (a slice of a flat gradient arena, written in place), else the gradients are
+        scattered into `gviews` afterwards."""
         B = self._msg.shape[0]
-        dp = torch.empty(self.np, device=dfilm.device)
+        scatter = dp is None
+        if scatter:
+            dp = torch.empty(self.np, device=dfilm.device)
+        elif dp.numel() != self.np or not dp.is_contiguous() or dp.dtype != torch.float32:
+            raise ValueError("FilmMlp: gradient block of the wrong size / layout")
         if self._lib.wv_train_film_backward(self._msg.data_ptr(), self._packed.data_ptr(), dfilm.data_ptr(), dp.data_ptr(), B, self.Dm, self.E, self.L,
                                             self.S, self.bands, self._ws.data_ptr(), self._ws.numel(), TrainHalf._stream()) != 0:
             raise RuntimeError(f"wv_train_film_backward: {self._lib.wv_train_last_error().decode()}")
         off = 0
-        for k in self.keys:
+        for k in (self.keys if scatter else ()):
             n = gviews[k].numel()
             gviews[k].copy_(dp[off:off + n].view_as(gviews[k]))
             off += n
@@ -685,6 +699,15 @@ class _NetTrainer:
         skip = () if with_msg else ("encoder.msg_embedding.", "encoder.film_layers.")
         items = [(k, np.asarray(v, dtype=np.float32)) for k, v in state_dict.items()
                  if not (skip and k.startswith(skip)) and not k.endswith("spec.weight")]
+        # the message MLP + FiLM parameters sit together, in the order the FiLM kernels read them: their packed block and its gradient
+        # are then plain slices of the arenas (no gather before the forward, no scatter after the backward)
+        self.film = FilmMlp(cfg) if with_msg else None
+        film_off = None
+        if with_msg:
+            fk, by = set(self.film.keys), dict(items)
+            items = [(k, v) for k, v in items if k not in fk]
+            film_off = sum(v.size for _, v in items)
+            items += [(k, by[k]) for k in self.film.keys]
         n = sum(v.size for _, v in items)
         self.arena, self.grads = torch.empty(n, device=device), torch.zeros(n, device=device)
         self.params, self.gviews, off = {}, {}, 0
@@ -705,7 +728,11 @@ class _NetTrainer:
         self.spec_post = TrainSpecAdd(C, n_fft // 2 + 1)
         self.stft_post = StftFeatures(n_fft, stride, cfg.spec_means[-1], cfg.spec_stds[-1])
         self.conv_post = TrainConvPost(C, cfg.dimension, cfg.last_kernel_size)
-        self.film = FilmMlp(cfg) if with_msg else None
+        self._film_p = self._film_g = None
+        if with_msg:
+            if n - film_off != self.film.np:
+                raise ValueError("message MLP / FiLM parameters do not match the configuration")
+            self._film_p, self._film_g = self.arena[film_off:], self.grads[film_off:]
         self.down_scale = (1 + cfg.n_residual_enc * rs ** 2) ** -0.5
         self.opt = FlatAdamW(n, lr=lr, device=device)
         self._enc = None
@@ -720,15 +747,10 @@ class _NetTrainer:
         g_dw, v_dw = self._wn(f"{pre}.{dw}")
         return dict(g_pw=g_pw, v_pw=v_pw, g_dw=g_dw, v_dw=v_dw, b_dw=self.params[f"{pre}.{dw}.conv.conv.bias"])
 
-    def _put(self, conv, dg, dv, inner=".conv.conv"):
+    def _gwn(self, conv, inner=".conv.conv"):
+        """(d original0, d original1) arena views of a weight-normed conv: destinations the kernels write in place."""
         b = conv + inner + ".parametrizations.weight."
-        self.gviews[b + "original0"].copy_(dg.view_as(self.gviews[b + "original0"]))
-        self.gviews[b + "original1"].copy_(dv.view_as(self.gviews[b + "original1"]))
-
-    def _put_half(self, pre, pw, dw, g):
-        self._put(f"{pre}.{pw}", g["dg_pw"], g["dv_pw"])
-        self._put(f"{pre}.{dw}", g["dg_dw"], g["dv_dw"])
-        self.gviews[f"{pre}.{dw}.conv.conv.bias"].copy_(g["db_dw"])
+        return self.gviews[b + "original0"], self.gviews[b + "original1"]
 
     def _into_half(self, pre, pw, dw):
         """Gradient-arena views of one 1x1 -> depth-wise unit: the kernels write them in place."""
@@ -767,7 +789,7 @@ class _NetTrainer:
             msg = _f(msg)
             if msg.shape[0] != x.shape[0]:                                         # one message for the batch (watermarking.py:320-329)
                 msg = msg.repeat(-(-x.shape[0] // msg.shape[0]), 1)[: x.shape[0]].contiguous()
-            sv["film"] = self.film.forward(msg, self.params)
+            sv["film"] = self.film.forward(msg, self.params, self._film_p)
         g, v = self._wn("encoder.conv_pre.1")
         h = self.conv_pre.forward(x, dict(g=g, v=v, b=self.params["encoder.conv_pre.1.conv.conv.bias"]), 1.0 / cfg.wav_std)
         for s, sc in enumerate(self.scales):
@@ -797,10 +819,9 @@ class _NetTrainer:
         cfg, rs, sv = self.cfg, self.cfg.res_scale_enc, self._enc
         if sv is None:
             raise RuntimeError("backward before forward")
-        g = self.conv_post.backward(sv["post_in"], self._post_p(), dz)
-        self._put("encoder.conv_post.1", g["dg_dw"], g["dv_dw"])
-        self._put("encoder.conv_post.2", g["dg_pw"], g["dv_pw"])
-        self.gviews["encoder.conv_post.2.conv.conv.bias"].copy_(g["db"])
+        (gd0, gd1), (gp0, gp1) = self._gwn("encoder.conv_post.1"), self._gwn("encoder.conv_post.2")
+        g = self.conv_post.backward(sv["post_in"], self._post_p(), dz,
+                                    dict(dg_dw=gd0, dv_dw=gd1, dg_pw=gp0, dv_pw=gp1, db=self.gviews["encoder.conv_post.2.conv.conv.bias"]))
         dh = g["dx"]
 
         dx_spec = torch.zeros_like(sv["x"]) if need_dx else None
@@ -827,12 +848,11 @@ class _NetTrainer:
             for j in reversed(range(len(sc["blocks"]))):
                 dh = self._block_bwd(sc["blocks"][j], f"encoder.blocks.{s}.{j}", rec["blocks"][j], dh, rs)
         if self.with_msg:
-            self.film.backward(dfilm, self.gviews)
+            self.film.backward(dfilm, self.gviews, self._film_g)
         gv = self._wn("encoder.conv_pre.1")
+        g0, g1 = self._gwn("encoder.conv_pre.1")
         gp = self.conv_pre.backward(sv["x"], dict(g=gv[0], v=gv[1], b=self.params["encoder.conv_pre.1.conv.conv.bias"]), 1.0 / cfg.wav_std,
-                                    dh, need_dx)
-        self._put("encoder.conv_pre.1", gp["dg"], gp["dv"])
-        self.gviews["encoder.conv_pre.1.conv.conv.bias"].copy_(gp["db"])
+                                    dh, need_dx, dict(dg=g0, dv=g1, db=self.gviews["encoder.conv_pre.1.conv.conv.bias"]))
         self._enc = None
         return gp["dx"] + dx_spec if need_dx else None
 
@@ -872,10 +892,9 @@ class EncoderNetTrainer(_NetTrainer):
         """Fills `self.grads` (every view of `self.gviews`); returns dL/dx through conv_pre when asked."""
         if self._z is None:
             raise RuntimeError("backward before forward")
-        g = self.head.backward(self._z, self._head_p(), dlogits)
-        for k, name in (("dw_rev", "reverse_convolution.weight"), ("db_rev", "reverse_convolution.bias"), ("dw_last", "last_layer.weight"),
-                        ("db_last", "last_layer.bias")):
-            self.gviews[name].copy_(g[k].view_as(self.gviews[name]))
+        g = self.head.backward(self._z, self._head_p(), dlogits,
+                               dict(dw_rev=self.gviews["reverse_convolution.weight"], db_rev=self.gviews["reverse_convolution.bias"],
+                                    dw_last=self.gviews["last_layer.weight"], db_last=self.gviews["last_layer.bias"]))
         self._z = None
         return self.encoder_backward(g["dz"], need_dx)
 
@@ -947,23 +966,21 @@ class GeneratorTrainer(_NetTrainer):
         if sv is None:
             raise RuntimeError("backward before forward")
         d_wm = _f(d_wm)
-        g = self.tail.backward(sv["tail_in"], self._tail_p(), self.post, cfg.wav_std, sv["delta"], d_wm)
-        self._put(f"decoder.model.{self.i_last}", g["dg"], g["dv"])
-        self.gviews[f"decoder.model.{self.i_last}.conv.conv.bias"].copy_(g["db"])
+        g0, g1 = self._gwn(f"decoder.model.{self.i_last}")
+        g = self.tail.backward(sv["tail_in"], self._tail_p(), self.post, cfg.wav_std, sv["delta"], d_wm,
+                               dict(dg=g0, dv=g1, db=self.gviews[f"decoder.model.{self.i_last}.conv.conv.bias"]))
         dh = g["dx"]
         for i in reversed(range(len(self.ups))):
             (ct, pw, res, r, C), du, rec = self.ups[i], self.dec_ups[i], sv["ups"][i]
             for j in reversed(range(len(res))):
                 dh = self._block_bwd(du["blocks"][j], f"decoder.model.{res[j]}", rec["blocks"][j], dh, rs)
-            gu = du["up"].backward(rec["up_in"], self._up_p(ct, pw), self.post if i > 0 else 1.0, dh, True)
-            self._put(f"decoder.model.{ct}", gu["dg_ct"], gu["dv_ct"], ".convtr.convtr")
-            self._put(f"decoder.model.{pw}", gu["dg_pw"], gu["dv_pw"])
-            self.gviews[f"decoder.model.{pw}.conv.conv.bias"].copy_(gu["db"])
+            (c0, c1), (p0, p1) = self._gwn(f"decoder.model.{ct}", ".convtr.convtr"), self._gwn(f"decoder.model.{pw}")
+            gu = du["up"].backward(rec["up_in"], self._up_p(ct, pw), self.post if i > 0 else 1.0, dh, True,
+                                   dict(dg_ct=c0, dv_ct=c1, dg_pw=p0, dv_pw=p1, db=self.gviews[f"decoder.model.{pw}.conv.conv.bias"]))
             dh = gu["dx"]
-        gi = self.dec_in.backward(sv["z"], self._in_p(), 1.0, dh, False, True)
-        self._put(f"decoder.model.{self.i_pw0}", gi["dg_pw"], gi["dv_pw"])
-        self._put(f"decoder.model.{self.i_dw0}", gi["dg_dw"], gi["dv_dw"])
-        self.gviews[f"decoder.model.{self.i_dw0}.conv.conv.bias"].copy_(gi["db_dw"])
+        (p0, p1), (d0, d1) = self._gwn(f"decoder.model.{self.i_pw0}"), self._gwn(f"decoder.model.{self.i_dw0}")
+        gi = self.dec_in.backward(sv["z"], self._in_p(), 1.0, dh, False, True,
+                                  dict(dg_pw=p0, dv_pw=p1, dg_dw=d0, dv_dw=d1, db_dw=self.gviews[f"decoder.model.{self.i_dw0}.conv.conv.bias"]))
         self._dec = None
         dx = self.encoder_backward(gi["dx"], need_dx)
         return None if dx is None else dx + d_wm
