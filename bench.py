@@ -357,7 +357,7 @@ def main():
                                   step_tflops=round(step_flops / (total_ms / a.steps * 1e-3) / 1e12, 2),
                                   note="hipEvent pair around every launch; `value` is from the clean pass before it"),
                scaling_measured=("N>1 not measured in this run" if world == 1 else "this line"))
-    if not a.no_cpu_baseline and a.workload == "embed_detect":
+    if not a.no_cpu_baseline and a.workload == "embed_detect" and world == 1:      # the CPU leg: rank 0 at N = 1 only
         cb, wm_ref, mp_ref = cpu_baseline(cfgG, cfgD, sdG, sdD, x_np, msg_np, min(a.cpu_clips, B))
         n = wm_ref.shape[0]
         out["cpu_baseline"] = cb
