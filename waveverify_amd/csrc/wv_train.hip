@@ -1124,7 +1124,7 @@ int wv_train_half_create(int C, wv_train_unit** out) { return wv_train_unit_crea
 void wv_train_half_destroy(wv_train_unit* h) { delete h; }
 
 // splits of the dW GEMM: enough workgroups to fill the chip even when the weight matrix is one 64 x 64 tile (C = 64 layers), within
-// a 64 MB scratch; a function of the shapes only, so the summation order -- and the result -- is reproducible
+// a 128 MB scratch; a function of the shapes only, so the summation order -- and the result -- is reproducible
 struct NtPlan { int S, TC; };
 static NtPlan nt_plan(int B, int T, int M, int K) {
     const int te = wv::nt_tile(M, K);
@@ -1132,8 +1132,7 @@ static NtPlan nt_plan(int B, int T, int M, int K) {
     const int TC = 512;
     const long long items = (long long)B * ((T + TC - 1) / TC);
     long long S = std::min<long long>(items, std::max<long long>(1, 1024 / tiles));
-    static const long long cap = [] { const char* e = getenv("WV_NT_CAP"); return (long long)(e ? atoi(e) : 32) << 20; }();
-    while (S > 1 && S * M * K > cap) S /= 2;
+    while (S > 1 && S * M * K > (32LL << 20)) S /= 2;          // <= 128 MB of partial sums (a 16 MB cap left one workgroup per CU: 1.07x the step)
     return NtPlan{(int)S, TC};
 }
 static int t_out(const wv_train_unit* h, int Tin) { return (Tin + h->stride - 1) / h->stride; }
