@@ -16,9 +16,12 @@
 //   bce / l1 / sumsq / adamw                                                                                            loss.py:947-1099, train.py:1322,1346-1358
 // How they are built: the forward of a unit IS the inference kernel (K1 on the LDS-DMA core, the round-1 core at ragged lengths) fed
 // by wn_fold_kernel, which folds g v / ||v|| on the device straight into the kernels' weight layouts (k-inner and K-major packs of W and
-// of W^T) and keeps 1 / ||v||.  Backward recomputes what forward did not keep, runs W^T @ dy on the same K1 kernel, the weight gradient
-// dW = sum_{b,t} dy a^T as a time-contracting MFMA GEMM (gemm_nt_kernel), the stencils' transposes as per-row kernels, and the
-// weight-norm backward (wn_bwd_kernel).  A first correct version: recompute-based and unfused.
+// of W^T) and keeps 1 / ||v||.  Backward runs W^T @ dy on the same K1 kernel with the activation's derivative (and a block's identity
+// shortcut) in its epilogue, the weight gradient dW = sum_{b,t} dy a^T as a time-contracting MFMA GEMM (gemm_nt_kernel), the stencils'
+// transposes as per-row kernels (one output frame or four samples per thread), and the weight-norm backward (wn_bwd_kernel /
+// dw_param_grads_kernel).  A ResnetBlock keeps its two 1x1 outputs from the forward kernels' epilogues (K1 RES = 4 / 5, the latter also
+// emitting y = x + s v), so its backward has no GEMM to recompute; a standalone unit recomputes its 1x1 output.  Layers the LDS-DMA
+// core does not take (ragged / narrow) run the same steps as separate kernels (elu_bwd, axpy_res, scale_dot, add_inplace).
 // Gradient parity against the reference's autograd: tests/test_gpu_train.py (units) and tests/test_gpu_trainer.py (whole nets).
 #include <hip/hip_runtime.h>
 
