@@ -463,7 +463,8 @@ def test_upsample_unit_gradients_vs_reference_autograd_and_oracle(golden_dir):
         for k in keys:
             assert rel(g[k], f[f"up{i}_{k}"]) <= 1e-4, (i, k, rel(g[k], f[f"up{i}_{k}"]))
     # the generator's decoder shapes at a training batch: 768 -> 384 (r = 8, 50 frames) and 192 -> 96 (r = 2, 8000 -> 16000)
-    for B, K, M, T, r in ((16, 768, 384, 50, 8), (4, 192, 96, 8000, 2)):
+    # ... and the other two ratios of the per-frame ConvTranspose kernels (r = 5: scalar loads, r = 4: one 16-byte vector per frame)
+    for B, K, M, T, r in ((16, 768, 384, 50, 8), (4, 192, 96, 8000, 2), (3, 384, 192, 400, 5), (2, 256, 128, 2000, 4)):
         rng = np.random.default_rng(K + r)
         x = rng.standard_normal((B, K, T)).astype(np.float32)
         dy = rng.standard_normal((B, M, T * r)).astype(np.float32)
@@ -479,7 +480,9 @@ def test_upsample_unit_gradients_vs_reference_autograd_and_oracle(golden_dir):
             assert rel(g[k], ref[k]) <= 1e-4 and torch.equal(g[k], g2[k]), (K, k, rel(g[k], ref[k]))
 
 
-@pytest.mark.parametrize("B,C,Tin,T,ks", [(4, 96, 16000, 16000, 5), (2, 96, 16320, 16001, 5), (3, 8, 40, 37, 7)])
+@pytest.mark.parametrize("B,C,Tin,T,ks", [(4, 96, 16000, 16000, 5), (2, 96, 16320, 16001, 5), (3, 8, 40, 37, 7),
+                                            # the four-samples-per-thread backward with decoder samples past the clip (no gradient there)
+                                            (2, 96, 16320, 16000, 5), (2, 16, 48, 40, 5)])
 def test_decoder_tail_vs_torch_autograd(B, C, Tin, T, ks):
     """Scale(post) -> ELU -> causal weight-normed Conv1d(C, 1, ks) -> Scale(wav_std) -> Tanh -> [:T] (seanet.py:1166-1204) written with
     torch.nn.functional in float64 (the reference builds exactly these torch ops; SConv1d's causal padding = left pad ks-1)."""
