@@ -39,15 +39,13 @@ namespace wv {
 // v [M][K], g [M] -> w [M][K] (plain), inv_norm [M]; optional packs: wq[k/4][Mp][4] (A operand of W @ X) and
 // wqT[m/4][Kp'][4] (A operand of W^T @ X, Kp' = padded K as the row count), and their K-major twins wt[k][Mp] /
 // wtT[m][Kp'] for the round-1 core that takes over at ragged lengths.  Padding is zeroed once by the host.
-__global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ g, const float* __restrict__ v,
-                                                      float* __restrict__ w, float* __restrict__ inv_norm,
-                                                      float* __restrict__ wq, float* __restrict__ wqT,
-                                                      int M, int K, int Mp, int KpT,
-                                                      const float* __restrict__ pack_param = nullptr, float pack_scale = 1.f,
-                                                      float* __restrict__ wt = nullptr, float* __restrict__ wtT = nullptr) {
-    __shared__ float red[4];
-    const int m = blockIdx.x, tid = threadIdx.x;
-    const float* vr = v + (size_t)m * K;
+struct WnFoldArgs {
+    const float* g; const float* v; float* w; float* inv_norm; float* wq; float* wqT; int M, K, Mp, KpT;
+    const float* pack_param; float pack_scale; float* wt; float* wtT;
+};
+__device__ __forceinline__ void wn_fold_row(const WnFoldArgs& a, int m, float* red) {
+    const int tid = threadIdx.x, K = a.K;
+    const float* vr = a.v + (size_t)m * K;
     float ss = 0.f;
     for (int k = tid; k < K; k += 256) ss = fmaf(vr[k], vr[k], ss);
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
@@ -55,17 +53,33 @@ __global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ 
     __syncthreads();
     ss = red[0] + red[1] + red[2] + red[3];
     const float inv = 1.f / sqrtf(ss);
-    const float sc = g[m] * inv;
-    if (tid == 0) inv_norm[m] = inv;
+    const float sc = a.g[m] * inv;
+    if (tid == 0) a.inv_norm[m] = inv;
     for (int k = tid; k < K; k += 256) {
         const float x = vr[k] * sc;
-        w[(size_t)m * K + k] = x;
-        const float xs = x * (pack_param ? pack_scale * pack_param[0] : pack_scale);   // a scalar folded into the GEMM operand only
-        if (wq) wq[((size_t)(k >> 2) * Mp + m) * 4 + (k & 3)] = xs;
-        if (wqT) wqT[((size_t)(m >> 2) * KpT + k) * 4 + (m & 3)] = xs;
-        if (wt) wt[(size_t)k * Mp + m] = xs;                       // K-major packs of the round-1 core (ragged T, M <= 32)
-        if (wtT) wtT[(size_t)m * KpT + k] = xs;
+        a.w[(size_t)m * K + k] = x;
+        const float xs = x * (a.pack_param ? a.pack_scale * a.pack_param[0] : a.pack_scale);   // a scalar folded into the GEMM operand only
+        if (a.wq) a.wq[((size_t)(k >> 2) * a.Mp + m) * 4 + (k & 3)] = xs;
+        if (a.wqT) a.wqT[((size_t)(m >> 2) * a.KpT + k) * 4 + (m & 3)] = xs;
+        if (a.wt) a.wt[(size_t)k * a.Mp + m] = xs;                 // K-major packs of the round-1 core (ragged T, M <= 32)
+        if (a.wtT) a.wtT[(size_t)m * a.KpT + k] = xs;
     }
+}
+__global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                      float* __restrict__ w, float* __restrict__ inv_norm,
+                                                      float* __restrict__ wq, float* __restrict__ wqT,
+                                                      int M, int K, int Mp, int KpT,
+                                                      const float* __restrict__ pack_param = nullptr, float pack_scale = 1.f,
+                                                      float* __restrict__ wt = nullptr, float* __restrict__ wtT = nullptr) {
+    __shared__ float red[4];
+    wn_fold_row(WnFoldArgs{g, v, w, inv_norm, wq, wqT, M, K, Mp, KpT, pack_param, pack_scale, wt, wtT}, blockIdx.x, red);
+}
+// both weights of a unit in one launch: blocks [0, a.M) fold a's rows, the rest b's
+__global__ __launch_bounds__(256) void wn_fold_pair_kernel(WnFoldArgs a, WnFoldArgs b) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    if (m < a.M) wn_fold_row(a, m, red);
+    else wn_fold_row(b, m - a.M, red);
 }
 
 // (dg, dv) of w = g * v / ||v||:  dot = <dw, v>;  dg = dot / ||v||;  dv = g / ||v|| * (dw - dot / ||v||^2 * v)
@@ -1152,10 +1166,9 @@ size_t wv_train_half_workspace_bytes(const wv_train_unit* h, int B, int T) { ret
 
 // fold both weights of the unit for this step (live weight norm)
 static int fold_step(wv_train_unit* h, const float* g_pw, const float* v_pw, const float* g_dw, const float* v_dw, hipStream_t s) {
-    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->M), dim3(256), 0, s, g_pw, v_pw, h->w_pw, h->inv_pw, h->wq, h->wqT, h->M, h->K, h->Mp, h->KpT,
-                       (const float*)nullptr, 1.f, h->wt, h->wtT);
-    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3(h->M), dim3(256), 0, s, g_dw, v_dw, h->w_dw, h->inv_dw, (float*)nullptr, (float*)nullptr, h->M, h->ks, 0, 0,
-                       (const float*)nullptr, 1.f, (float*)nullptr, (float*)nullptr);
+    const wv::WnFoldArgs fa{g_pw, v_pw, h->w_pw, h->inv_pw, h->wq, h->wqT, h->M, h->K, h->Mp, h->KpT, nullptr, 1.f, h->wt, h->wtT};
+    const wv::WnFoldArgs fb{g_dw, v_dw, h->w_dw, h->inv_dw, nullptr, nullptr, h->M, h->ks, 0, 0, nullptr, 1.f, nullptr, nullptr};
+    hipLaunchKernelGGL(wv::wn_fold_pair_kernel, dim3(2 * h->M), dim3(256), 0, s, fa, fb);
     T_LAUNCH(hipGetLastError());
     return WV_OK;
 }
