@@ -151,12 +151,14 @@ int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const floa
                 float pre_scale, int pre_elu, float out_scale, int bands,
                 float* Yact, float act_scale, void* stream);
 
-/* Whole SEANetResnetBlock in one launch (narrow layers, C in {64, 96, 128, 192}, k = 5, dilation 1, T % 4 == 0;
- * modules/seanet.py:245-281 with dws_conv_block :39-116):
- *   y = Xr + out_scale * ( DW5( W2 @ ELU( DW5( W1 @ Xa ) + b1 ) ) + b2 ),   Xa = ELU(pre_scale * Xr) given pre-activated
- * Xa, Xr [B,C,T]; w_pw1/w_pw2 [C,C]; w_dw1/w_dw2 [C,5]; b1/b2 [C]; Y and/or Yact = ELU(act_scale*y) [B,C,T].
+/* Whole SEANetResnetBlock in one launch, raw in / raw out (narrow layers, C in {64, 96, 128, 192}, k = 5,
+ * dilation 1, T % 4 == 0; modules/seanet.py:245-281 with dws_conv_block :39-116):
+ *   y = X + out_scale * ( DW5( W2 @ ELU( DW5( W1 @ ELU(pre_scale * X) ) + b1 ) ) + b2 )
+ * X [B,C,T] is read once from HBM (activated inside, re-read from L2 as the residual operand); the intermediate
+ * stays in LDS.  w_pw1/w_pw2 [C,C]; w_dw1/w_dw2 [C,5]; b1/b2 [C]; Y and/or Yact = ELU(act_scale*y) [B,C,T].
+ * Bit-identical to the block run as two wv_op_pw_dw units.
  * Returns WV_EINVAL for shapes the fused kernel does not cover (the nets then run two wv_op_pw_dw units). */
-int wv_op_resblock(const float* Xa, const float* Xr, const float* w_pw1, const float* w_dw1, const float* b1,
+int wv_op_resblock(const float* X, float pre_scale, const float* w_pw1, const float* w_dw1, const float* b1,
                    const float* w_pw2, const float* w_dw2, const float* b2, float* Y, float* Yact,
                    int B, int C, int T, float out_scale, float act_scale, void* stream);
 

@@ -144,13 +144,15 @@ def test_upsample_convtr_pw_dma_core(ops, K, M, Tin, r, pre_elu):
     close(gact, O.elu(ref * np.float32(0.9)), what="upsample (activated copy)")
 
 
-@pytest.mark.parametrize("C,T", [(64, 16000), (64, 120), (64, 4), (96, 1000), (96, 128), (128, 8000), (128, 124),
-                                 (192, 8000), (192, 56), (192, 60), (64, 112), (128, 240)])
+@pytest.mark.parametrize("C,T", [(64, 16000), (64, 244), (64, 248), (64, 4), (64, 240), (96, 1000), (96, 236), (96, 240), (96, 128),
+                                 (128, 8000), (128, 244), (128, 252), (128, 488), (192, 8000), (192, 116), (192, 120), (192, 56),
+                                 (64, 112), (128, 492), (96, 8), (192, 12)])
 def test_fused_resblock(ops, C, T):
-    """Whole ResnetBlock in one launch (u stays in LDS) vs the oracle's two-unit composition; lengths around
-    every tile edge (120 / 56 outputs per tile, 8-column halo)."""
+    """Whole ResnetBlock in one launch, raw in / raw out (wv_rb.hip: x activated on its way into LDS, u stays in LDS) vs the
+    oracle's two-unit composition; lengths around every tile edge (244 / 236 / 116 outputs per tile, 8-column halo, first-tile
+    zero padding of both convs), both outputs, and bit-equality with the block run as two pw_dw units."""
     rng = np.random.default_rng(C + T)
-    B = 2
+    B = 3
     X = rnd(rng, B, C, T)
     w1, w2 = rnd(rng, C, C, 1, scale=C ** -0.5), rnd(rng, C, C, 1, scale=C ** -0.5)
     d1, d2 = rnd(rng, C, 1, 5, scale=0.45), rnd(rng, C, 1, 5, scale=0.45)
@@ -159,9 +161,18 @@ def test_fused_resblock(ops, C, T):
     xa = O.elu(X * pre)
     u = O.sconv1d(O.sconv1d(xa, w1, None), d1, b1, groups=C)
     y = X + s_out * O.sconv1d(O.sconv1d(O.elu(u), w2, None), d2, b2, groups=C)
-    got, gact = ops.resblock(cu(xa), cu(X), w1, d1, b1, w2, d2, b2, out_scale=float(s_out), act_scale=float(s_act))
+    Xd = cu(X)
+    got, gact = ops.resblock(Xd, w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out), act_scale=float(s_act))
     close(got, y.astype(np.float32), what="fused resblock")
     close(gact, O.elu(y.astype(np.float32) * s_act), what="fused resblock (activated copy)")
+    only_raw = ops.resblock(Xd, w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out))
+    only_act = ops.resblock(Xd, w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out), act_scale=float(s_act), want_raw=False)
+    assert torch.equal(only_raw, got) and torch.equal(only_act, gact)
+    # the same block as two K1 launches (self-activating first unit): the fused kernel keeps their arithmetic order
+    _, ua = ops.pw_dw(Xd, w1, d1, b1, pre_scale=float(pre), pre_elu=True, act_scale=1.0)
+    two, two_act = ops.pw_dw(ua, w2, d2, b2, resid=Xd, pre_elu=False, out_scale=float(s_out), act_scale=float(s_act))
+    assert torch.equal(two, got), f"fused block differs from two launches: {float((two - got).abs().max()):.3e}"
+    assert torch.equal(two_act, gact)
 
 
 @pytest.mark.parametrize("B,C,T", [(6, 128, 400), (7, 128, 36), (5, 96, 200), (9, 64, 60), (3, 256, 2000), (16, 192, 12), (4, 384, 124)])

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Fused-ResnetBlock kernel vs the two-launch form on the narrow layer shapes. python tools/rbbench.py"""
+"""One-launch ResnetBlock kernel (wv_rb.hip, raw in / raw out) vs the two-launch form on the narrow layer shapes.
+python tools/rbbench.py"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,14 +16,14 @@ def t_of(f, reps=5):
 B = 256
 for C, T in ((64, 16000), (96, 16000), (128, 8000), (192, 8000)):
     rng = np.random.default_rng(0)
-    X = torch.randn(B, C, T, device="cuda"); Xa = torch.nn.functional.elu(X * 0.87)
+    X = torch.randn(B, C, T, device="cuda")
     w1 = rng.standard_normal((C, C, 1)).astype(np.float32) * C ** -0.5; w2 = w1[::-1].copy()
     d1 = rng.standard_normal((C, 1, 5)).astype(np.float32) * 0.4; d2 = d1[::-1].copy()
     b1 = rng.standard_normal(C).astype(np.float32) * 0.1; b2 = b1[::-1].copy()
-    def fused(): ops.resblock(Xa, X, w1, d1, b1, w2, d2, b2, out_scale=0.5, act_scale=0.9)
+    def fused(): ops.resblock(X, w1, d1, b1, w2, d2, b2, pre_scale=0.87, out_scale=0.5)
     def two():
-        _, u = ops.pw_dw(Xa, w1, d1, b1, pre_elu=False, act_scale=1.0)
-        ops.pw_dw(u, w2, d2, b2, resid=X, pre_elu=False, out_scale=0.5, act_scale=0.9)
+        _, u = ops.pw_dw(X, w1, d1, b1, pre_scale=0.87, pre_elu=True, act_scale=1.0)
+        ops.pw_dw(u, w2, d2, b2, resid=X, pre_elu=False, out_scale=0.5)
     fl = 2 * 2.0 * B * C * (C * T + 5 * T)
     for nm, f in (("fused", fused), ("two launches", two)):
         us, k = t_of(f)

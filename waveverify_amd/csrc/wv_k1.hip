@@ -1023,239 +1023,4 @@ hipError_t launch_stft_k1(const StftArgs& a, hipStream_t s) {
     return stft_k1_run<K1<4, 16, 64>>(a, s);
 }
 
-// =================================================================================================
-// Whole SEANetResnetBlock in ONE launch for narrow layers (C <= 192; modules/seanet.py:245-281, 39-116):
-//     y = x + s * DW5( W2 @ ELU( DW5( W1 @ ELU(c*x) ) + b1 ) ) + b2 )
-// As two K1 launches such a block crosses HBM five times (read xa, write u, read u, read x, write y) and
-// both launches are bandwidth- or latency-bound (K = C is only 4-12 chunks deep).  Fused, the
-// intermediate u never leaves the CU: a workgroup owns ALL C channels of one time window, so after the
-// first GEMM + stencil the activated u[C][BN] sits in LDS in exactly the natural [k][t] layout the second
-// GEMM reads its B operand from.  HBM traffic drops to read xa, read x, write y (+ the activated copy),
-// and with f32 matrix math at 157 TFLOP/s peak the block becomes matrix-bound even at C = 64.
-//
-// Window of BN columns starting at time ti0 = to0 - 8: H1 on all BN columns, u on columns 0..BN-5
-// (column o <-> time ti0 + 4 + o), y on columns 0..BN-9 (column o <-> time ti0 + 8 + o = to0 + o):
-// BN - 8 outputs per tile, the 8-column halo is recomputed.  Zero padding: xa is DMA'd as 0 outside
-// [0,T) (so H1 = 0 there, the 1x1 has no bias) and u is forced to 0 at times < 0, which is the zero pad
-// SConv1d puts in front of the second depth-wise conv.
-// =================================================================================================
-template <int C_, int NT_>
-struct RB {
-    static constexpr int C = C_, WM = C_ / 32, NTHREADS = 64 * WM, NT = NT_, BN = 32 * NT_, BKC = 16, KQ = 4;
-    static constexpr int A4 = KQ * C;                        // f32x4 per A stage [kq][m]
-    static constexpr int B4 = BKC * BN / 4;                  // f32x4 per B stage [k][t]
-    static constexpr int STAGE4 = A4 + B4;
-    static constexpr int U4 = C * BN / 4;                    // f32x4 of the resident u[C][BN]
-    static constexpr int CG = BN / 4;
-    static constexpr int TTO = BN - 8;
-    static constexpr size_t SMEM = (size_t)(2 * STAGE4 + U4) * 16;
-    static_assert(C_ % 32 == 0 && A4 % 64 == 0 && B4 % 64 == 0, "staging maps");
-};
-
-template <class R>
-__device__ __forceinline__ void rb_dma_A(const f32x4* wq, int Mp, int c, f32x4* Ast, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {                            // A4 / 64 = 2 * WM pieces: two per wave
-        const int idx = (2 * wave + i) * 64 + lane;
-        const int kq = idx / R::C, m = idx % R::C;
-        __builtin_amdgcn_global_load_lds((gptr_t)(wq + (size_t)(c * R::KQ + kq) * Mp + m), (lptr_t)(Ast + (2 * wave + i) * 64), 16, 0, 0);
-    }
-}
-
-// one 16-deep chunk of MFMAs: A fragments from the stage, B rows from `Brow0` (row 0 of the chunk)
-template <class R>
-__device__ __forceinline__ void rb_chunk(f32x16 (&acc)[R::NT], const f32x4* As, const float* Brow0, int wave, int h, int i31) {
-    typedef typename NVec<R::NT>::type bvec;
-    const f32x4 a0 = As[h * R::C + 32 * wave + i31];
-    const f32x4 a1 = As[(h + 2) * R::C + 32 * wave + i31];
-    const float* Bf = Brow0 + R::NT * i31;
-#define WV_RB_STEP(AV, ROW)                                                                        \
-    { const bvec bv = *reinterpret_cast<const bvec*>(Bf + (ROW) * R::BN);                          \
-      _Pragma("unroll") for (int e = 0; e < R::NT; ++e)                                            \
-          acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, bv[e], acc[e], 0, 0, 0); }
-    WV_RB_STEP(a0.x, 4 * h + 0) WV_RB_STEP(a0.y, 4 * h + 1) WV_RB_STEP(a0.z, 4 * h + 2) WV_RB_STEP(a0.w, 4 * h + 3)
-    WV_RB_STEP(a1.x, 8 + 4 * h + 0) WV_RB_STEP(a1.y, 8 + 4 * h + 1) WV_RB_STEP(a1.z, 8 + 4 * h + 2) WV_RB_STEP(a1.w, 8 + 4 * h + 3)
-#undef WV_RB_STEP
-}
-
-// 5-tap stencil of one accumulator row set: y[e] = bias + sum_i w[i] * H[NT*q + e + i]
-template <int NT>
-__device__ __forceinline__ void rb_stencil(const f32x16 (&acc)[NT], int r, const f32x4& w0, const f32x4& w1, float (&y)[NT]) {
-    constexpr int NSH = 4 / NT;
-    float hh[NT + 4], cur[NT];
-#pragma unroll
-    for (int e = 0; e < NT; ++e) { cur[e] = acc[e][r]; hh[e] = cur[e]; }
-#pragma unroll
-    for (int s = 1; s <= NSH; ++s) {
-#pragma unroll
-        for (int e = 0; e < NT; ++e) { cur[e] = dpp_next(cur[e]); hh[s * NT + e] = cur[e]; }
-    }
-#pragma unroll
-    for (int e = 0; e < NT; ++e) {
-        float v = w1.y;
-        v = fmaf(w0.x, hh[e], v); v = fmaf(w0.y, hh[e + 1], v); v = fmaf(w0.z, hh[e + 2], v);
-        v = fmaf(w0.w, hh[e + 3], v); v = fmaf(w1.x, hh[e + 4], v);
-        y[e] = fmaf(v, w1.z, w1.w);                            // (1, 0): kept so that both cores round alike
-    }
-}
-
-template <class R>
-__global__ __launch_bounds__(R::NTHREADS) void resblock_kernel(RbArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    typedef typename NVec<R::NT>::type ovec;
-    f32x4* S4 = reinterpret_cast<f32x4*>(smem);
-    float* U = smem + 2 * R::STAGE4 * 4;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, i31 = lane & 31, q = i31;
-    const int b = blockIdx.x / p.num_t, tt = blockIdx.x % p.num_t;
-    const int to0 = tt * R::TTO, ti0 = to0 - 8;
-    const int T = p.T;
-    constexpr int NCH = R::C / 16;
-    const f32x4* wq1 = reinterpret_cast<const f32x4*>(p.pw1.wq);
-    const f32x4* wq2 = reinterpret_cast<const f32x4*>(p.pw2.wq);
-
-    // ---- B operand of GEMM 1: rows of xa by DMA; the pieces of a chunk are dealt round-robin to the waves
-    const float* Xab = p.Xa + (size_t)b * R::C * T;
-    const int col = ti0 + 4 * (lane % R::CG);
-    const bool inr = col >= 0 && col + 3 < T;
-    const float* bsrc = inr ? Xab + col : g_zero16;
-    const size_t bld = inr ? (size_t)T : 0;
-    auto dma_B = [&](int c, f32x4* Bst) {
-        for (int i = wave; i < R::B4 / 64; i += R::WM) {
-            const int row = (i * 64 + lane) / R::CG;
-            __builtin_amdgcn_global_load_lds((gptr_t)(bsrc + (size_t)(c * 16 + row) * bld), (lptr_t)(Bst + i * 64), 16, 0, 0);
-        }
-    };
-    f32x16 acc[R::NT];
-#pragma unroll
-    for (int e = 0; e < R::NT; ++e)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-
-    // ================= GEMM 1: H1 = W1 @ xa ==========================================================
-    rb_dma_A<R>(wq1, p.pw1.Mp, 0, S4, wave, lane);
-    dma_B(0, S4 + R::A4);
-    __syncthreads();
-    for (int c = 0; c < NCH; ++c) {
-        const f32x4* S = S4 + (c & 1) * R::STAGE4;
-        f32x4* Sn = S4 + ((c + 1) & 1) * R::STAGE4;
-        if (c + 1 < NCH) { rb_dma_A<R>(wq1, p.pw1.Mp, c + 1, Sn, wave, lane); dma_B(c + 1, Sn + R::A4); }
-        else rb_dma_A<R>(wq2, p.pw2.Mp, 0, Sn, wave, lane);   // first weights of GEMM 2 land behind epilogue 1
-        rb_chunk<R>(acc, S, reinterpret_cast<const float*>(S + R::A4), wave, h, i31);
-        __syncthreads();
-    }
-    // ================= epilogue 1: u = ELU(DW5(H1) + b1) -> LDS ========================================
-    const int o = R::NT * q;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.tab1 + row * 8);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(p.tab1 + row * 8 + 4);
-        float y[R::NT];
-        rb_stencil<R::NT>(acc, r, w0, w1, y);
-        ovec uv;
-#pragma unroll
-        for (int e = 0; e < R::NT; ++e) {
-            const bool ok = o + e <= R::BN - 5 && ti0 + 4 + o + e >= 0;
-            uv[e] = ok ? elu1(y[e] * 1.f) : 0.f;
-        }
-        *reinterpret_cast<ovec*>(U + row * R::BN + o) = uv;
-#pragma unroll
-        for (int e = 0; e < R::NT; ++e) acc[e][r] = 0.f;
-    }
-    // residual rows of epilogue 2 in flight across GEMM 2
-    const float* Xrb = p.Xr + (size_t)b * R::C * T;
-    const int to = to0 + o;
-    const bool act_lane = o < R::TTO && to < T;                // T % 4 == 0 and TTO % NT == 0: whole vectors
-    ovec res[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-        ovec v;
-#pragma unroll
-        for (int e = 0; e < R::NT; ++e) v[e] = 0.f;
-        if (act_lane) v = *reinterpret_cast<const ovec*>(Xrb + (size_t)row * T + to);
-        res[r] = v;
-    }
-    __syncthreads();                                           // u complete (also waits for the A DMA of GEMM 2, chunk 0)
-    // ================= GEMM 2: H2 = W2 @ u (B operand resident) ========================================
-    for (int c = 0; c < NCH; ++c) {
-        const f32x4* S = S4 + ((NCH + c) & 1) * R::STAGE4;
-        if (c + 1 < NCH) rb_dma_A<R>(wq2, p.pw2.Mp, c + 1, S4 + ((NCH + c + 1) & 1) * R::STAGE4, wave, lane);
-        rb_chunk<R>(acc, S, U + (size_t)(c * 16) * R::BN, wave, h, i31);
-        __syncthreads();
-    }
-    // ================= epilogue 2: y = x + s * (DW5(H2) + b2) ===========================================
-    float* Yb = p.Y ? p.Y + (size_t)b * R::C * T : nullptr;
-    float* Ab = p.Yact ? p.Yact + (size_t)b * R::C * T : nullptr;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.tab2 + row * 8);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(p.tab2 + row * 8 + 4);
-        float y[R::NT];
-        rb_stencil<R::NT>(acc, r, w0, w1, y);
-        const ovec rr = res[r & 3];
-        if (r + 4 < 16) {
-            const int rown = 32 * wave + ((r + 4) & 3) + 8 * ((r + 4) >> 2) + 4 * h;
-            ovec v;
-#pragma unroll
-            for (int e = 0; e < R::NT; ++e) v[e] = 0.f;
-            if (act_lane) v = *reinterpret_cast<const ovec*>(Xrb + (size_t)rown * T + to);
-            res[r & 3] = v;
-        }
-        if (act_lane) {
-            ovec yv, av;
-#pragma unroll
-            for (int e = 0; e < R::NT; ++e) { yv[e] = fmaf(y[e], p.out_scale, rr[e]); av[e] = elu1(yv[e] * p.act_scale); }
-            const size_t yo = (size_t)row * T + to;
-            if (Yb) *reinterpret_cast<ovec*>(Yb + yo) = yv;
-            if (Ab) *reinterpret_cast<ovec*>(Ab + yo) = av;
-        }
-    }
-}
-
-bool rb_supported(const RbArgs& a) {
-    if (!(a.C == 64 || a.C == 96 || a.C == 128 || a.C == 192)) return false;
-    if (!a.Xa || !a.Xr || (a.T & 3) || !a.pw1.wq || !a.pw2.wq || !a.tab1 || !a.tab2) return false;
-    if (a.pw1.M != a.C || a.pw1.K != a.C || a.pw2.M != a.C || a.pw2.K != a.C) return false;
-    return aligned16(a.Xa) && aligned16(a.Xr) && (!a.Y || aligned16(a.Y)) && (!a.Yact || aligned16(a.Yact));
-}
-
-template <class R>
-static hipError_t rb_run(RbArgs a, hipStream_t s) {
-    a.num_t = (a.T + R::TTO - 1) / R::TTO;
-    const long long nblk = (long long)a.num_t * a.B;
-    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    static std::atomic<unsigned> attr{0};
-    if (R::SMEM > 64 * 1024) {
-        int d = 0; (void)hipGetDevice(&d);
-        const unsigned bit = 1u << (d & 31);
-        if (!(attr.load(std::memory_order_relaxed) & bit)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<R>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::SMEM);
-            if (e != hipSuccess) return e;
-            attr.fetch_or(bit, std::memory_order_relaxed);
-        }
-    }
-    std::string name;
-    if (prof::enabled()) name = "resblock<" + std::to_string(R::C) + "," + std::to_string(R::BN) + ">";
-    const double C = a.C, Bd = a.B, T = a.T;
-    prof::Scope ps(s, name.c_str(), 2.0 * 2.0 * Bd * C * (C * T + 5.0 * T),
-                   4.0 * Bd * C * T * (2.0 + (a.Y ? 1.0 : 0.0) + (a.Yact ? 1.0 : 0.0)));
-    hipLaunchKernelGGL(resblock_kernel<R>, dim3((unsigned)nblk), dim3(R::NTHREADS), R::SMEM, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_resblock(const RbArgs& a, hipStream_t s) {
-    if (!rb_supported(a)) return hipErrorNotSupported;
-    switch (a.C) {                                                // 64-column windows: the measured better width for every C
-        case 64: return rb_run<RB<64, 2>>(a, s);
-        case 96: return rb_run<RB<96, 2>>(a, s);
-        case 128: return rb_run<RB<128, 2>>(a, s);
-        default: return rb_run<RB<192, 2>>(a, s);
-    }
-}
-
 }  // namespace wv

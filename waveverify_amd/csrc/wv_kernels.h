@@ -60,18 +60,18 @@ hipError_t launch_pw_dw(const PwDwArgs& a, hipStream_t s);
 bool k1_supported(const PwDwArgs& a);
 hipError_t launch_k1(const PwDwArgs& a, hipStream_t s);   // hipErrorNotSupported: use the round-1 kernel
 bool pw_dw_geometry(PwDwArgs& a, int BN);                 // time-tile geometry shared by both cores
-// ---- whole ResnetBlock in one launch (C <= 192; wv_k1.hip) -----------------------------------
+// ---- whole ResnetBlock in one launch, raw in / raw out (C in {64, 96, 128, 192}; wv_rb.hip) -------------
 struct RbArgs {
-    const float* Xa;      // [B, C, T] ELU(pre_scale * x): the block's input, pre-activated by its producer
-    const float* Xr;      // [B, C, T] x (residual operand)
-    PwWeight pw1, pw2;    // the two 1x1 convs (no bias)
+    const float* X;       // [B, C, T] x: the block's input (activated inside) and its residual operand
+    float pre_scale;      // the block's Scale in front of its first ELU (seanet.py:183)
+    PwWeight pw1, pw2;    // the two 1x1 convs (no bias); only the k-inner layout wq is read
     const float* tab1;    // [C][8] per channel: 5 depth-wise taps, bias, 1, 0 (pack_rb_table)
     const float* tab2;
     float* Y;             // [B, C, T] y = x + out_scale * block(x), or null
     float* Yact;          // [B, C, T] ELU(act_scale * y), or null
     float out_scale, act_scale;
     int B, C, T;
-    int num_t;            // filled by the launcher
+    int num_t, ntiles;    // filled by the launcher: tiles per clip, tiles in all
 };
 bool rb_supported(const RbArgs& a);
 hipError_t launch_resblock(const RbArgs& a, hipStream_t s);   // hipErrorNotSupported: run it as two K1 launches

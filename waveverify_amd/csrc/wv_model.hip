@@ -482,11 +482,15 @@ WsLayout layout(const wv_model* m, int B, int T) {
 // by the producer's epilogue, PwDwArgs::Yact, so that the consumer stages it by LDS-DMA), either may be
 // null.  r[2] / a[2] are the ping-pong buffers behind them, u the ResnetBlock intermediate.
 // Does a ResnetBlock of C channels want its input pre-activated by the producer (second output, one more HBM
-// write pass) or does its first unit apply scale -> ELU itself while staging through registers?  Narrow layers
-// (one m-tile: no redundant activation work, and they are bandwidth-bound) activate themselves.
-// Measured (one box, interleaved): self-activation wins up to C = 128 (-1.8 ms/step), the producer-side copy from C = 129 up;
-// re-measured after the epilogues lost their waterfall loops: thresholds 129 / 97 / 65 / 0 -> 81.2 / 82.1 / 82.5 / 83.7 ms per step.
-inline bool wants_act_copy(int C) { return C >= 129; }
+// write pass)?  Blocks the one-launch kernel takes (wv_rb.hip: C in {64, 96, 128, 192}, k = 5, dilation 1, T % 4 == 0)
+// read x raw and activate it on the way into LDS.  Blocks run as two K1 launches: narrow ones (one m-tile,
+// bandwidth-bound) apply scale -> ELU themselves while staging through registers, from C = 129 up the producer-side
+// copy wins (measured, one box, interleaved: thresholds 129 / 97 / 65 / 0 -> 81.2 / 82.1 / 82.5 / 83.7 ms per step).
+inline bool fused_block(const wv_config& c, int C, int T) {
+    return (C == 64 || C == 96 || C == 128 || C == 192) && c.residual_kernel_size == 5 && c.dilation_base == 1 && (T & 3) == 0 &&
+           (long long)C * T * 4 < 0x7f000000LL;
+}
+inline bool wants_act_copy(const wv_config& c, int C, int T) { return C >= 129 && !fused_block(c, C, T); }
 
 struct Stream {
     float* r[2]; float* a[2]; float* u;
@@ -495,18 +499,15 @@ struct Stream {
     float* other_act() const { return act == a[0] ? a[1] : a[0]; }
 };
 
-// SEANetResnetBlock (seanet.py:245-281) as two K1 launches.  next_scale > 0: also write ELU(next_scale*y);
+// SEANetResnetBlock (seanet.py:245-281): one launch for the narrow layers (wv_rb.hip), else two K1 launches.  next_scale > 0: also write ELU(next_scale*y);
 // want_raw: write y itself (needed when y is a later residual / raw operand).
 int run_resblock(const ResBlock& r, Stream& st, bool want_raw, float next_scale, int B, int T, hipStream_t s,
                  const char* role) {
     wv::prof::set_role(role);
-    // Fused form: measured slower than two K1 launches until it is made persistent;
-    // opt-in with WV_FUSED_RB=1 for tools/rbbench.py and the parity tests of the in-model path.
-    static const bool fused_on = getenv("WV_FUSED_RB") && atoi(getenv("WV_FUSED_RB")) != 0;
-    if (fused_on && st.act && st.raw && r.tab1 && r.dil1 == 1 && r.dil2 == 1) {
-        // narrow layers: the whole block in one launch, the intermediate stays in LDS (wv_k1.hip)
+    if (st.raw && r.tab1 && r.dil1 == 1 && r.dil2 == 1) {
+        // narrow layers: the whole block in one launch, raw in / raw out, the intermediate stays in LDS (wv_rb.hip)
         wv::RbArgs f{};
-        f.Xa = st.act; f.Xr = st.raw; f.pw1 = r.pw1; f.pw2 = r.pw2; f.tab1 = r.tab1; f.tab2 = r.tab2;
+        f.X = st.raw; f.pre_scale = r.pre_scale; f.pw1 = r.pw1; f.pw2 = r.pw2; f.tab1 = r.tab1; f.tab2 = r.tab2;
         f.Y = want_raw ? st.other_raw() : nullptr;
         f.Yact = next_scale > 0.f ? st.other_act() : nullptr;
         f.out_scale = r.out_scale; f.act_scale = next_scale; f.B = B; f.C = r.pw1.M; f.T = T;
@@ -569,7 +570,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
     }
     wv::prof::set_role("enc.conv_pre");
     sm.raw = sm.r[0];
-    sm.act = (m->enc_blocks[0].empty() || !wants_act_copy(c.channels_enc)) ? nullptr : sm.a[0];   // also ELU(c1 * y) for the first ResnetBlock
+    sm.act = (m->enc_blocks[0].empty() || !wants_act_copy(c, c.channels_enc, T)) ? nullptr : sm.a[0];   // also ELU(c1 * y) for the first ResnetBlock
     LAUNCH(wv::launch_conv_pre(x, m->pre_w, m->pre_b, sm.raw, sm.act, sm.act ? m->enc_blocks[0][0].pre_scale : 0.f,
                                B, c.channels_enc, T, c.kernel_size, 1.f / c.wav_std, st));
     int Tl = T, C = c.channels_enc;
@@ -581,7 +582,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
             for (size_t j = 0; j < blocks.size(); ++j) {
                 // the last block feeds the SpecBlock add, which takes y raw (as its residual operand)
                 const bool last = j + 1 == blocks.size();
-                int rc = run_resblock(blocks[j], sm, true, (last || !wants_act_copy(C)) ? 0.f : blocks[j + 1].pre_scale, B, Tl, st,
+                int rc = run_resblock(blocks[j], sm, true, (last || !wants_act_copy(c, C, Tl)) ? 0.f : blocks[j + 1].pre_scale, B, Tl, st,
                                       "enc.resblock");
                 if (rc) return rc;
             }
@@ -623,7 +624,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         wv::PwDwArgs a{};
         if (sm.act) { a.X = sm.act; a.pre_scale = 1.f; a.pre_elu = 0; }
         else { a.X = sm.raw; a.pre_scale = d.pre_scale; a.pre_elu = 1; }
-        const bool next_has_blocks = s + 1 < c.n_strides && !m->enc_blocks[s + 1].empty() && wants_act_copy(2 * C);
+        const bool next_has_blocks = s + 1 < c.n_strides && !m->enc_blocks[s + 1].empty() && wants_act_copy(c, 2 * C, (Tl + d.ratio - 1) / d.ratio);
         float* yr = sm.raw ? sm.other_raw() : sm.r[0];
         float* ya = next_has_blocks ? (sm.act ? sm.other_act() : sm.a[0]) : nullptr;
         a.pw = d.pw; a.dw_w = d.dw_w; a.dw_b = d.dw_b; a.Y = yr; a.Yact = ya;
@@ -849,7 +850,7 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
         a.X = sm.act; a.ct_w = u.ct_w; a.ct_wt = u.ct_wt; a.ratio = u.ratio; a.pw = u.pw; a.dw_w = u.id_taps; a.dw_b = u.pw_b;
         const bool has_blocks = !u.res.empty();
         a.Y = (has_blocks || last_up) ? sm.r[0] : nullptr;
-        const bool blocks_act = has_blocks && wants_act_copy(u.pw.M);
+        const bool blocks_act = has_blocks && wants_act_copy(c, u.pw.M, Tl * u.ratio);
         a.Yact = has_blocks ? (blocks_act ? sm.other_act() : nullptr) : (last_up ? nullptr : sm.other_act());
         a.act_scale = has_blocks ? u.res[0].pre_scale : stage_next;
         a.B = B; a.Tin = Tl; a.Tout = Tl * u.ratio; a.ks = 5; a.stride = 1; a.dil = 1; a.pad = 4;
@@ -859,7 +860,7 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
         Tl = a.Tout;
         for (size_t j = 0; j < u.res.size(); ++j) {
             const bool last = j + 1 == u.res.size();
-            const float next = last ? stage_next : (wants_act_copy(u.pw.M) ? u.res[j + 1].pre_scale : 0.f);
+            const float next = last ? stage_next : (wants_act_copy(c, u.pw.M, Tl) ? u.res[j + 1].pre_scale : 0.f);
             rc = run_resblock(u.res[j], sm, !last || last_up, next, B, Tl, st, "dec.resblock");
             if (rc) return rc;
         }

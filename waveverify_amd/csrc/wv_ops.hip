@@ -70,13 +70,13 @@ int wv_op_pw_dw(const float* X, const float* w_pw, const float* w_dw, const floa
     return done(t, wv::launch_pw_dw(a, (hipStream_t)stream), (hipStream_t)stream);
 }
 
-int wv_op_resblock(const float* Xa, const float* Xr, const float* w_pw1, const float* w_dw1, const float* b1,
+int wv_op_resblock(const float* X, float pre_scale, const float* w_pw1, const float* w_dw1, const float* b1,
                    const float* w_pw2, const float* w_dw2, const float* b2, float* Y, float* Yact,
                    int B, int C, int T, float out_scale, float act_scale, void* stream) {
-    if (!Xa || !Xr || !w_pw1 || !w_dw1 || !w_pw2 || !w_dw2 || (!Y && !Yact) || B < 1 || C < 1 || T < 1) return WV_EINVAL;
+    if (!X || !w_pw1 || !w_dw1 || !w_pw2 || !w_dw2 || (!Y && !Yact) || B < 1 || C < 1 || T < 1) return WV_EINVAL;
     Tmp t;
     wv::RbArgs a{};
-    a.Xa = Xa; a.Xr = Xr; a.pw1 = t.pw(w_pw1, C, C); a.pw2 = t.pw(w_pw2, C, C);
+    a.X = X; a.pre_scale = pre_scale; a.pw1 = t.pw(w_pw1, C, C); a.pw2 = t.pw(w_pw2, C, C);
     a.tab1 = t.upv(wv::pack_rb_table(w_dw1, b1, C)); a.tab2 = t.upv(wv::pack_rb_table(w_dw2, b2, C));
     a.Y = Y; a.Yact = Yact; a.out_scale = out_scale; a.act_scale = act_scale; a.B = B; a.C = C; a.T = T;
     const hipError_t e = wv::launch_resblock(a, (hipStream_t)stream);

@@ -60,17 +60,21 @@ def pw_dw(X, w_pw, w_dw, dw_bias=None, film=None, resid=None, stride=1, dilation
     return Y if act_scale is None else (Y, Yact)
 
 
-def resblock(Xa, Xr, w_pw1, w_dw1, b1, w_pw2, w_dw2, b2, out_scale=1.0, act_scale: Optional[float] = None):
-    """Fused SEANetResnetBlock on a pre-activated input Xa = ELU(pre_scale * Xr); -> Y or (Y, Yact)."""
+def resblock(X, w_pw1, w_dw1, b1, w_pw2, w_dw2, b2, pre_scale=1.0, out_scale=1.0, act_scale: Optional[float] = None,
+             want_raw: bool = True):
+    """Fused SEANetResnetBlock, raw in / raw out: y = X + out_scale * half2(half1(ELU(pre_scale * X))).
+    -> Y, or (Y, Yact) with act_scale given, or Yact alone with want_raw=False."""
     lib = _lib.load()
-    Xa, Xr = _dev(Xa), _dev(Xr)
-    B, Cc, T = Xr.shape
+    X = _dev(X)
+    B, Cc, T = X.shape
     ws = [_w(w_pw1).reshape(Cc, Cc), _w(w_dw1).reshape(Cc, -1), _w(b1), _w(w_pw2).reshape(Cc, Cc),
           _w(w_dw2).reshape(Cc, -1), _w(b2)]
-    Y = torch.empty_like(Xr)
-    Yact = torch.empty_like(Xr) if act_scale is not None else None
-    _lib.check(lib.wv_op_resblock(Xa.data_ptr(), Xr.data_ptr(), *[_hp(w) for w in ws], Y.data_ptr(), _dp(Yact),
+    Y = torch.empty_like(X) if want_raw else None
+    Yact = torch.empty_like(X) if act_scale is not None else None
+    _lib.check(lib.wv_op_resblock(X.data_ptr(), float(pre_scale), *[_hp(w) for w in ws], _dp(Y), _dp(Yact),
                                   B, Cc, T, out_scale, float(act_scale or 0.0), _stream()), "wv_op_resblock")
+    if Y is None:
+        return Yact
     return Y if act_scale is None else (Y, Yact)
 
 
