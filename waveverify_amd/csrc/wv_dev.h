@@ -10,7 +10,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));   // 4-byte aligned pair (global loads may be unaligned)
 constexpr int NT_ = 256;   // threads per workgroup
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
+// ELU(x) = x > 0 ? x : exp(x) - 1, as the median of (x, exp(x) - 1, 0): exp(x) - 1 lies above x on both sides of zero, so for
+// x > 0 the middle value is x and for x < 0 it is exp(x) - 1 -- the same values as the select form, one v_med3_f32 instead of a
+// compare + select through VCC (f32 matrix work shares the SIMD's lanes with VALU work: every instruction here is matrix time)
+__device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
 __device__ __forceinline__ float act(float x, float scale, int elu) {
     x *= scale;
     return elu ? elu1(x) : x;

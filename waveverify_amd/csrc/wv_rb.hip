@@ -5,19 +5,22 @@
 //
 // As two K1 launches such a block crosses HBM five times (read x, write u, read u, read x, write y) and both
 // launches are bandwidth- or latency-bound (profiles/r02_chunked_batch_infinity_cache.txt: 49-80 TFLOP/s).  Here
-// a PERSISTENT workgroup owns all C channels of one time window after the other:
+// a PERSISTENT workgroup owns all C channels of one time window after the other, and x is read from HBM ONCE:
 //
-//   * x arrives raw, once: every thread fetches its 16-byte pieces of the NEXT window into registers while the
-//     current one computes (issued at the start of epilogue 1, consumed a whole tile later), activates them
-//     (scale -> ELU, once per element) and writes them into the window buffer S[C][WD] in LDS -- the natural
-//     [k][t] layout the B operand is read from.
-//   * The weights never touch LDS: a wave owns one 32-row strip of W1 / W2 and streams its A fragments
-//     (two 16-byte loads per 16-deep chunk, L2-resident packed layout wq[k/4][m][4]) one chunk ahead into
-//     registers.  No A staging, no per-chunk barrier: FOUR barriers per tile (K1 as two launches: 8-24).
+//   * The next window's x is copied into the window buffer S[C][WD] by LDS-DMA (buffer_load ... lds), all of it issued in
+//     one burst when the second GEMM has finished with the buffer and BEFORE epilogue 2's stores, whose VALU work and
+//     store issue cover its latency.  (Refill loads interleaved with the stores doubled the time of that epilogue; a
+//     residual re-read from global memory went past L2 -- 2.3x the x bytes fetched, profiles/r03_resblock_traffic.txt.)
+//   * The activation pass reads x back from S in the MFMA accumulator layout (a lane takes exactly the elements where
+//     its own outputs lie: 16 rows of its wave's 32-row strip x NT consecutive columns), keeps them raw in registers --
+//     the residual operand of epilogue 2 -- and writes ELU(c*x) in place: the natural [k][t] layout the B operand is
+//     read from.  The 8 halo columns in front are activated in place by a few extra 16-byte pieces.
+//   * The weights never touch LDS: a wave owns one 32-row strip of W1 / W2 and streams its A fragments (two
+//     16-byte buffer loads per 16-deep chunk, L2-resident packed layout wq[k/4][m][4]) into a register ring.
+//     No A staging, no per-chunk barrier: FOUR barriers per tile (K1 as two launches: 8-24).
 //   * u = ELU(DW5(H1) + b1) is written over the same buffer (after a barrier) and is the B operand of the
 //     second GEMM; it never leaves the CU.  Both stencils run from the accumulators (a lane holds NT
-//     consecutive columns; right neighbours by DPP), as in K1's k5 epilogue.
-//   * The residual x is re-read from L2 in epilogue 2 (the window was fetched by this CU one tile ago).
+//     consecutive columns; the right neighbours' taps are DPP operands of the multiply-adds themselves).
 //
 // Geometry.  Waves = (C/32 row strips) x (NG column groups of 32*NT columns).  Adjacent groups overlap by the
 // stencil's 4 columns, so a window holds WD = NG*(32*NT-4)+4 columns and yields TTO = WD-8 outputs (the
@@ -37,17 +40,45 @@ namespace wv {
 
 namespace {
 
-__device__ __forceinline__ float rb_dpp_next(float v) {        // lane i <- lane i+1 (wave_shl:1), lane 63 <- 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-}
-
 template <int NT> struct RbVec;
 template <> struct RbVec<4> { typedef f32x4 type; };
 template <> struct RbVec<2> { typedef f32x2 type; };
 
 constexpr int RB_OOB = 0x7f000000;                              // byte offset beyond any num_records here
-#ifndef RB_SCHED_MASK
-#define RB_SCHED_MASK 0
+// geometry per channel count: <C, column groups, 32-column tiles per wave, waves per SIMD>
+#ifndef RB_CFG64
+#define RB_CFG64 RB<64, 2, 4, 2>                                // 2 x 2 waves, 252-column windows, two workgroups per CU
+#endif
+#ifndef RB_CFG96
+#define RB_CFG96 RB<96, 4, 2, 3>                                // 3 x 4 waves, 244-column windows
+#endif
+#ifndef RB_CFG128
+#define RB_CFG128 RB<128, 2, 4, 2>                              // 4 x 2 waves, 252-column windows
+#endif
+#ifndef RB_CFG192
+#define RB_CFG192 RB<192, 2, 2, 3>                              // 6 x 2 waves, 124-column windows
+#endif
+#ifndef RB_PD
+#define RB_PD 3                                                 // B rows in flight ahead of their MFMAs
+#endif
+#ifndef RB_AD
+#define RB_AD 1                                                 // A chunks in flight ahead of their MFMAs (ring of RB_AD + 1; 1 or 3)
+#endif
+
+#ifndef RB_X
+#define RB_X 0        // timing ablations for tools/variant.sh builds only (results are WRONG with any bit set): 1 no ELU, 2 plain fma
+#endif                // instead of the DPP multiply-adds, 4 no LDS writes, 8 no stores, 16 no refill loads, 32 no exp in the ELUs
+__device__ __forceinline__ float rb_elu(float x) {
+    if (RB_X & 1) return x;
+    if (RB_X & 32) return __builtin_amdgcn_fmed3f(x, x * 1.4426950408889634f - 1.f, 0.f);
+    return elu1(x);
+}
+// Diagnostic builds only (tools/variant.sh ... -DRB_STAMP): per-phase shader-clock totals of every wave, written over the head of
+// the output tensor at the end (tools/rbbench.py --stamps reads them back; the output is garbage then).
+#ifdef RB_STAMP
+#define RB_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define RB_T(i) do {} while (0)
 #endif
 
 // C channels, NG column groups, NT 32-column tiles per wave (interleaved: tile e = columns NT*j + e), WPS waves per SIMD
@@ -58,13 +89,13 @@ struct RB {
     static constexpr int GS = 32 * NT - 4;                      // columns a group contributes
     static constexpr int WD = NG * GS + 4;                      // window columns in LDS
     static constexpr int TTO = WD - 8;                          // outputs per tile
-    static constexpr int LD = WD;                               // LDS row stride: pieces of a window are contiguous
+    static constexpr int LD = WD;                               // LDS row stride
     static constexpr int NCH = C / 16;
     static constexpr int W4 = WD / 4, P4 = C * W4;              // 16-byte pieces per row / per window
-    static constexpr int RT = NTHREADS / W4;                    // rows the x fetch covers per pass
-    static constexpr int XPER = C / RT;                         // pieces a thread carries
-    static constexpr size_t SMEM = ((size_t)C * LD + 2 * C * 8) * sizeof(float);
-    static_assert(C % 32 == 0 && WD % 4 == 0 && (NT == 2 || NT == 4) && C % RT == 0, "geometry");
+    static constexpr int NI = (P4 + NTHREADS - 1) / NTHREADS;   // LDS-DMA instructions per wave and window (64 pieces each)
+    static constexpr size_t SMEM = ((size_t)NI * NTHREADS * 4 + 2 * C * 8) * sizeof(float);   // the last DMA piece may run past C * LD
+    static_assert(C % 32 == 0 && WD % 4 == 0 && (NT == 2 || NT == 4) && NTHREADS >= 2 * C, "geometry");
+    static_assert((2 * NCH) % (RB_AD + 1) == 0, "the A ring must close over a tile");
 };
 
 #define RB_BARRIER()                                             \
@@ -74,40 +105,80 @@ struct RB {
         asm volatile("" ::: "memory");                           \
     } while (0)
 
-// 5-tap stencil from the accumulators: y[e] = bias + sum_i w[i] * H[NT*q + e + i]  (taps ascending, as K1)
+__device__ __forceinline__ float rb_dpp_next(float v) {        // lane i <- lane i+1 (wave_shl:1), lane 63 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+// y += w * (the next lane's h): the lane shift is a DPP operand of the multiply-add itself (v_fmac_f32 is a fused
+// multiply-add, so this rounds like fmaf).  h must not have been written by the instruction right before.
+__device__ __forceinline__ void rb_fma_next(float& y, float h, float w) {
+    if (RB_X & 2) { y = fmaf(w, h, y); return; }
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(y) : "v"(h), "v"(w));
+}
+
+// 5-tap stencil from the accumulators: y[e] = bias + sum_i w[i] * H[NT*q + e + i]  (taps ascending, as K1).  Columns past the lane's
+// own NT come from the next lane (NT = 4) or the next two (NT = 2: one shifted copy, then the same DPP multiply-add on it).
 template <int NT>
 __device__ __forceinline__ void rb_stencil(const f32x16 (&acc)[NT], int r, const f32x4& w0, const f32x4& w1, float (&y)[NT]) {
-    constexpr int NSH = 4 / NT;
-    float hh[NT + 4], cur[NT];
+    const float w[5] = {w0.x, w0.y, w0.z, w0.w, w1.x};
+    float own[NT];
 #pragma unroll
-    for (int e = 0; e < NT; ++e) { cur[e] = acc[e][r]; hh[e] = cur[e]; }
+    for (int e = 0; e < NT; ++e) own[e] = acc[e][r];
+    if constexpr (NT == 4) {
 #pragma unroll
-    for (int s = 1; s <= NSH; ++s) {
+        for (int e = 0; e < 4; ++e) {
+            float v = w1.y;
 #pragma unroll
-        for (int e = 0; e < NT; ++e) { cur[e] = rb_dpp_next(cur[e]); hh[s * NT + e] = cur[e]; }
-    }
+            for (int i = 0; i + e < 4; ++i) v = fmaf(w[i], own[e + i], v);
+            y[e] = v;
+        }
 #pragma unroll
-    for (int e = 0; e < NT; ++e) {
-        float v = fmaf(w0.x, hh[e], w1.y);
-        v = fmaf(w0.y, hh[e + 1], v); v = fmaf(w0.z, hh[e + 2], v);
-        v = fmaf(w0.w, hh[e + 3], v); v = fmaf(w1.x, hh[e + 4], v);
-        y[e] = v;
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 4 - e; i < 5; ++i) rb_fma_next(y[e], own[e + i - 4], w[i]);
+    } else {
+        float sh[2] = {rb_dpp_next(own[0]), rb_dpp_next(own[1])};        // columns 2q + 2, 2q + 3
+        float v0 = fmaf(w[0], own[0], w1.y), v1 = fmaf(w[0], own[1], w1.y);
+        v0 = fmaf(w[1], own[1], v0);
+        rb_fma_next(v1, own[0], w[1]);
+        rb_fma_next(v0, own[0], w[2]); rb_fma_next(v1, own[1], w[2]);
+        rb_fma_next(v0, own[1], w[3]);
+        asm volatile("" : "+v"(sh[0]), "+v"(sh[1]));                     // the shifted copies are complete before they are DPP operands
+        rb_fma_next(v1, sh[0], w[3]);
+        rb_fma_next(v0, sh[0], w[4]); rb_fma_next(v1, sh[1], w[4]);
+        y[0] = v0; y[1] = v1;
     }
 }
 
-// one 16-deep chunk of MFMAs: A fragments a0 / a1 from registers, B rows 16c .. 16c+15 of the window
-template <class R>
-__device__ __forceinline__ void rb_chunk(f32x16 (&acc)[R::NT], const f32x4& a0, const f32x4& a1, const float* Bf, int c, int h) {
+// One GEMM of the block: acc = W @ S over all C rows of the window.  A fragments: global chunk g in ar[g % NA], loaded AD chunks
+// ahead at the head of a chunk; the chunks after the last wrap into the OTHER matrix (rw_next) for the GEMM that follows.  B rows: one
+// ds_read per 2-deep step (a lane's NT columns of row k; lane half h owns k in [4h,4h+4) U [8+4h,12+4h) of every 16), issued PD steps
+// ahead of the MFMAs that consume them into a ring of PD + 1 row vectors.  The order is pinned (scheduling barrier per step): left to
+// itself the compiler issues each read right in front of its MFMAs and sinks the A loads to the end of the chunk, so that both
+// latencies are exposed once per step / chunk.
+template <class R, int G0, class LoadA>
+__device__ __forceinline__ void rb_gemm(f32x16 (&acc)[R::NT], f32x4 (&ar)[RB_AD + 1][2], const float* Bf, LoadA&& load_a,
+                                        const __amdgpu_buffer_rsrc_t& rw, const __amdgpu_buffer_rsrc_t& rw_next) {
     typedef typename RbVec<R::NT>::type bvec;
-#define WV_RB_STEP(AV, ROW)                                                                        \
-    { const bvec bv = *reinterpret_cast<const bvec*>(Bf + (ROW) * R::LD);                          \
-      _Pragma("unroll") for (int e = 0; e < R::NT; ++e)                                            \
-          acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, bv[e], acc[e], 0, 0, 0); }
-    WV_RB_STEP(a0.x, 16 * c + 4 * h + 0) WV_RB_STEP(a0.y, 16 * c + 4 * h + 1)
-    WV_RB_STEP(a0.z, 16 * c + 4 * h + 2) WV_RB_STEP(a0.w, 16 * c + 4 * h + 3)
-    WV_RB_STEP(a1.x, 16 * c + 8 + 4 * h + 0) WV_RB_STEP(a1.y, 16 * c + 8 + 4 * h + 1)
-    WV_RB_STEP(a1.z, 16 * c + 8 + 4 * h + 2) WV_RB_STEP(a1.w, 16 * c + 8 + 4 * h + 3)
-#undef WV_RB_STEP
+    constexpr int NS = 8 * R::NCH, PD = RB_PD, NB = PD + 1, AD = RB_AD, NA = AD + 1;
+    bvec bq[NB];
+    auto row_of = [](int s) { return 16 * (s >> 3) + ((s & 7) < 4 ? (s & 7) : 4 + (s & 7)); };     // + 4h, folded into Bf
+#pragma unroll
+    for (int s = 0; s < PD; ++s) bq[s % NB] = *reinterpret_cast<const bvec*>(Bf + row_of(s) * R::LD);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int c = s >> 3, j = s & 7;
+        if (j == 0) {
+            if (c + AD < R::NCH) load_a(rw, c + AD, ar[(G0 + c + AD) % NA]);
+            else load_a(rw_next, c + AD - R::NCH, ar[(G0 + c + AD) % NA]);
+        }
+        if (s + PD < NS) bq[(s + PD) % NB] = *reinterpret_cast<const bvec*>(Bf + row_of(s + PD) * R::LD);
+        const f32x4 av = ar[(G0 + c) % NA][j >> 2];
+        const float a = av[j & 3];
+        const bvec bv = bq[s % NB];
+#pragma unroll
+        for (int e = 0; e < R::NT; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[e], acc[e], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // OUT: 1 = Y, 2 = Yact, 3 = both
@@ -116,91 +187,125 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef typename RbVec<R::NT>::type ovec;
     typedef unsigned uvec __attribute__((ext_vector_type(R::NT)));
-    constexpr int NT = R::NT, C = R::C, LD = R::LD, NCH = R::NCH;
+    constexpr int NT = R::NT, C = R::C, LD = R::LD, NCH = R::NCH, AD = RB_AD, NA = AD + 1;
     float* S = smem;
-    float* tab = smem + C * LD;                                  // [2][C][8]: taps, bias
+    float* tab = smem + R::NI * R::NTHREADS * 4;                 // [2][C][8]: taps, bias
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int strip = wave % R::WM, grp = wave / R::WM;
     const int h = lane >> 5, q = lane & 31;
     const int T = p.T, ntiles = p.ntiles, num_t = p.num_t;
+    const int row_bytes = T * 4, clip_bytes = C * T * 4;
 
     for (int i = tid; i < C * 8; i += R::NTHREADS) { tab[i] = p.tab1[i]; tab[C * 8 + i] = p.tab2[i]; }
 
     // ---- A fragments: wq[k/4][Mp][4]; chunk c, lane half h: a0 = wq[4c + h][m], a1 = wq[4c + h + 2][m].  Buffer loads: one
-    // per-lane byte offset per matrix, the chunk as a compile-time scalar offset (per-chunk 64-bit addresses, hoisted out
-    // of the tile loop by the compiler, cost 8 registers per chunk)
+    // per-lane byte offset, the chunk as a compile-time scalar offset (per-chunk 64-bit addresses, hoisted out of the tile loop by
+    // the compiler, cost 8 registers per chunk)
     constexpr int MP = (C + M_ALIGN - 1) / M_ALIGN * M_ALIGN;    // the packed weights' row count (PwWeight::Mp)
     const __amdgpu_buffer_rsrc_t rW1 = uniform_rsrc(p.pw1.wq, NCH * 4 * MP * 16);
     const __amdgpu_buffer_rsrc_t rW2 = uniform_rsrc(p.pw2.wq, NCH * 4 * MP * 16);
     const int avoff = (h * MP + 32 * strip + q) * 16;
-    f32x4 ar[2][2];
+    f32x4 ar[NA][2];
     auto load_a = [&](const __amdgpu_buffer_rsrc_t& rw, int c, f32x4 (&dst)[2]) {
         dst[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, avoff, c * 4 * MP * 16, 0));
         dst[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, avoff, (c * 4 + 2) * MP * 16, 0));
     };
 
-    // ---- x pieces of one window: threads form an [RT rows][W4 pieces] grid (the few left over idle here); piece i of a
-    // thread is row xr + i * RT at its own column, so its address is one per-lane offset plus a scalar step and the edge
-    // test (T % 4 == 0: a piece is all inside [0,T) or all outside) is per thread, not per piece
-    const int xr = tid / R::W4, xc = tid - xr * R::W4;
-    const bool xthread = tid < R::RT * R::W4;
-    f32x4 xp[R::XPER];
-    auto xfetch = [&](int tile) {
-        const int b = tile / num_t, tt = tile - b * num_t;
-        const int t = tt * R::TTO - 8 + 4 * xc;
-        const __amdgpu_buffer_rsrc_t rX = uniform_rsrc(p.X + (size_t)b * C * T, C * T * 4);
-        const int voff = (xthread && t >= 0 && t < T) ? (xr * T + t) * 4 : RB_OOB;
+    // ---- this lane's place in a window: rows 32*strip + 4h + (r&3) + 8(r>>2), r = 0..15; x / S columns co + 8 .. (its outputs are
+    // columns co .. co + NT - 1 of the tile), B / u columns co ..
+    const int co = R::GS * grp + NT * q;                         // first output (= u, H) column of this lane
+    const bool own = NT * q < R::GS && co < R::TTO;              // lanes that own outputs (and x columns inside the window)
+    const bool uw = NT * q < R::GS;                              // lanes that own u columns
+    const int row0 = 32 * strip + 4 * h;
+    const float* Bf = S + co + 4 * h * LD;                       // B rows of this lane's half, its columns
+    const float* Wrow1 = tab + row0 * 8;
+    const float* Wrow2 = Wrow1 + C * 8;
+    float* Urow = S + row0 * LD + co;
+    float* Xrow = Urow + 8;
+    // halo: the 8 columns in front of the outputs, 2 pieces per row, threads 0 .. 2C-1 activate them
+    const bool hthread = tid < 2 * C;
+    const int hrow = tid >> 1, hpc = tid & 1;
+
+    ovec X[16];                                                  // raw x where this lane's outputs lie: the residual operand
+    // ---- window refill by LDS-DMA: instruction i of this wave copies pieces (i * NWAVES + wave) * 64 + lane of the row-major
+    // [C][W4] piece grid (LDS image = the window itself, LD = WD).  Interior windows take precomputed per-lane offsets; the first
+    // and last windows of a clip test every piece against [0,T) (T % 4 == 0: a piece is all inside or all outside; outside
+    // reads an out-of-range offset = zeros, the causal padding).
+    int xo[R::NI];
 #pragma unroll
-        for (int i = 0; i < R::XPER; ++i)
-            xp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, voff, i * R::RT * T * 4, 0));
+    for (int i = 0; i < R::NI; ++i) {
+        const int pc = (i * R::NWAVES + wave) * 64 + lane;
+        const int row = pc / R::W4, c4 = pc - row * R::W4;
+        xo[i] = pc < R::P4 ? (row * T + 4 * c4) * 4 : RB_OOB;
+    }
+    auto refill = [&](int t) {                                   // window of tile t -> S
+        const int b = t / num_t, tt = t - b * num_t;
+        const int tw0 = tt * R::TTO - 8;
+        const __amdgpu_buffer_rsrc_t rX = uniform_rsrc(p.X + (size_t)b * C * T, clip_bytes);
+        if (tw0 >= 0 && tw0 + R::WD <= T) {
+#pragma unroll
+            for (int i = 0; i < R::NI; ++i) {
+                const int vo = xo[i];          // local copy: a dependent-size array element passed directly makes hipcc's host pass drop the kernel stub
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(S + (i * R::NWAVES + wave) * 256), 16, vo, tw0 * 4, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R::NI; ++i) {
+                const int pc = (i * R::NWAVES + wave) * 64 + lane;
+                const int row = pc / R::W4, c4 = pc - row * R::W4, tx = tw0 + 4 * c4;
+                const int vo = (pc < R::P4 && tx >= 0 && tx < T) ? (row * T + tx) * 4 : RB_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(S + (i * R::NWAVES + wave) * 256), 16, vo, 0, 0, 0);
+            }
+        }
     };
+    auto x_off = [&](int to0) { const int t = to0 + co; return (own && t < T) ? (row0 * T + t) * 4 : RB_OOB; };
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
-    xfetch(tile);
-    load_a(rW1, 0, ar[0]);
-    RB_BARRIER();                                                // tables visible
+    refill(tile);
+#pragma unroll
+    for (int c = 0; c < AD; ++c) load_a(rW1, c, ar[c % NA]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RB_BARRIER();                                                // tables visible, first window landed
 
-    const float* Bf = S + R::GS * grp + NT * q;                  // this lane's B columns
-    const float* Wrow1 = tab + (32 * strip + 4 * h) * 8;
-    const float* Wrow2 = Wrow1 + C * 8;
-    float* Urow = S + (32 * strip + 4 * h) * LD + R::GS * grp + NT * q;
-    const bool uw = NT * q < R::GS;                              // lanes that own u / y columns
-
+#ifdef RB_STAMP
+    unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / num_t, tt = tile - b * num_t;
         const int to0 = tt * R::TTO;
-        // ================= activation pass: S = ELU(c * x) ==========================================
-        if (xthread) {
-            f32x4* Sx = reinterpret_cast<f32x4*>(S) + xr * R::W4 + xc;
+        // ================= activation pass: X = x (raw), S = ELU(c * x) in place ======================
+        if (hthread) {
+            f32x4* hp = reinterpret_cast<f32x4*>(S + hrow * LD + 4 * hpc);
+            f32x4 v = *hp;
+            v.x = rb_elu(v.x * p.pre_scale); v.y = rb_elu(v.y * p.pre_scale); v.z = rb_elu(v.z * p.pre_scale); v.w = rb_elu(v.w * p.pre_scale);
+            *hp = v;
+        }
+        if (own) {
 #pragma unroll
-            for (int i = 0; i < R::XPER; ++i) {
-                f32x4 v = xp[i];
-                v.x = act(v.x, p.pre_scale, 1); v.y = act(v.y, p.pre_scale, 1);
-                v.z = act(v.z, p.pre_scale, 1); v.w = act(v.w, p.pre_scale, 1);
-                Sx[i * R::RT * R::W4] = v;
+            for (int r = 0; r < 16; ++r) X[r] = *reinterpret_cast<const ovec*>(Xrow + ((r & 3) + 8 * (r >> 2)) * LD);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ovec v;
+#pragma unroll
+                for (int e = 0; e < NT; ++e) v[e] = rb_elu(X[r][e] * p.pre_scale);
+                if (!((RB_X & 4) && T > 0)) *reinterpret_cast<ovec*>(Xrow + ((r & 3) + 8 * (r >> 2)) * LD) = v;
             }
         }
+        RB_T(0);
         RB_BARRIER();                                            // B1: window complete
+        RB_T(1);
         // ================= GEMM 1: H1 = W1 @ S =======================================================
         f32x16 acc[NT];
 #pragma unroll
         for (int e = 0; e < NT; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 1 < NCH) load_a(rW1, c + 1, ar[(c + 1) & 1]);
-            else load_a(rW2, 0, ar[(c + 1) & 1]);            // first chunk of W2 lands behind epilogue 1
-            rb_chunk<R>(acc, ar[c & 1][0], ar[c & 1][1], Bf, c, h);
-            __builtin_amdgcn_sched_barrier(RB_SCHED_MASK);       // the A loads stay one chunk ahead (hoisted, they cost a register set per chunk)
-        }
+        rb_gemm<R, 0>(acc, ar, Bf, load_a, rW1, rW2);           // the first chunk(s) of W2 land behind epilogue 1
+        RB_T(2);
         RB_BARRIER();                                            // B2: every wave has read the window (u overwrites it)
-        {   // next window's x: in flight across epilogue 1, GEMM 2 and epilogue 2
-            const int next = tile + gridDim.x;
-            if (next < ntiles) xfetch(next);
-        }
+        RB_T(3);
         // ================= epilogue 1: u = ELU(DW5(H1) + b1) -> S ======================================
         {
             f32x4 w0n = *reinterpret_cast<const f32x4*>(Wrow1), w1n = *reinterpret_cast<const f32x4*>(Wrow1 + 4);
@@ -217,8 +322,8 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
                 rb_stencil<NT>(acc, r, w0, w1, y);
                 ovec uv;
 #pragma unroll
-                for (int e = 0; e < NT; ++e) uv[e] = elu1(y[e] * 1.f);
-                if (uw) *reinterpret_cast<ovec*>(Urow + cr * LD) = uv;
+                for (int e = 0; e < NT; ++e) uv[e] = rb_elu(y[e] * 1.f);
+                if (uw && !((RB_X & 4) && T > 0)) *reinterpret_cast<ovec*>(Urow + cr * LD) = uv;
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (tt == 0 && grp == 0 && NT * q < 4) {             // u at times < 0 is the second conv's zero padding
@@ -229,39 +334,28 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
                 for (int r = 0; r < 16; ++r) *reinterpret_cast<ovec*>(Urow + ((r & 3) + 8 * (r >> 2)) * LD) = z;
             }
         }
+        RB_T(4);
         RB_BARRIER();                                            // B3: u complete
+        RB_T(5);
         // ================= GEMM 2: H2 = W2 @ u ========================================================
-        // epilogue-2 addressing (range-checked buffers over one clip's [C][T] block, as K1's k5 epilogue)
-        const int to = to0 + R::GS * grp + NT * q;
-        const bool ovalid = uw && R::GS * grp + NT * q < R::TTO && to < T;
-        const int voff0 = ovalid ? ((32 * strip + 4 * h) * T + to) * 4 : RB_OOB;
-        const int row_bytes = T * 4, clip_bytes = C * T * 4;
-        const size_t bo = (size_t)b * C * T;
-        const __amdgpu_buffer_rsrc_t rR = uniform_rsrc(p.X + bo, clip_bytes);
-        ovec res4[4];
 #pragma unroll
         for (int e = 0; e < NT; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 1 < NCH) load_a(rW2, c + 1, ar[(NCH + c + 1) & 1]);
-            else {
-                load_a(rW1, 0, ar[(NCH + c + 1) & 1]);       // next tile's first chunk of W1
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if constexpr (NT == 4) res4[r] = __builtin_bit_cast(ovec, __builtin_amdgcn_raw_buffer_load_b128(rR, voff0 + ((r & 3) + 8 * (r >> 2)) * row_bytes, 0, 0));
-                    else res4[r] = __builtin_bit_cast(ovec, __builtin_amdgcn_raw_buffer_load_b64(rR, voff0 + ((r & 3) + 8 * (r >> 2)) * row_bytes, 0, 0));
-                }
-            }
-            rb_chunk<R>(acc, ar[(NCH + c) & 1][0], ar[(NCH + c) & 1][1], Bf, c, h);
-            __builtin_amdgcn_sched_barrier(RB_SCHED_MASK);
-        }
+        rb_gemm<R, NCH>(acc, ar, Bf, load_a, rW2, rW1);         // ... and the next tile's first chunk(s) of W1 behind epilogue 2
+        RB_T(6);
         RB_BARRIER();                                            // B4: every wave has read u (the next window overwrites it)
-        // ================= epilogue 2: y = x + s * (DW5(H2) + b2) -> HBM ================================
+        RB_T(7);
+        // ================= epilogue 2: y = x + s * (DW5(H2) + b2) -> HBM; refill x ======================
         {
+            // range-checked buffers over one clip's [C][T] block (as K1's k5 epilogue): no mask, no branch, 32-bit offsets
+            const size_t bo = (size_t)b * C * T;
             const __amdgpu_buffer_rsrc_t rY = uniform_rsrc((OUT & 1) ? p.Y + bo : p.X, (OUT & 1) ? clip_bytes : 0);
             const __amdgpu_buffer_rsrc_t rA = uniform_rsrc((OUT & 2) ? p.Yact + bo : p.X, (OUT & 2) ? clip_bytes : 0);
+            const int voff0 = x_off(to0);
+            // the next window of this workgroup: every DMA piece is issued here, ahead of the stores below
+            const int next = tile + gridDim.x;
+            if (next < ntiles && !((RB_X & 16) && T > 0)) refill(next);
             f32x4 w0n = *reinterpret_cast<const f32x4*>(Wrow2), w1n = *reinterpret_cast<const f32x4*>(Wrow2 + 4);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -274,31 +368,35 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
                 }
                 float v[NT];
                 rb_stencil<NT>(acc, r, w0, w1, v);
-                const ovec rr = res4[r & 3];
-                if (r + 4 < 16) {
-                    const int o4 = voff0 + (((r + 4) & 3) + 8 * ((r + 4) >> 2)) * row_bytes;
-                    if constexpr (NT == 4) res4[r & 3] = __builtin_bit_cast(ovec, __builtin_amdgcn_raw_buffer_load_b128(rR, o4, 0, 0));
-                    else res4[r & 3] = __builtin_bit_cast(ovec, __builtin_amdgcn_raw_buffer_load_b64(rR, o4, 0, 0));
-                }
                 ovec y;
 #pragma unroll
-                for (int e = 0; e < NT; ++e) y[e] = fmaf(v[e], p.out_scale, rr[e]);
+                for (int e = 0; e < NT; ++e) y[e] = fmaf(v[e], p.out_scale, X[r][e]);
                 const int off = voff0 + cr * row_bytes;
-                if constexpr ((OUT & 1) != 0) {
+                if ((OUT & 1) != 0 && !((RB_X & 8) && T > 0)) {
                     if constexpr (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
                 }
                 if constexpr ((OUT & 2) != 0) {
                     ovec a;
 #pragma unroll
-                    for (int e = 0; e < NT; ++e) a[e] = elu1(y[e] * p.act_scale);
+                    for (int e = 0; e < NT; ++e) a[e] = rb_elu(y[e] * p.act_scale);
                     if constexpr (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, a), rA, off, 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, a), rA, off, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        RB_T(8);
+        // the refill is older than this epilogue's stores: wait until only those are outstanding, then meet the other waves
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(16 * ((OUT & 1) + (OUT >> 1))) : "memory");
+        RB_BARRIER();                                            // B0: the next window has landed
     }
+#ifdef RB_STAMP
+    if (lane == 0 && (OUT & 1)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int i = 0; i < 9; ++i) p.Y[((size_t)blockIdx.x * R::NWAVES + wave) * 9 + i] = (float)ph[i];
+    }
+#endif
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -367,10 +465,10 @@ bool rb_supported(const RbArgs& a) {
 hipError_t launch_resblock(const RbArgs& a, hipStream_t s) {
     if (!rb_supported(a)) return hipErrorNotSupported;
     switch (a.C) {
-        case 64: return rb_pick_out<RB<64, 2, 4, 2>>(a, s);      // 2 x 2 waves, 252-column windows, two workgroups per CU
-        case 96: return rb_pick_out<RB<96, 4, 2, 3>>(a, s);      // 3 x 4 waves, 244-column windows
-        case 128: return rb_pick_out<RB<128, 2, 4, 2>>(a, s);    // 4 x 2 waves, 252-column windows
-        default: return rb_pick_out<RB<192, 2, 2, 3>>(a, s);     // 6 x 2 waves, 124-column windows
+        case 64: return rb_pick_out<RB_CFG64>(a, s);
+        case 96: return rb_pick_out<RB_CFG96>(a, s);
+        case 128: return rb_pick_out<RB_CFG128>(a, s);
+        default: return rb_pick_out<RB_CFG192>(a, s);
     }
 }
 
