@@ -8,6 +8,10 @@ batch: wm = G(x, msg) + x, then the detector's time-averaged bit probabilities o
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Started as plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) the script launches that
+torch.distributed.run command itself as a CHILD process -- before anything touches the GPU, never by exec -- relays rank 0's JSON
+line and exits with the child's code.
+
 Clips are independent units, so N GPUs = N data-parallel shards with NO data-path collective
 (SURVEY.md section 8e); weak scaling (256 clips per GPU).  Rank 0 prints ONE JSON line.
 
@@ -36,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def parse():
@@ -49,7 +53,7 @@ def parse():
     ap.add_argument("--cpu-clips", type=int, default=16, help="clips of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="embed_detect",
-                    choices=["embed_detect", "longform", "detector_stress", "grad_allreduce", "train_step"],
+                    choices=["embed_detect", "longform", "detector_stress", "grad_allreduce", "train_step", "rendezvous"],
                     help="embed_detect = BASELINE configs[1] (the headline); longform = configs[3] "
                          "(32 x 30 s, embed+locate+detect); detector_stress = configs[4] (1024 clips, detector "
                          "only); grad_allreduce = configs[2]'s gradient exchange (no model compute); train_step = the "
@@ -79,10 +83,10 @@ def cpu_baseline(cfgG, cfgD, sdG, sdD, x, msg, n):
         t2 = time.perf_counter()
         tg.append(t1 - t0); td.append(t2 - t1)
     dt = float(np.median([a + b for a, b in zip(tg, td)]))
-    return dict(value=n / dt, unit="clips/s", cores=threads, kind="port",
+    return dict(value=n / dt, unit="clips/s", cores=threads, host_cpus=os.cpu_count(), kind="port",
                 generator_s=round(float(np.median(tg)), 3), detector_s=round(float(np.median(td)), 3),
                 sample=f"{n} clips x 1 s @ 16 kHz, embed+detect by the torch-CPU port of the reference path "
-                       f"(fp32, {threads} threads), 1 warm-up + 3 repetitions, median {dt:.2f} s per pass "
+                       f"(fp32, {threads} threads of the host's {os.cpu_count()} CPUs), 1 warm-up + 3 repetitions, median {dt:.2f} s per pass "
                        f"(generator {np.median(tg):.2f} s, detector {np.median(td):.2f} s)"), wm.numpy(), mp.numpy()
 
 
@@ -121,8 +125,8 @@ def grad_allreduce(a, dev, dist, world, rank):
         bus = 2.0 * (world - 1) / world * total / (ms * 1e-3) / 1e9 if world > 1 else 0.0
         print(json.dumps(dict(
             metric="grad all-reduce ms per training step (56.1 + 170.1 MB fp32, bucketed)", value=round(ms, 3), unit="ms",
-            n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=False,
-            scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
+            n_gpus=world, rccl_ranks=dist.get_world_size() if dist else 0, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
+            higher_is_better=False, scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload="grad_allreduce: BASELINE.json configs[2] gradient exchange only (no model compute)",
                         payload_bytes=total, payloads=payloads, bucket_bytes=bucket, buckets=len(buckets),
                         backend="nccl (RCCL)" if dist else "none (single rank: flatten/unflatten only)",
@@ -175,7 +179,8 @@ def train_step(a, dev, dist, world, rank):
         pick = lambda o: {k: round(float(o[k].item()), 5) for k in ("dec/loss", "loc/loss", "waveform/loss")}       # noqa: E731
         print(json.dumps(dict(
             metric="clips/sec training step (generator update: G+D+L forward/backward, BCE + waveform losses), 1s@16kHz bs=64 per GPU",
-            value=round(world * B * a.steps / elapsed, 2), unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+            value=round(world * B * a.steps / elapsed, 2), unit="clips/s", n_gpus=world, rccl_ranks=dist.get_world_size() if dist else 0,
+            steps=a.steps, warmup=a.warmup,
             ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload=f"train_step: BASELINE.json configs[2] per-GPU batch ({B} clips x {a.seconds:g} s); the part of the reference's "
                                  "generator update that runs on the HIP training units (no audio effects, mel/STFT losses or discriminator)",
@@ -183,23 +188,92 @@ def train_step(a, dev, dist, world, rank):
                         parallelism=f"dp{world} (three flat gradient arenas, bucketed mean all-reduce)",
                         parameters=dict(generator=int(tr.G.arena.numel()), detector=int(tr.D.arena.numel()), locator=int(tr.L.arena.numel()))),
             losses_first=pick(outs[0]), losses_last=pick(outs[-1]),
-            note="first correct version of the backward path (recompute-based, unfused); no roofline claim")), flush=True)
+            note="backward on saved activations (the blocks' 1x1 outputs kept from forward), activation derivative / residual / scale "
+                 "epilogues fused into the K1 GEMMs, parameter gradients written in place into one flat arena per net")), flush=True)
+
+
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (the reference's
+    counterpart is the Accelerator's launcher-driven DDP, scripts/train.py:180,875-876).  The parent never initialises the GPU and
+    never replaces itself; it relays the one JSON line rank 0 prints and returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                                   # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")             # dmabuf IPC: RCCL across processes needs it on this driver
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in child.stdout.splitlines():                          # rank 0's single JSON line; anything else goes to stderr
+        try:
+            if ln.lstrip().startswith("{"):
+                json.loads(ln)
+                line = ln
+                continue
+        except ValueError:
+            pass
+        print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif child.returncode == 0:
+        print("bench.py: the ranks printed no JSON line", file=sys.stderr)
+        return 1
+    return child.returncode
+
+
+def rendezvous(a, dist, world, rank, backend):
+    """Launcher check (no model, no GPU needed with WV_BENCH_BACKEND=gloo): every rank joins, a barrier and the MAX all-reduce of the
+    elapsed time run exactly as in the timed workloads, rank 0 prints the line."""
+    t0 = time.perf_counter()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps(dict(metric="launcher rendezvous (no compute)", value=round(elapsed * 1e3, 3), unit="ms", n_gpus=world,
+                              rccl_ranks=world if backend == "nccl" else 0, backend=backend, steps=0, warmup=0,
+                              higher_is_better=False, config=dict(workload="rendezvous"))), flush=True)
 
 
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if a.gpus > 1 and env_world is None:
+        raise SystemExit(self_launch(a))                          # before any GPU call
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus and (world > 1 or a.gpus > 1):
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    backend = os.environ.get("WV_BENCH_BACKEND", "nccl")          # test-only switch: "gloo" runs the launcher path without GPUs
+    if backend not in ("nccl", "gloo") or (backend == "gloo" and a.workload != "rendezvous"):
+        raise SystemExit("WV_BENCH_BACKEND=gloo is for --workload rendezvous only")
+    dist = None
+    if backend == "gloo":
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        rendezvous(a, dist, world, rank, backend)
+        if dist:
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
     if world > 1 or os.environ.get("WV_BENCH_FORCE_DIST") == "1":   # the latter: 1-rank rehearsal of the N>1 path
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)          # RCCL; used for barrier + MAX only (embed/detect)
         world = dist.get_world_size()                            # n_gpus is what RCCL reports
+    if a.workload == "rendezvous":
+        rendezvous(a, dist, world, rank, backend)
+        if dist:
+            dist.destroy_process_group()
+        return
     if a.workload in ("grad_allreduce", "train_step"):
         (grad_allreduce if a.workload == "grad_allreduce" else train_step)(a, dev, dist, world, rank)
         if dist:
@@ -264,6 +338,15 @@ def main():
     elapsed, (wm, mp, bits) = timed(False)        # the number: clean pass, events off
     elapsed_prof, _ = timed(True)                 # the anatomy: same K steps with per-launch events
     prof = profile.collect()
+    with_locator = None
+    if a.workload == "embed_detect":              # BASELINE configs[1] words the step "generator+locator+detector": the same K steps
+        cfgL = default_config("locator")          # with the locator's forward on wm as well, reported beside the headline
+        Lnet = HipNet(cfgL, random_state_dict(cfgL, 0), dev)
+        step()
+        el, _ = timed(False)
+        with_locator = dict(metric="clips/sec embed+locate+detect, 1s@16kHz bs=256", value=round(world * B * a.steps / el, 2),
+                            ms_per_step=round(el / a.steps * 1e3, 3))
+        Lnet = None
 
     if rank != 0:
         if dist:
@@ -281,10 +364,13 @@ def main():
     dom_avg_s = dom["ms"] / dom["launches"] * 1e-3
     ach = dom["flops"] / dom["launches"] / dom_avg_s / 1e12
     pmc = None
-    try:        # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command (profiles/)
-        pmc = json.load(open(PMC_FILE))
+    try:        # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command (profiles/), valid for the
+        pmc = json.load(open(PMC_FILE))          # library build they were taken on only: dropped when the kernel sources changed since
+        from waveverify_amd import _lib
+        if pmc.get("library") != _lib.load().wv_version().decode():
+            pmc = None
     except Exception:
-        pass
+        pmc = None
     headline = a.workload == "embed_detect" and B == 256 and T == 16000
 
     def traffic_of(kernel):
@@ -304,7 +390,7 @@ def main():
         roof = dict(bound="hbm", achieved=round(gbs_dom, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                     frac=round(gbs_dom / PEAK_HBM_GBS, 4))
     roofline = dict(kernel=dom_name, **roof, traffic=traffic_of(dom_name),
-                    traffic_source=("profiles/r02_pmc_traffic.json: GB per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, "
+                    traffic_source=("profiles/r03_pmc_traffic.json: GB per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, "
                                     "separate rocprofv3 --pmc passes over this command") if traffic_of(dom_name) else None,
                     arithmetic_intensity_flop_per_byte=round(dom_ai, 1), ridge_flop_per_byte=round(ridge, 1),
                     tflops=round(ach, 2), hbm_gbs=round(gbs_dom, 1),
@@ -343,7 +429,7 @@ def main():
               "detector_stress": "clips/sec detect, 1s@16kHz bs=1024"}[a.workload]
     step_flops = sum(v["flops"] for v in by_kernel.values()) / a.steps
     out = dict(metric=metric, value=round(world * B * a.steps / elapsed, 2),
-               unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+               unit="clips/s", n_gpus=world, rccl_ranks=dist.get_world_size() if dist else 0, steps=a.steps, warmup=a.warmup,
                ms_per_step=round(elapsed / a.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload=f"{a.workload}: {B} clips x {a.seconds:g} s @ 16 kHz per GPU "
@@ -351,7 +437,7 @@ def main():
                                     "seeded random weights",
                            batch_per_gpu=B, global_batch=B * world, clip_samples=T,
                            parallelism=f"dp{world} (independent clip shards, no data-path collective)"),
-               roofline=roofline, roofline_film=roofline_film, kernels=kernels[:10],
+               with_locator=with_locator, roofline=roofline, roofline_film=roofline_film, kernels=kernels[:10],
                profiled_pass=dict(profiler_on=True, ms_per_step=round(elapsed_prof / a.steps * 1e3, 3),
                                   kernel_time_ms_per_step=round(total_ms / a.steps, 3),
                                   step_tflops=round(step_flops / (total_ms / a.steps * 1e-3) / 1e12, 2),

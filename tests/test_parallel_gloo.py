@@ -138,3 +138,31 @@ def test_flat_arena_allreduce_two_ranks():
     want = torch.arange(1000, dtype=torch.float32) * 1.5
     for rank, n, arena in res:
         assert n == 4 and torch.equal(arena, want)
+
+
+def _bench(args, **env):
+    import subprocess
+    import sys
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the parent starts two ranks as a child torch.distributed.run (gloo here: the
+    test-only backend switch, no GPU), relays rank 0's single JSON line and returns the child's exit code."""
+    import json
+    r = _bench(["--gpus", "2", "--workload", "rendezvous"], WV_BENCH_BACKEND="gloo")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["backend"] == "gloo" and out["config"]["workload"] == "rendezvous"
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _bench(["--gpus", "2", "--workload", "rendezvous"], WV_BENCH_BACKEND="gloo", WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=3" in r.stderr
+    r = _bench(["--gpus", "1", "--workload", "rendezvous"], WV_BENCH_BACKEND="gloo", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr

@@ -32,6 +32,17 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources and headers, 12 hex digits: wv_version() carries it, so that measurements keyed to a build
+    (profiles/*_pmc_traffic.json) can tell when the kernels have changed since."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + HEADERS):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:12]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not stale():
         return LIB
@@ -40,8 +51,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(HERE, "lib", src.replace(".hip", ".o"))
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
-               "-ffp-contract=fast" if src in ("wv_kernels.hip", "wv_k1.hip", "wv_rb.hip") else "-ffp-contract=off",
-               "-c", os.path.join(CSRC, src), "-o", obj]
+               "-ffp-contract=fast" if src in ("wv_kernels.hip", "wv_k1.hip", "wv_rb.hip") else "-ffp-contract=off"]
+        if src == "wv_model.hip":
+            cmd.append(f'-DWV_SRC_HASH="{source_hash()}"')
+        cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

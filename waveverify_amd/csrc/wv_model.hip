@@ -666,7 +666,10 @@ int check_common(const wv_model* m, int B, int T, const void* ws, size_t ws_byte
 extern "C" {
 
 const char* wv_last_error(void) { return g_err.c_str(); }
-const char* wv_version(void) { return "waveverify_hip 0.1 (gfx950, f32 MFMA)"; }
+#ifndef WV_SRC_HASH
+#define WV_SRC_HASH "unhashed"
+#endif
+const char* wv_version(void) { return "waveverify_hip 0.3 (gfx950, f32 MFMA) src " WV_SRC_HASH; }
 
 int wv_config_default(int kind, wv_config* c) {
     if (!c || kind < 0 || kind > 2) return fail(WV_EINVAL, "bad kind / null cfg");
