@@ -254,7 +254,10 @@ int wv_train_unit_backward(wv_train_unit* u, const float* x, const float* g_pw, 
  *     y = x + s * half2(half1(pre_scale * x)),   s = res_scale * res_scale_param[0]  (res_scale_param may be NULL: s = res_scale)
  * forward keeps the two intermediate activations and the two 1x1 outputs in `saved` (wv_train_block_saved_bytes: four activation-sized
  * tensors; the forward kernels store the 1x1 outputs themselves, backward then has no GEMM to recompute) for backward, which returns
- * dx, both halves' parameter gradients and d(res_scale_param).  Same shape limits as the half. */
+ * dx, both halves' parameter gradients and d(res_scale_param).  Same shape limits as the half.
+ * CONTRACT: wv_train_block_backward reuses the weight folds (W, its packed copies, 1/||v||) that the forward left in the handle, so it
+ * must follow the wv_train_block_forward that produced `saved` with the SAME parameter tensors, and nothing may change their values or
+ * run another forward on this handle in between (optimizer steps come after backward).  Other parameter pointers fail with WV_ESTATE. */
 typedef struct wv_train_block wv_train_block;
 typedef struct { const float *g_pw, *v_pw, *g_dw, *v_dw, *bias; } wv_half_params;     /* device pointers */
 typedef struct { float *dg_pw, *dv_pw, *dg_dw, *dv_dw, *db; } wv_half_grads;          /* device pointers */
@@ -375,6 +378,12 @@ int wv_train_bce_logits(const float* logits, const float* mask, const float* msg
  * grad_scale * sign(a - b) / n.  Workspace: wv_train_bce_workspace_bytes(). */
 int wv_train_l1(const float* a, const float* b, float* loss, float* da, float grad_scale, size_t n, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The training units' live weight-norm fold on its own: w[m][k] = g[m] * v[m][k] / ||v[m]||, inv_norm[m] = 1 / ||v[m]|| (modules/conv.py:73-74:
+ * the norm runs over all dimensions but the first; K = their product).  The same device code folds the weights inside every training
+ * forward, so a trained net written out in the reference's STRIPPED checkpoint layout (scripts/train.py:1624-1629 removes the
+ * parametrizations before saving) holds exactly the weights the training forward used.  g [M], v [M][K], w [M][K], inv_norm [M]: device pointers. */
+int wv_train_fold_weight(const float* g, const float* v, float* w, float* inv_norm, int M, int K, void* stream);
+
 /* Optimizer step over FLAT device arenas (a net's parameters / gradients / AdamW moments are contiguous; scripts/train.py:1346-1358,
  * conf/base.yml:128-130): wv_train_sumsq = sum of squares of the gradient arena (fixed-order two-stage sum; device scalar `out`);
  * wv_train_adamw = torch.nn.utils.clip_grad_norm_(max_norm) -- when grad_sumsq is given -- followed by torch.optim.AdamW's
@@ -424,6 +433,15 @@ int wv_aug_sequence(const float* in0, const float* in1, const float* in2, float*
  * publish them (waveverify_amd/effects.py) -- third-party arithmetic that is not in this image: parity with the libraries is UNPINNED. */
 int wv_fx_fir_bank(const float* x, const float* taps, float* y, int rows, int T, int n_filters, int L, int stride, int pad_l, int pad_r,
                    int replicate, int interleave, void* stream);
+/* Adjoints of the two effects (the reference's julius filters and torchaudio resampler are plain differentiable torch ops --
+ * utils/effect_augmentation.py:1451-1501,1684-1870 -- so a loss gradient crosses them through the TRANSPOSED operator):
+ * the transpose of wv_fx_fir_bank with stride 1 is the same call on dy with time-reversed taps and L-1 zeros of padding on both sides
+ * (giving the gradient towards the PADDED signal), followed by wv_fx_fold_replicate, the transpose of the replicate padding:
+ * dx[t] = dxp[t + pad_l], with the pad samples' gradients added to dx[0] / dx[T-1].  dxp [rows][T + pad_l + pad_r], dx [rows][T]. */
+int wv_fx_fold_replicate(const float* dxp, float* dx, int rows, int T, int pad_l, int pad_r, void* stream);
+/* transpose of wv_fx_resample: dx[row][s] = sum_{m = n*new + f < Tout, j : n*orig + j - width = s} kernels[f][j] * dy[row][m];  dy [rows][Tout], dx [rows][T] */
+int wv_fx_resample_adjoint(const float* dy, const float* kernels, float* dx, int rows, int T, int orig, int new_, int L, int width, int Tout,
+                           void* stream);
 /* polyphase sinc resampling by orig : nw (both already divided by their gcd), torchaudio's formulation: kernels [nw][L], L = 2*width + orig;
  * y[row][m] = sum_j kernels[m % nw][j] * xz[(m / nw)*orig + j - width] for m < Tout = ceil(nw * T / orig), xz zero outside [0,T). */
 int wv_fx_resample(const float* x, const float* kernels, float* y, int rows, int T, int orig, int nw, int L, int width, int Tout, void* stream);

@@ -65,3 +65,18 @@ def resample(x: np.ndarray, orig_freq: int, new_freq: int, width_param: int = 6,
         k = np.where(a == 0, 1.0, np.sin(a) / np.where(a == 0, 1.0, a)) * window * scale
         out[..., m] = (xz[..., n * orig:n * orig + 2 * width + orig] * k).sum(-1)
     return out
+
+
+def filter_gradient(name: str, x: np.ndarray, d: np.ndarray, cutoff: float, zeros: float = 8) -> np.ndarray:
+    """d/dx of <filter(x), d> for the low / high-pass filter, by torch autograd (float64) through an explicit restatement: replicate
+    padding (F.pad mode 'replicate'), conv1d with the taps above.  What the reference's autograd computes through julius' filter."""
+    import torch
+    import torch.nn.functional as F
+    half = int(zeros / cutoff / 2)
+    taps = torch.from_numpy(lowpass_filter_taps(cutoff, half)).double().view(1, 1, -1)
+    xt = torch.from_numpy(x.astype(np.float64)).requires_grad_(True)
+    B, C, T = xt.shape
+    low = F.conv1d(F.pad(xt.reshape(B * C, 1, T), (half, half), mode="replicate"), taps).reshape(B, C, T)
+    y = low if name == "lowpass_filter" else xt - low
+    (y * torch.from_numpy(d.astype(np.float64))).sum().backward()
+    return xt.grad.numpy()

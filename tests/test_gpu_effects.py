@@ -73,3 +73,75 @@ def test_effect_wrappers_keep_the_reference_conventions():
         E.apply_effect("mp3_lossy_compression", {}, x, mask)
     with pytest.raises(RuntimeError, match="GPU"):
         E.lowpass(torch.zeros(1, 1, 100), 0.1)
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.mark.parametrize("name,params", [("lowpass_filter", {"cutoff_freq": 3000}), ("lowpass_filter", {"cutoff_freq": 100}),
+                                         ("highpass_filter", {"cutoff_freq": 500}), ("bandpass_filter", {"cutoff_freq_low": 300, "cutoff_freq_high": 3500}),
+                                         ("resample", {"new_sample_rate": 8000}), ("resample", {"new_sample_rate": 12000}),
+                                         ("resample", {"new_sample_rate": 22050}), ("identity", {}),
+                                         ("lowpass_filter", {"cutoff_freq": 5000})])
+@pytest.mark.parametrize("T", [16000, 1001])
+def test_effect_adjoints_are_the_transposed_operators(name, params, T):
+    """The reference differentiates through its julius filters and torchaudio resampler (plain torch ops), so the generator's gradient is
+    A^T d for the linear effect A.  <A x, d> == <x, A^T d> for random x, d pins apply_effect_backward to apply_effect on the device (the
+    replicate padding's transpose, the crop / zero pad of the resample round trip and the pass-through cases included), and the
+    float64 restatement's autograd gives the same gradient."""
+    g = torch.Generator(device="cuda").manual_seed(T + len(name))
+    x = torch.randn(2, 1, T, device="cuda", generator=g) * 0.1
+    d = torch.randn(2, 1, T, device="cuda", generator=g)
+    y, _ = E.apply_effect(name, params, x, None)
+    dx = E.apply_effect_backward(name, params, d)
+    assert dx.shape == x.shape
+    lhs, rhs = _dot(y, d), _dot(x, dx)
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), float(y.norm() * d.norm()) * 1e-2, 1e-6), (lhs, rhs)
+    if name in ("lowpass_filter", "highpass_filter") and params["cutoff_freq"] <= 4000:
+        ref = OF.filter_gradient(name, x.cpu().numpy(), d.cpu().numpy(), params["cutoff_freq"] / 8000.0)
+        assert err(dx, ref) <= 2e-5
+
+
+def test_straight_through_effects_keep_the_identity_gradient():
+    d = torch.randn(1, 1, 400, device="cuda")
+    assert E.apply_effect_backward("mp3_lossy_compression", {}, d) is d
+
+
+def test_trainer_routes_the_gradient_through_the_effect_adjoint():
+    """WatermarkTrainer with effects.apply_effect / apply_effect_backward attached: the gradient that reaches the generator for a clip
+    with a scheduled low-pass is the transposed filter of what the detector and locator returned (not the identity)."""
+    from waveverify_amd.config import default_config
+    from waveverify_amd.init import random_state_dict
+    from waveverify_amd.train import WatermarkTrainer
+
+    class OneEffect:                                                   # a scheduler that always picks one low-pass for clip 0
+        def select_effects(self, batch_size):
+            return [("lowpass_filter", {"cutoff_freq": 2000})]
+
+        def update_effect_metrics(self, *a, **k):
+            pass
+    small = dict(channels_enc=8, dimension=16, strides=[2, 2], n_fft_base=16)
+    cg = default_config("generator", channels_dec=8, n_residual_dec=1, **small)
+    cd, cl = default_config("detector", output_dim=8, **small), default_config("locator", output_dim=8, **small)
+    seen = {}
+
+    def back(name, params, d_out):
+        seen["in"] = d_out.clone()
+        seen["out"] = E.apply_effect_backward(name, params, d_out)
+        return seen["out"]
+    tr = WatermarkTrainer(cg, random_state_dict(cg, 1, parametrized=True), cd, random_state_dict(cd, 1, parametrized=True), cl,
+                          random_state_dict(cl, 1, parametrized=True), effect_scheduler=OneEffect(), apply_effect=E.apply_effect, effect_backward=back)
+    got = {}
+    g_back = tr.G.backward
+    tr.G.backward = lambda d_wm, need_dx=False: (got.__setitem__("d_wm", d_wm.clone()), g_back(d_wm, need_dx))[1]
+    x = torch.randn(2, 1, 1600, device="cuda") * 0.1
+    msg = torch.randint(0, 2, (2, 16), device="cuda").float()
+    out = tr.step(x, msg, augment=False)
+    assert np.isfinite(float(out["loss"].item()))
+    wav_grad = got["d_wm"] - 0                                          # d_wm = effect^T (dD + dL) + d(waveform loss)
+    _, d_wav = __import__("waveverify_amd.train", fromlist=["l1_loss"]).l1_loss(tr.G.forward(x, msg) * 0 + x, x, grad_scale=1.0)
+    assert not torch.equal(seen["in"], seen["out"])                     # the adjoint is not the identity
+    assert torch.equal(seen["out"], E.lowpass_adjoint(seen["in"], 2000 / 8000))
+    # clip 0 went through the adjoint, clip 1 (no effect) did not: removing the effect's share leaves the same waveform-loss gradient form
+    assert float((wav_grad[0] - seen["out"][0]).abs().max()) <= float(tr.lambdas["waveform/loss"]) / x[0].numel() + 1e-6

@@ -358,3 +358,70 @@ def test_watermark_step_with_gpu_effects():
     outs = [tr.step(_cu(x), _cu(msg)) for _ in range(2)]
     assert all(np.isfinite(float(o["loss"].item())) for o in outs)
     assert tr.effect_update_count == 8 and sum(v["selection_count"] for v in sched.get_effect_statistics().values()) == 8
+
+
+def test_trained_nets_round_trip_through_the_reference_checkpoint_format(tmp_path):
+    """Train three steps -> save_checkpoint (atomic format, weight norm stripped: scripts/train.py:1589-1676) -> WaveVerify(path)
+    (waveverify/core.py:324-426) -> embed / detect / locate agree with the trainers' own forward passes.  The state dicts carry every
+    key of the reference's modules: the DFT buffers and the detector's / locator's unused message MLP + FiLM tensors included.
+    (Not bit for bit: the SpecBlock's scalar rides in the GEMM operand of the training unit and in the epilogue of the inference
+    unit -- same function, one rounding apart.)"""
+    from waveverify_amd import WaveVerify
+    from waveverify_amd.checkpoint import load_checkpoint
+    from waveverify_amd.params import param_specs
+    from waveverify_amd.train import WatermarkTrainer
+    cfgs = [default_config(k) for k in ("generator", "detector", "locator")]
+    sds = [random_state_dict(c, 0, parametrized=True) for c in cfgs]
+    tr = WatermarkTrainer(cfgs[0], sds[0], cfgs[1], sds[1], cfgs[2], sds[2], lr=5e-4)
+    rng = np.random.default_rng(5)
+    x = _cu((0.1 * rng.standard_normal((4, 1, 16000))).astype(np.float32))
+    msg = _cu(rng.integers(0, 2, (4, 16)).astype(np.float32))
+    np.random.seed(0); torch.manual_seed(0)
+    for _ in range(3):
+        tr.step(x, msg)
+    path = tr.save_checkpoint(tmp_path, "best")
+    assert path.name == "best.pth" and not (tmp_path / "best.tmp").exists()
+    ck = torch.load(str(path), map_location="cpu", weights_only=True)           # tensors and plain containers only
+    assert ck["step"] == 3 and set(ck["models"]) == {"generator", "detector", "locator"}
+    for kind, cfg in zip(("generator", "detector", "locator"), cfgs):
+        keys = {k for k, _, _ in param_specs(cfg)} | {f"encoder.spec_blocks.{s}.spec.weight" for s in range(len(cfg.strides))} | {"encoder.spec_post.spec.weight"}
+        assert set(ck["models"][kind]) == keys, kind
+        assert not any("parametrizations" in k for k in ck["models"][kind])
+    # the trained weights differ from the initial ones, the untouched FiLM tensors of the detector do not
+    w0 = random_state_dict(cfgs[1], 0)
+    assert not np.array_equal(ck["models"]["detector"]["encoder.conv_post.2.conv.conv.weight"].numpy(), w0["encoder.conv_post.2.conv.conv.weight"])
+    assert np.array_equal(ck["models"]["detector"]["encoder.film_layers.0.0.gamma_layer.weight"].numpy(), w0["encoder.film_layers.0.0.gamma_layer.weight"])
+    sds2, cfgs2 = load_checkpoint(tmp_path)
+    assert cfgs2["generator"].to_dict() == cfgs[0].to_dict()
+    wv = WaveVerify(str(tmp_path))
+    wm_t = tr.G.forward(x, msg)
+    wm_i = wv.embed_batch(x, msg)
+    assert float((wm_t - wm_i).abs().max()) <= 2e-6
+    bits, mp = wv.detect_batch(wm_t)
+    mp_t = torch.sigmoid(tr.D.forward(wm_t)).mean(-1)
+    assert float((mp - mp_t).abs().max()) <= 2e-6
+    loc_t = torch.sigmoid(tr.L.forward(wm_t))[:, 0]
+    assert float((wv.locate_batch(wm_t) - loc_t).abs().max()) <= 2e-5
+    # the live weight-norm layout round-trips too (host fold at load)
+    p2 = tr.save_checkpoint(tmp_path / "live", "latest", parametrized=True)
+    ck2 = torch.load(str(p2), map_location="cpu", weights_only=True)
+    assert any(k.endswith("parametrizations.weight.original0") for k in ck2["models"]["generator"])
+    wv2 = WaveVerify(str(tmp_path / "live"))
+    assert float((wv2.embed_batch(x, msg) - wm_t).abs().max()) <= 2e-6
+
+
+def test_one_message_for_the_whole_batch():
+    """watermarking.py:320-329: a [1, nbits] (or shorter) message is repeated over the batch -- for G, the decoding loss and the metrics."""
+    from waveverify_amd.train import WatermarkTrainer
+    cfgs = [default_config(k) for k in ("generator", "detector", "locator")]
+    sds = [random_state_dict(c, 0, parametrized=True) for c in cfgs]
+    rng = np.random.default_rng(6)
+    x = _cu((0.1 * rng.standard_normal((3, 1, 16000))).astype(np.float32))
+    one = _cu(rng.integers(0, 2, (1, 16)).astype(np.float32))
+    outs = []
+    for m in (one, one.repeat(3, 1)):
+        tr = WatermarkTrainer(cfgs[0], sds[0], cfgs[1], sds[1], cfgs[2], sds[2])
+        np.random.seed(1); torch.manual_seed(1)
+        o = tr.step(x, m)
+        outs.append((float(o["dec/loss"].item()), float(o["loss"].item()), tr.G.arena.clone()))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])

@@ -322,3 +322,15 @@ def test_gradient_destination_views_are_checked():
     for bad in (arena[:11], arena[:24:2], arena[:12].double()):
         with pytest.raises(ValueError):
             _dst(dict(dv=bad), "dv", (3, 4), "cpu")
+
+
+def test_stft_basis_is_the_reference_buffer(golden_dir):
+    """checkpoint.stft_basis forms the `...spec.weight` buffers written into state dicts with the reference's own torch calls
+    (modules/conv.py:1003-1020): bit-equal to the buffers of the reference's modules (tests/golden/dft_basis.npz)."""
+    import os
+    import numpy as np
+    from waveverify_amd.checkpoint import stft_basis
+    g = np.load(os.path.join(golden_dir, "dft_basis.npz"))
+    b64 = stft_basis(64)
+    assert tuple(b64.shape) == (66, 1, 64) and np.array_equal(b64[:, 0].numpy(), g["n64"])
+    assert np.array_equal(stft_basis(1024)[::19, 0].numpy(), g["n1024_rows_every19"])

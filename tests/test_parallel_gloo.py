@@ -166,3 +166,46 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=3" in r.stderr
     r = _bench(["--gpus", "1", "--workload", "rendezvous"], WV_BENCH_BACKEND="gloo", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        sizes = [7, 300, 1, 64, 1200, 5, 900, 33]                       # parameters of an arena, in forward order
+        ranges, off = {}, 0
+        for i, n in enumerate(sizes):
+            ranges[f"p{i}"] = (off, off + n)
+            off += n
+        grads = torch.randn(off, generator=g)
+        ref = grads.clone()
+        n_ref = parallel.allreduce_mean_flat_(ref, bucket_bytes=4 * 500)         # post-backward version: 500-element buckets
+        live = grads.clone()
+        red = parallel.OverlappedFlatReducer(live, ranges, bucket_bytes=4 * 500)
+        launched = []
+        for keys in (["p7", "p6"], ["p5"], ["p3", "p4"], ["p2"], ["p0"]):       # backward order; p1 is never marked
+            launched.append(red.mark(keys))
+        n_live = red.wait()                                                      # flushes the buckets p1 holds back
+        assert n_live == n_ref and sum(launched) >= 2 and sum(launched) < n_live
+        assert torch.equal(live, ref)
+        torch.save(live, os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_reducer_equals_the_post_backward_all_reduce(tmp_path):
+    """Buckets launched while 'backward' is still marking parameters give exactly the arena the post-backward all-reduce gives, on
+    both ranks; buckets holding an unmarked parameter go out at wait()."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(a, b)
+
+
+def test_overlapped_reducer_without_a_process_group_is_inert():
+    g = torch.arange(10, dtype=torch.float32)
+    red = parallel.OverlappedFlatReducer(g, {"a": (0, 4), "b": (4, 10)}, bucket_bytes=16)
+    assert red.mark(["b"]) >= 1 and red.wait() == 0 and torch.equal(g, torch.arange(10, dtype=torch.float32))

@@ -125,6 +125,8 @@ SIGNATURES = {
                                   C.c_int, C.c_int, C.c_int, _VP]),
     "wv_fx_resample": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "wv_fx_fir_bank": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
+    "wv_fx_fold_replicate": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
+    "wv_fx_resample_adjoint": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "wv_profile_enable": (C.c_int, [C.c_int]),
     "wv_profile_reset": (C.c_int, []),
     "wv_profile_collect": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
@@ -139,6 +141,7 @@ SIGNATURES = {
     "wv_train_half_forward": (C.c_int, [_VP] * 7 + [C.c_float, _VP, C.c_int, C.c_int, _VP]),
     "wv_train_half_backward": (C.c_int, [_VP] * 6 + [C.c_float] + [_VP] * 7 + [C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     "wv_train_last_error": (C.c_char_p, []),
+    "wv_train_fold_weight": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP]),
     "wv_op_resblock": (C.c_int, [_VP, C.c_float] + [_VP] * 8 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _VP]),
     "wv_op_dw_pw": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, _VP, C.c_float, _VP]),

@@ -1,4 +1,4 @@
-"""Checkpoint reading: the reference's on-disk formats -> {kind: state_dict} + NetConfigs.
+"""Checkpoint reading and writing: the reference's on-disk formats <-> {kind: state_dict} + NetConfigs.
 
 Formats (all read with torch.load(..., weights_only=True): nothing in the file is executed):
   * atomic: one .pth dict {step, models{generator,detector,locator,discriminator}, optimizers,
@@ -196,3 +196,51 @@ def load_checkpoint(path) -> Tuple[Dict[str, dict], Dict[str, NetConfig]]:
     cfgs = {k: apply_argbind_config(k, infer_config(k, sd), flat if isinstance(flat, dict) else None)
             for k, sd in sds.items()}
     return sds, cfgs
+
+
+def stft_basis(n_fft: int) -> torch.Tensor:
+    """The `...spec.weight` buffer of a CausalSTFT ([2F, 1, n_fft], F = n_fft/2 + 1), formed with the reference's own torch calls
+    (/root/reference/modules/conv.py:1003-1020: float32 angle -2*pi/n_fft * k * n, cos rows then sin rows, periodic Hann window,
+    norm "backward" = no scaling).  The nets recompute their basis at load; state dicts written here carry it so that the
+    reference's `load_state_dict(strict=True)` finds every key."""
+    import math
+    n = torch.arange(n_fft, dtype=torch.float32).view(1, 1, n_fft)
+    k = torch.arange(n_fft // 2 + 1, dtype=torch.float32).view(-1, 1, 1)
+    ang = -2 * math.pi / n_fft * k * n
+    return torch.cat([torch.cos(ang), torch.sin(ang)], dim=0) * torch.hann_window(n_fft, dtype=torch.float32)
+
+
+def argbind_config(cfgs: Mapping[str, NetConfig]) -> Dict[str, object]:
+    """The flat 'Class.argument' dict the reference saves next to the weights (scripts/train.py:1652) for the scalars tensor
+    shapes cannot tell; `apply_argbind_config` reads it back."""
+    flat: Dict[str, object] = {}
+    for kind, cfg in cfgs.items():
+        c = _CLASS[kind]
+        flat[f"{c}.res_scale_enc"] = float(cfg.res_scale_enc)
+        flat[f"{c}.dilation_base"] = int(cfg.dilation_base)
+        if kind == "generator":
+            flat[f"{c}.res_scale_dec"] = float(cfg.res_scale_dec)
+    return flat
+
+
+def save_atomic_checkpoint(save_path, tag: str, models: Mapping[str, Mapping[str, torch.Tensor]], step: int = 0,
+                           config: Optional[Mapping[str, object]] = None, extra: Optional[Mapping[str, object]] = None) -> Path:
+    """Write <save_path>/<tag>.pth in the reference's atomic format (scripts/train.py:1589-1676): one dict {step, models{generator,
+    detector, locator}, config, ...}, written to a temporary file and renamed into place.  Tensors and plain containers only, so
+    the file loads with torch.load(weights_only=True) -- here and in the reference (waveverify/core.py:324-426)."""
+    save_path = Path(save_path)
+    save_path.mkdir(parents=True, exist_ok=True)
+    final, tmp = save_path / f"{tag}.pth", save_path / f"{tag}.tmp"
+    data: Dict[str, object] = {"step": int(step), "models": {k: dict(v) for k, v in models.items()}, "message_threshold": 0.5}
+    if config is not None:
+        data["config"] = dict(config)
+    if extra:
+        data.update(extra)
+    try:
+        torch.save(data, str(tmp))
+        tmp.replace(final)
+    except Exception:
+        if tmp.exists():
+            tmp.unlink()
+        raise
+    return final

@@ -71,7 +71,65 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     y[(size_t)row * Tout + m] = acc;
 }
 
+// ---- adjoints (the gradient of a loss through these effects: in the reference they are plain differentiable torch ops, so the
+// generator's gradient passes through the TRANSPOSED filter, not through an identity) --------------------------------------------
+// Transpose of the replicate padding in front of a 'same' FIR: dxp [rows][T + pad_l + pad_r] is the gradient towards the padded signal;
+// dx[t] = dxp[t + pad_l], and the pad samples (copies of x[0] / x[T-1]) send theirs to the two end samples.  One workgroup per row.
+__global__ __launch_bounds__(256) void fold_replicate_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int T, int pad_l, int pad_r) {
+    __shared__ float red[2][4];
+    const int row = blockIdx.x, tid = threadIdx.x, Tp = T + pad_l + pad_r;
+    const float* src = dxp + (size_t)row * Tp;
+    float* dst = dx + (size_t)row * T;
+    for (int t = tid; t < T; t += 256) dst[t] = src[t + pad_l];
+    float a = 0.f, b = 0.f;
+    for (int i = tid; i < pad_l; i += 256) a += src[i];
+    for (int i = tid; i < pad_r; i += 256) b += src[pad_l + T + i];
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = a; red[1][tid >> 6] = b; }
+    __syncthreads();
+    if (tid == 0) {
+        const float sa = red[0][0] + red[0][1] + red[0][2] + red[0][3], sb = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (T == 1) dst[0] = dst[0] + sa + sb;
+        else { dst[0] += sa; dst[T - 1] += sb; }
+    }
+}
+
+// Transpose of resample_kernel: dx[row][s] = sum over outputs m = n * nw + f (m < Tout) and taps j with n * orig + j - width = s of
+// K[f][j] * dy[row][m].  One thread per input sample.
+__global__ __launch_bounds__(256) void resample_adjoint_kernel(const float* __restrict__ dy, const float* __restrict__ K, float* __restrict__ dx,
+                                                                int T, int Tout, int orig, int nw, int L, int width) {
+    const int row = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= T) return;
+    const float* dr = dy + (size_t)row * Tout;
+    const int hi = (s + width) / orig;                              // j = s + width - n * orig >= 0
+    int lo = s + width - (L - 1);                                   // j <= L - 1
+    lo = lo <= 0 ? 0 : (lo + orig - 1) / orig;
+    float acc = 0.f;
+    for (int n = lo; n <= hi; ++n) {
+        const int j = s + width - n * orig;
+        for (int f = 0; f < nw; ++f) {
+            const int m = n * nw + f;
+            if (m < Tout) acc = fmaf(K[(size_t)f * L + j], dr[m], acc);
+        }
+    }
+    dx[(size_t)row * T + s] = acc;
+}
+
 }  // namespace wv
+
+extern "C" int wv_fx_fold_replicate(const float* dxp, float* dx, int rows, int T, int pad_l, int pad_r, void* stream) {
+    if (!dxp || !dx || rows < 1 || T < 1 || pad_l < 0 || pad_r < 0) return WV_EINVAL;
+    hipLaunchKernelGGL(wv::fold_replicate_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dxp, dx, T, pad_l, pad_r);
+    return hipGetLastError() == hipSuccess ? WV_OK : WV_EHIP;
+}
+
+extern "C" int wv_fx_resample_adjoint(const float* dy, const float* kernels, float* dx, int rows, int T, int orig, int nw, int L, int width, int Tout,
+                                      void* stream) {
+    if (!dy || !kernels || !dx || rows < 1 || rows > 65535 || T < 1 || orig < 1 || nw < 1 || L < 1 || width < 0 || Tout < 1) return WV_EINVAL;
+    hipLaunchKernelGGL(wv::resample_adjoint_kernel, dim3((T + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, dy, kernels, dx, T, Tout, orig, nw, L,
+                       width);
+    return hipGetLastError() == hipSuccess ? WV_OK : WV_EHIP;
+}
 
 extern "C" int wv_fx_resample(const float* x, const float* kernels, float* y, int rows, int T, int orig, int nw, int L, int width, int Tout, void* stream) {
     if (!x || !kernels || !y || rows < 1 || rows > 65535 || T < 1 || orig < 1 || nw < 1 || L < 1 || width < 0 || Tout < 1) return WV_EINVAL;

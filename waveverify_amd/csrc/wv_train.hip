@@ -1102,6 +1102,7 @@ struct wv_train_unit {
     float *w_pw = nullptr, *inv_pw = nullptr, *wq = nullptr, *wqT = nullptr, *wt = nullptr, *wtT = nullptr;   // folded 1x1 weight + packs
     float *w_dw = nullptr, *inv_dw = nullptr, *id_taps = nullptr;                 // folded taps [M][ks]; identity stencil rows
     float *dW = nullptr, *dwdb = nullptr, *dw_taps = nullptr;                     // weight-gradient scratch
+    const float* folded[4] = {nullptr, nullptr, nullptr, nullptr};               // the (g_pw, v_pw, g_dw, v_dw) the folded copies were made from
     std::vector<void*> owned;
     ~wv_train_unit() { for (void* p : owned) (void)hipFree(p); }
 };
@@ -1170,6 +1171,7 @@ static int fold_step(wv_train_unit* h, const float* g_pw, const float* v_pw, con
     const wv::WnFoldArgs fb{g_dw, v_dw, h->w_dw, h->inv_dw, nullptr, nullptr, h->M, h->ks, 0, 0, nullptr, 1.f, nullptr, nullptr};
     hipLaunchKernelGGL(wv::wn_fold_pair_kernel, dim3(2 * h->M), dim3(256), 0, s, fa, fb);
     T_LAUNCH(hipGetLastError());
+    h->folded[0] = g_pw; h->folded[1] = v_pw; h->folded[2] = g_dw; h->folded[3] = v_dw;
     return WV_OK;
 }
 
@@ -1257,6 +1259,10 @@ static int unit_backward_impl(wv_train_unit* h, const float* x, const float* g_p
     float* parts = (float*)(w + 2 * am + ak + al256((size_t)B * M * (ks + 1) * 4));
     // the step's weights: folded here unless this call continues a forward that kept its 1x1 output (the block's forward folded the
     // same parameters into the same buffers moments ago)
+    // A backward on saved activations reuses the folds (W, its packs, 1 / ||v||) its forward left in the handle: it must follow THAT forward,
+    // with the same parameter tensors and no parameter update or other forward on this handle in between.  Other tensors are caught here.
+    if (h_saved && (h->folded[0] != g_pw || h->folded[1] != v_pw || h->folded[2] != g_dw || h->folded[3] != v_dw))
+        return tfail(WV_ESTATE, "backward on saved activations: the parameters are not the ones this handle's last forward folded");
     int rc = h_saved ? WV_OK : fold_step(h, g_pw, v_pw, g_dw, v_dw, s);
     if (rc) return rc;
     if (!h_saved) {
@@ -2050,6 +2056,14 @@ int wv_train_l1(const float* a, const float* b, float* loss, float* da, float gr
 }
 
 // ---- gradient norm + AdamW over flat arenas ---------------------------------------------------------------------------------
+int wv_train_fold_weight(const float* g, const float* v, float* w, float* inv_norm, int M, int K, void* stream) {
+    if (!g || !v || !w || !inv_norm || M < 1 || K < 1) return tfail(WV_EINVAL, "null / bad argument");
+    hipLaunchKernelGGL(wv::wn_fold_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, g, v, w, inv_norm, (float*)nullptr,
+                       (float*)nullptr, M, K, 0, 0, (const float*)nullptr, 1.f, (float*)nullptr, (float*)nullptr);
+    T_LAUNCH(hipGetLastError());
+    return WV_OK;
+}
+
 int wv_train_sumsq(const float* g, size_t n, float* out, void* ws, size_t ws_bytes, void* stream) {
     if (!g || !out || !n) return tfail(WV_EINVAL, "null / bad argument");
     if (!ws || ws_bytes < wv_train_bce_workspace_bytes()) return tfail(WV_ENOMEM, "workspace too small");

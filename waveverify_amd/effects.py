@@ -116,6 +116,12 @@ def bandpass(x: torch.Tensor, cutoff_low: float, cutoff_high: float) -> torch.Te
     return lows[1] - lows[0]
 
 
+def resampled_length(T: int, orig_freq: int, new_freq: int) -> int:
+    """Length of `resample_waveform`'s output: ceil(new * T / orig) with the two rates divided by their gcd."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    return int(math.ceil((int(new_freq) // g) * T / (int(orig_freq) // g)))
+
+
 def resample_waveform(x: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
     """torchaudio.transforms.Resample(orig_freq, new_freq)(x) on [..., T]."""
     if int(orig_freq) == int(new_freq):
@@ -131,6 +137,87 @@ def resample_waveform(x: torch.Tensor, orig_freq: int, new_freq: int) -> torch.T
     if lib.wv_fx_resample(xr.data_ptr(), kd.data_ptr(), y.data_ptr(), xr.shape[0], T, orig, new, k.shape[1], width, t_out, _stream()) != 0:
         raise RuntimeError("wv_fx_resample failed")
     return y.reshape(shape[:-1] + [t_out])
+
+
+# ---- adjoints: the gradient of a loss through these effects -------------------------------------------------------------------------
+# In the reference the four effects are plain differentiable torch ops (julius' FFT / direct convolutions, torchaudio's strided conv1d;
+# effect_augmentation.py:1451-1501,1684-1870 -- not the straight-through Function classes of :462-500), so the generator's gradient
+# crosses them through the TRANSPOSED filter.
+def _fir_adjoint(dy: torch.Tensor, taps: np.ndarray, half: int) -> torch.Tensor:
+    """Transpose of `_fir` for ONE filter: dy [..., T] -> dx [..., T] (time-reversed taps over the zero-padded gradient, then the
+    transpose of the replicate padding)."""
+    lib = _lib.load()
+    shape = list(dy.shape)
+    T = shape[-1]
+    dr = _dev(dy).reshape(-1, T)
+    L = taps.shape[1]
+    rev = torch.from_numpy(np.ascontiguousarray(taps[:1, ::-1])).to(dr.device)
+    dxp = torch.empty(dr.shape[0], 1, T + L - 1, device=dr.device)               # gradient towards the replicate-padded signal
+    if lib.wv_fx_fir_bank(dr.data_ptr(), rev.data_ptr(), dxp.data_ptr(), dr.shape[0], T, 1, L, 1, L - 1, L - 1, 0, 0, _stream()) != 0:
+        raise RuntimeError("wv_fx_fir_bank failed")
+    dx = torch.empty_like(dr)
+    if lib.wv_fx_fold_replicate(dxp.data_ptr(), dx.data_ptr(), dr.shape[0], T, half, half, _stream()) != 0:
+        raise RuntimeError("wv_fx_fold_replicate failed")
+    return dx.reshape(shape)
+
+
+def lowpass_adjoint(dy: torch.Tensor, cutoff: float) -> torch.Tensor:
+    taps, half = lowpass_taps([cutoff])
+    return _fir_adjoint(dy, taps, half)
+
+
+def highpass_adjoint(dy: torch.Tensor, cutoff: float) -> torch.Tensor:
+    return _dev(dy) - lowpass_adjoint(dy, cutoff)
+
+
+def bandpass_adjoint(dy: torch.Tensor, cutoff_low: float, cutoff_high: float) -> torch.Tensor:
+    taps, half = lowpass_taps([cutoff_low, cutoff_high])
+    return _fir_adjoint(dy, taps[1:2], half) - _fir_adjoint(dy, taps[0:1], half)
+
+
+def resample_waveform_adjoint(dy: torch.Tensor, orig_freq: int, new_freq: int, t_in: int) -> torch.Tensor:
+    """Transpose of `resample_waveform(x [..., t_in], orig_freq, new_freq)`: dy [..., t_out] -> dx [..., t_in]."""
+    if int(orig_freq) == int(new_freq):
+        return _dev(dy)
+    lib = _lib.load()
+    k, width, orig, new = resample_kernels(orig_freq, new_freq)
+    shape = list(dy.shape)
+    dr = _dev(dy).reshape(-1, shape[-1])
+    kd = torch.from_numpy(np.ascontiguousarray(k)).to(dr.device)
+    dx = torch.empty(dr.shape[0], t_in, device=dr.device)
+    if lib.wv_fx_resample_adjoint(dr.data_ptr(), kd.data_ptr(), dx.data_ptr(), dr.shape[0], t_in, orig, new, k.shape[1], width, shape[-1], _stream()) != 0:
+        raise RuntimeError("wv_fx_resample_adjoint failed")
+    return dx.reshape(shape[:-1] + [t_in])
+
+
+DIFFERENTIABLE = ("identity", "highpass_filter", "lowpass_filter", "bandpass_filter", "resample")
+
+
+def apply_effect_backward(name: str, params: dict, d_out: torch.Tensor, sample_rate: int = DEFAULT_SAMPLE_RATE) -> torch.Tensor:
+    """Gradient towards the input of `apply_effect(name, params, audio)` given the gradient towards its output (same length): the
+    transposed operator for the effects the reference differentiates through (`DIFFERENTIABLE`); anything else is one of the
+    reference's straight-through effects (effect_augmentation.py:462-500) and passes the gradient unchanged."""
+    if name not in DIFFERENTIABLE or name == "identity":
+        return d_out
+    A = AudioEffects
+    T = d_out.shape[-1]
+    if name == "lowpass_filter" or name == "highpass_filter":
+        c = A._cutoff(params.get("cutoff_freq", 3000 if name == "lowpass_filter" else 500), sample_rate)
+        try:
+            return (lowpass_adjoint if name == "lowpass_filter" else highpass_adjoint)(d_out, c)
+        except ValueError:                                   # the forward passed the input through
+            return d_out
+    if name == "bandpass_filter":
+        nyquist = sample_rate / 2.0
+        lo = max(0.0, min(params.get("cutoff_freq_low", 300), nyquist - EPSILON)) / nyquist
+        hi = max(0.0, min(params.get("cutoff_freq_high", 8000), nyquist - EPSILON)) / nyquist
+        return bandpass_adjoint(d_out, lo, hi)
+    new_sr = int(params["new_sample_rate"])                  # resample: down, up, then cropped / zero-padded back to T
+    t_mid = resampled_length(T, sample_rate, new_sr)
+    t_up = resampled_length(t_mid, new_sr, sample_rate)
+    d_up = d_out[..., :t_up] if t_up <= T else torch.nn.functional.pad(d_out, (0, t_up - T))     # transpose of the crop / zero pad
+    d_mid = resample_waveform_adjoint(d_up.contiguous(), new_sr, sample_rate, t_mid)
+    return resample_waveform_adjoint(d_mid, sample_rate, new_sr, T)
 
 
 # ---- the reference's effect wrappers -------------------------------------------------------------------------------------------------

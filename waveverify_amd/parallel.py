@@ -133,3 +133,82 @@ def allreduce_mean_flat_(arena: torch.Tensor, bucket_bytes: int = DEFAULT_BUCKET
         w.wait()
     arena.div_(world)
     return len(works)
+
+
+class OverlappedFlatReducer:
+    """The same mean all-reduce as `allreduce_mean_flat_` -- identical buckets (slices cut from the END of the arena), identical
+    collectives, identical result -- but every bucket is launched as soon as backward has written the last gradient inside it, so
+    that the transfer runs under the rest of the backward pass (DDP's overlap, /root/reference/scripts/train.py:875-876,1277,1347).
+
+        red = OverlappedFlatReducer(grads, ranges)     # ranges: {parameter key: (lo, hi)} offsets into the arena
+        ... backward ...; red.mark(keys just written) after every stage ...
+        red.flush()                                    # launch whatever is still pending (nothing, when every key was marked)
+        red.wait()                                     # before the optimizer reads the arena: waits, then divides by the world size
+
+    Every rank marks in the same order (same code path), so the collectives are issued in the same order everywhere.  With one
+    rank (or no process group) nothing is launched and the arena is left as it is."""
+
+    def __init__(self, arena: torch.Tensor, ranges, bucket_bytes: int = DEFAULT_BUCKET_BYTES, group=None):
+        import torch.distributed as dist
+        if arena.dim() != 1 or not arena.is_contiguous():
+            raise ValueError("flat contiguous arena required")
+        self.arena, self.group = arena, group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        per = max(1, bucket_bytes // arena.element_size())
+        self.buckets, hi = [], arena.numel()                      # [(lo, hi)], last layers first
+        while hi > 0:
+            lo = max(0, hi - per)
+            self.buckets.append((lo, hi))
+            hi = lo
+        self.pending = [set() for _ in self.buckets]              # keys not yet written, per bucket
+        self.where = {}                                           # key -> buckets it touches
+        for k, (lo, hi) in ranges.items():
+            if hi <= lo:
+                continue
+            hit = [i for i, (blo, bhi) in enumerate(self.buckets) if lo < bhi and hi > blo]
+            self.where[k] = hit
+            for i in hit:
+                self.pending[i].add(k)
+        self.launched = [False] * len(self.buckets)
+        self.works = []
+
+    def _launch(self, i: int) -> None:
+        import torch.distributed as dist
+        lo, hi = self.buckets[i]
+        self.launched[i] = True
+        if self.active:
+            self.works.append(dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def mark(self, keys) -> int:
+        """The gradients of `keys` are final.  Launches every bucket this completes; returns how many."""
+        touched = set()
+        for k in keys:
+            for i in self.where.get(k, ()):
+                self.pending[i].discard(k)
+                touched.add(i)
+        n = 0
+        for i in sorted(touched):                                 # ascending bucket index = from the end of the arena
+            if not self.launched[i] and not self.pending[i]:
+                self._launch(i)
+                n += 1
+        return n
+
+    def flush(self) -> int:
+        n = 0
+        for i in range(len(self.buckets)):
+            if not self.launched[i]:
+                self._launch(i)
+                n += 1
+        return n
+
+    def wait(self) -> int:
+        """Complete the reduction (flushes first).  Returns the number of collectives that ran."""
+        self.flush()
+        for w in self.works:
+            w.wait()
+        n = len(self.works)
+        self.works = []
+        if self.active:
+            self.arena.div_(self.world)
+        return n

@@ -430,7 +430,11 @@ class _HalfGrads(C.Structure):
 class TrainBlock:
     """Whole SEANetResnetBlock (/root/reference/modules/seanet.py:245-281, identity shortcut):
     y = x + res_scale * res_scale_param * half2(half1(pre_scale * x)); `res_scale_param` is the trainable [1]
-    tensor of zero_init blocks or None."""
+    tensor of zero_init blocks or None.
+
+    Contract: `backward(..., saved)` reuses the weight folds its `forward` left in the handle -- call it after THAT forward, with the
+    same parameter tensors, before any optimizer step or other forward on this block (different tensors raise; changed values in the
+    same tensors cannot be detected)."""
 
     def __init__(self, channels: int):
         self._lib = _lib.load()
@@ -699,6 +703,9 @@ class _NetTrainer:
         skip = () if with_msg else ("encoder.msg_embedding.", "encoder.film_layers.")
         items = [(k, np.asarray(v, dtype=np.float32)) for k, v in state_dict.items()
                  if not (skip and k.startswith(skip)) and not k.endswith("spec.weight")]
+        # the tensors this net never touches (a detector's / locator's message MLP + FiLM: grad None in the reference) are carried along
+        # for state_dict(): the reference's own state dicts hold them
+        self.frozen = {k: torch.from_numpy(np.array(v, dtype=np.float32)) for k, v in state_dict.items() if skip and k.startswith(skip)}
         # the message MLP + FiLM parameters sit together, in the order the FiLM kernels read them: their packed block and its gradient
         # are then plain slices of the arenas (no gather before the forward, no scatter after the backward)
         self.film = FilmMlp(cfg) if with_msg else None
@@ -710,11 +717,13 @@ class _NetTrainer:
             items += [(k, by[k]) for k in self.film.keys]
         n = sum(v.size for _, v in items)
         self.arena, self.grads = torch.empty(n, device=device), torch.zeros(n, device=device)
-        self.params, self.gviews, off = {}, {}, 0
+        self.params, self.gviews, self.ranges, off = {}, {}, {}, 0
         for k, v in items:
             self.arena[off:off + v.size] = torch.from_numpy(v.reshape(-1)).to(device)
             self.params[k], self.gviews[k] = self.arena[off:off + v.size].view(v.shape), self.grads[off:off + v.size].view(v.shape)
+            self.ranges[k] = (off, off + v.size)
             off += v.size
+        self._reducer = None
         rs, C = cfg.res_scale_enc, cfg.channels_enc
         self.conv_pre = TrainConvPre(C, cfg.kernel_size)
         self.scales, stride = [], 1
@@ -766,6 +775,66 @@ class _NetTrainer:
         g_dw, v_dw = self._wn("encoder.conv_post.1")
         g_pw, v_pw = self._wn("encoder.conv_post.2")
         return dict(g_dw=g_dw, v_dw=v_dw, g_pw=g_pw, v_pw=v_pw, b=self.params["encoder.conv_post.2.conv.conv.bias"])
+
+    # ---- gradient exchange overlapped with backward --------------------------------------------------------------------------------
+    def begin_reduce(self, bucket_bytes: Optional[int] = None):
+        """Arm the overlapped all-reduce for the backward pass that follows (one process per GPU; a no-op reducer with one rank):
+        every bucket of the gradient arena goes on the wire as soon as backward has written the last gradient inside it."""
+        from .parallel import DEFAULT_BUCKET_BYTES, OverlappedFlatReducer
+        self._reducer = OverlappedFlatReducer(self.grads, self.ranges, bucket_bytes or DEFAULT_BUCKET_BYTES)
+        return self._reducer
+
+    def _done(self, *prefixes) -> None:
+        """Backward has finished every gradient whose key starts with one of `prefixes`."""
+        if self._reducer is not None and self._reducer.active:
+            self._reducer.mark([k for k in self.ranges if k.startswith(prefixes)])
+
+    def finish_reduce(self) -> int:
+        """Wait for the exchange (launching what backward did not mark) and take the mean.  Returns the number of collectives."""
+        if self._reducer is None:
+            from .parallel import allreduce_mean_flat_
+            return allreduce_mean_flat_(self.grads)
+        n = self._reducer.wait()
+        self._reducer = None
+        return n
+
+    # ---- the trained net in the reference's checkpoint layouts ---------------------------------------------------------------------
+    def _fold(self, g: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        """g * v / ||v|| by the training units' own device fold (wv_train_fold_weight): exactly the weights the forward passes use."""
+        lib = _lib.load()
+        M, K = int(v.shape[0]), int(v.numel() // v.shape[0])
+        w, inv = torch.empty_like(v), torch.empty(M, device=v.device)
+        if lib.wv_train_fold_weight(g.data_ptr(), v.data_ptr(), w.data_ptr(), inv.data_ptr(), M, K, TrainHalf._stream()) != 0:
+            raise RuntimeError(f"wv_train_fold_weight: {lib.wv_train_last_error().decode()}")
+        return w
+
+    def state_dict(self, parametrized: bool = False) -> Dict[str, torch.Tensor]:
+        """The net as the reference's `state_dict()` (CPU tensors, every key of /root/reference/modules/seanet.py's modules incl. the
+        DFT buffers and, for a detector / locator, the unused message MLP + FiLM tensors it was built with).
+        parametrized=False: the STRIPPED layout the reference writes (scripts/train.py:1624-1650 removes the weight-norm
+        parametrizations before saving; `...conv.conv.weight` = g v / ||v||, folded on the device like every training forward);
+        parametrized=True: the live layout (`...parametrizations.weight.original0/1`)."""
+        from .params import param_specs
+        from .checkpoint import stft_basis
+        out: Dict[str, torch.Tensor] = {}
+        for key, shape, role in param_specs(self.cfg):
+            if role == "wn":
+                base = key[: -len("weight")] + "parametrizations.weight.original"
+                g, v = self.params[base + "0"], self.params[base + "1"]
+                if parametrized:
+                    out[base + "0"], out[base + "1"] = g.detach().cpu().clone(), v.detach().cpu().clone()
+                else:
+                    out[key] = self._fold(g, v).cpu()
+            elif key in self.params:
+                out[key] = self.params[key].detach().cpu().clone()
+            elif key in self.frozen:
+                out[key] = self.frozen[key].clone()
+            else:
+                raise KeyError(f"{key}: not in the state dict this trainer was built from")
+        for s in range(len(self.cfg.ratios_enc) + 1):
+            pre = "encoder.spec_post" if s == len(self.cfg.ratios_enc) else f"encoder.spec_blocks.{s}"
+            out[pre + ".spec.weight"] = stft_basis((2 ** s) * self.cfg.n_fft_base)
+        return out
 
     def _block_fwd(self, blk, pre, h, pre_scale, rs):
         ps = [self._half(pre + ".block", 1, 2), self._half(pre + ".block", 4, 5)]
@@ -823,6 +892,7 @@ class _NetTrainer:
         g = self.conv_post.backward(sv["post_in"], self._post_p(), dz,
                                     dict(dg_dw=gd0, dv_dw=gd1, dg_pw=gp0, dv_pw=gp1, db=self.gviews["encoder.conv_post.2.conv.conv.bias"]))
         dh = g["dx"]
+        self._done("encoder.conv_post.")
 
         dx_spec = torch.zeros_like(sv["x"]) if need_dx else None
 
@@ -836,6 +906,7 @@ class _NetTrainer:
             if need_dx:
                 stft.backward(sv["x"], gs["dP"], dx_spec, True)
         spec_back(self.spec_post, self.stft_post, "encoder.spec_post", sv["P_post"], dh)
+        self._done("encoder.spec_post.")
         dfilm = torch.zeros_like(sv["film"]) if self.with_msg else None
         for s in reversed(range(len(self.scales))):
             sc, rec = self.scales[s], sv["scales"][s]
@@ -847,18 +918,20 @@ class _NetTrainer:
             spec_back(sc["spec"], sc["stft"], f"encoder.spec_blocks.{s}", rec["P"], dh)          # the add passes dh through unchanged
             for j in reversed(range(len(sc["blocks"]))):
                 dh = self._block_bwd(sc["blocks"][j], f"encoder.blocks.{s}.{j}", rec["blocks"][j], dh, rs)
+            self._done(f"encoder.downsample.{s}.", f"encoder.spec_blocks.{s}.", f"encoder.blocks.{s}.")
         if self.with_msg:
             self.film.backward(dfilm, self.gviews, self._film_g)
+            self._done("encoder.msg_embedding.", "encoder.film_layers.")
         gv = self._wn("encoder.conv_pre.1")
         g0, g1 = self._gwn("encoder.conv_pre.1")
         gp = self.conv_pre.backward(sv["x"], dict(g=gv[0], v=gv[1], b=self.params["encoder.conv_pre.1.conv.conv.bias"]), 1.0 / cfg.wav_std,
                                     dh, need_dx, dict(dg=g0, dv=g1, db=self.gviews["encoder.conv_pre.1.conv.conv.bias"]))
         self._enc = None
+        self._done("encoder.conv_pre.")
         return gp["dx"] + dx_spec if need_dx else None
 
     def _optimizer_step(self):
-        from .parallel import allreduce_mean_flat_
-        allreduce_mean_flat_(self.grads)
+        self.finish_reduce()
         return self.opt.step(self.arena, self.grads, self.max_norm)
 
 
@@ -896,6 +969,7 @@ class EncoderNetTrainer(_NetTrainer):
                                dict(dw_rev=self.gviews["reverse_convolution.weight"], db_rev=self.gviews["reverse_convolution.bias"],
                                     dw_last=self.gviews["last_layer.weight"], db_last=self.gviews["last_layer.bias"]))
         self._z = None
+        self._done("reverse_convolution.", "last_layer.")
         return self.encoder_backward(g["dz"], need_dx)
 
     def step(self, x: torch.Tensor, mask: torch.Tensor, msg: Optional[torch.Tensor] = None):
@@ -903,6 +977,7 @@ class EncoderNetTrainer(_NetTrainer):
         backward -> mean all-reduce of the gradient arena -> clip + AdamW + ExponentialLR.  Returns (loss, gradient norm)."""
         logits = self.forward(x)
         loss, dz = bce_logits(logits, mask, msg)
+        self.begin_reduce()
         self.backward(dz)
         return loss, self._optimizer_step()
 
@@ -970,18 +1045,22 @@ class GeneratorTrainer(_NetTrainer):
         g = self.tail.backward(sv["tail_in"], self._tail_p(), self.post, cfg.wav_std, sv["delta"], d_wm,
                                dict(dg=g0, dv=g1, db=self.gviews[f"decoder.model.{self.i_last}.conv.conv.bias"]))
         dh = g["dx"]
+        self._done(f"decoder.model.{self.i_last}.")
         for i in reversed(range(len(self.ups))):
             (ct, pw, res, r, C), du, rec = self.ups[i], self.dec_ups[i], sv["ups"][i]
             for j in reversed(range(len(res))):
                 dh = self._block_bwd(du["blocks"][j], f"decoder.model.{res[j]}", rec["blocks"][j], dh, rs)
+                self._done(f"decoder.model.{res[j]}.")
             (c0, c1), (p0, p1) = self._gwn(f"decoder.model.{ct}", ".convtr.convtr"), self._gwn(f"decoder.model.{pw}")
             gu = du["up"].backward(rec["up_in"], self._up_p(ct, pw), self.post if i > 0 else 1.0, dh, True,
                                    dict(dg_ct=c0, dv_ct=c1, dg_pw=p0, dv_pw=p1, db=self.gviews[f"decoder.model.{pw}.conv.conv.bias"]))
             dh = gu["dx"]
+            self._done(f"decoder.model.{ct}.", f"decoder.model.{pw}.")
         (p0, p1), (d0, d1) = self._gwn(f"decoder.model.{self.i_pw0}"), self._gwn(f"decoder.model.{self.i_dw0}")
         gi = self.dec_in.backward(sv["z"], self._in_p(), 1.0, dh, False, True,
                                   dict(dg_pw=p0, dv_pw=p1, dg_dw=d0, dv_dw=d1, db_dw=self.gviews[f"decoder.model.{self.i_dw0}.conv.conv.bias"]))
         self._dec = None
+        self._done(f"decoder.model.{self.i_pw0}.", f"decoder.model.{self.i_dw0}.")
         dx = self.encoder_backward(gi["dx"], need_dx)
         return None if dx is None else dx + d_wm
 
@@ -1021,12 +1100,16 @@ class WatermarkTrainer:
     LAMBDAS = {"waveform/loss": 1000.0, "loc/loss": 100.0, "dec/loss": 10000.0}
 
     def __init__(self, cfgG, sdG, cfgD, sdD, cfgL, sdL, lr: float = 1e-4, max_norm: float = 1000.0, sample_rate: int = 16000,
-                 window_duration: float = 0.1, device="cuda", effect_scheduler=None, apply_effect=None):
+                 window_duration: float = 0.1, device="cuda", effect_scheduler=None, apply_effect=None, effect_backward=None):
         """effect_scheduler: a waveverify_amd.effect_scheduler.EffectScheduler (watermarking.py:266-271); every step then selects
         effects as `_apply_adaptive_effects` does (watermarking.py:537: select_effects(batch size), i.e. at most one per known effect,
         applied to the FIRST clips of the batch) and feeds per-clip BER / mIoU back (`_update_effect_metrics`, watermarking.py:697-752).
-        apply_effect(name, params, audio [1,1,T], mask [1,1,T]) -> (audio, mask) runs the non-identity effects (PyTorch side; their
-        gradient is the straight-through identity of effect_augmentation.py:462-500); without it only 'identity' can be scheduled."""
+        apply_effect(name, params, audio [1,1,T], mask [1,1,T]) -> (audio, mask) runs the non-identity effects; without it only
+        'identity' can be scheduled.  effect_backward(name, params, d_out [1,1,T]) -> d_in carries the loss gradient back through an
+        effect: the reference differentiates through its julius filters and torchaudio resampler (plain torch ops,
+        effect_augmentation.py:1451-1501,1684-1870), so their gradient is the transposed filter (`effects.apply_effect_backward`);
+        its SoX / codec / quantisation effects are straight-through Functions (:462-500) whose gradient is the identity -- which is
+        also what a missing `effect_backward` means for every effect."""
         from .augment import TemporalAugmenter
         from .metrics import BER, MIOU
         self.G = GeneratorTrainer(cfgG, sdG, lr, max_norm, device)
@@ -1034,9 +1117,24 @@ class WatermarkTrainer:
         self.L = EncoderNetTrainer(cfgL, sdL, lr, max_norm, device)
         self.aug = TemporalAugmenter(sample_rate, window_duration)
         self.lambdas = dict(self.LAMBDAS)
-        self.effect_scheduler, self.apply_effect = effect_scheduler, apply_effect
+        self.effect_scheduler, self.apply_effect, self.effect_backward = effect_scheduler, apply_effect, effect_backward
         self.ber_calculator, self.miou_calculator = BER(threshold=0.5), MIOU()
         self.effect_update_count = 0
+
+    def state_dicts(self, parametrized: bool = False) -> Dict[str, Dict[str, torch.Tensor]]:
+        """{generator, detector, locator: state dict} in the reference's stripped (default) or live weight-norm layout."""
+        return {"generator": self.G.state_dict(parametrized), "detector": self.D.state_dict(parametrized), "locator": self.L.state_dict(parametrized)}
+
+    def save_checkpoint(self, save_path, tag: str = "latest", step: Optional[int] = None, parametrized: bool = False):
+        """Write the three nets as the reference's atomic checkpoint <save_path>/<tag>.pth (scripts/train.py:1589-1676: weight-norm
+        parametrizations removed, temporary file renamed into place) -- the file `WaveVerify(checkpoint=<save_path>)` reads
+        (waveverify/core.py:324-426), here and in the reference.  The optimizer moments go along as plain tensors."""
+        from .checkpoint import argbind_config, save_atomic_checkpoint
+        opts = {k: {"step": int(n.opt.t), "lr": float(n.opt.lr), "exp_avg": n.opt.m.detach().cpu(), "exp_avg_sq": n.opt.v.detach().cpu()}
+                for k, n in (("generator", self.G), ("detector", self.D), ("locator", self.L))}
+        cfgs = {"generator": self.G.cfg, "detector": self.D.cfg, "locator": self.L.cfg}
+        return save_atomic_checkpoint(save_path, tag, self.state_dicts(parametrized), self.G.opt.t if step is None else step,
+                                      argbind_config(cfgs), {"optimizers": opts})
 
     def _effects(self, wm_aug, mask):
         """-> (audio, mask, effects_applied): the straight-through effects on the first clips (watermarking.py:521-612)."""
@@ -1064,8 +1162,11 @@ class WatermarkTrainer:
             self.effect_update_count += 1
 
     def step(self, x: torch.Tensor, msg: torch.Tensor, extra_d_wm: Optional[torch.Tensor] = None, augment: bool = True):
-        from .parallel import allreduce_mean_flat_
         x, msg = _f(x), _f(msg)
+        if msg.dim() == 1:
+            msg = msg[None]
+        if msg.shape[0] != x.shape[0]:                                 # one (or a shorter list of) message(s) for the batch: repeated as the
+            msg = msg.repeat(-(-x.shape[0] // msg.shape[0]), 1)[: x.shape[0]].contiguous()   # reference's forward does (watermarking.py:320-329)
         lam = self.lambdas
         wm = self.G.forward(x, msg)
         if augment:
@@ -1078,21 +1179,32 @@ class WatermarkTrainer:
             wm_aug, mask, applied = self._effects(wm_aug, mask)
         logits_d = self.D.forward(wm_aug)
         dec, dzD = bce_logits(logits_d, mask, msg, grad_scale=lam["dec/loss"])
+        # each net's gradient exchange starts inside its own backward (bucket by bucket) and runs under everything that follows:
+        # the detector's under the locator's passes and the generator's backward, the locator's under the generator's backward
+        self.D.begin_reduce()
         d_aug = self.D.backward(dzD, need_dx=True)
+        self.D._reducer.flush()
         logits_l = self.L.forward(wm_aug)
         loc, dzL = bce_logits(logits_l, mask, None, grad_scale=lam["loc/loss"])
+        self.L.begin_reduce()
         d_aug = d_aug + self.L.backward(dzL, need_dx=True)
+        self.L._reducer.flush()
         if applied:
             self._update_effect_metrics(logits_d, logits_l, msg, mask, applied)
             stats = dict(stats, selected_effects=applied)
+            if self.effect_backward is not None:                          # back through each clip's effect (identity when there is no hook)
+                for i, (name, params) in enumerate(applied):
+                    if str(name) != "identity":
+                        d_aug[i:i + 1] = self.effect_backward(str(name), params, d_aug[i:i + 1].clone())
         d_wm = self.aug.backward(d_aug) if augment else d_aug
         wav, d_wav = l1_loss(wm, x, grad_scale=lam["waveform/loss"])
         d_wm = d_wm + d_wav
         if extra_d_wm is not None:
             d_wm = d_wm + _f(extra_d_wm)
+        self.G.begin_reduce()
         self.G.backward(d_wm)
         for net in (self.G, self.D, self.L):
-            allreduce_mean_flat_(net.grads)
+            net.finish_reduce()
         norm = self.G.opt.step(self.G.arena, self.G.grads, self.G.max_norm)          # clipping: the generator only
         self.D.opt.step(self.D.arena, self.D.grads, None)
         self.L.opt.step(self.L.arena, self.L.grads, None)
