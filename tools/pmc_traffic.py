@@ -29,7 +29,7 @@ def short(name: str) -> str:
     m = re.match(r"void wv::stft_k1_kernel<wv::K1<(\d+), (\d+), (\d+)>", name)
     if m:
         return f"stft_logmag<{m.group(3)},{32 * int(m.group(1))},k1>"
-    m = re.search(r"rb_kernel<wv::\(anonymous namespace\)::RB<(\d+), (\d+), (\d+), (\d+)>", name)
+    m = re.search(r"rb_kernel<wv::\(anonymous namespace\)::RB<(\d+), (\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         c, ng, nt = int(m.group(1)), int(m.group(2)), int(m.group(3))
         return f"resblock<{c},{ng * (32 * nt - 4) + 4}>"

@@ -15,7 +15,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        m = re.search(r"RB<(\d+), (\d+), (\d+), (\d+)>", k)
+        m = re.search(r"RB<(\d+), (\d+), (\d+), (\d+), (\d+)>", k)
         if not m: continue
         acc[m.group(0)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 B = 256

@@ -19,4 +19,5 @@ for src in wv_kernels.hip wv_k1.hip wv_rb.hip wv_model.hip wv_ops.hip wv_train.h
   if [ -n "${repl[$src]}" ]; then objs="$objs ${repl[$src]}"; else objs="$objs waveverify_amd/lib/${src%.hip}.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/bin/libwv_$name.so $objs
+python3 -c "import ctypes,sys; ctypes.CDLL(sys.argv[1])" tools/bin/libwv_$name.so   # every kernel stub resolves (hipcc has dropped some silently)
 echo tools/bin/libwv_$name.so

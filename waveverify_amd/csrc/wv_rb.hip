@@ -45,24 +45,27 @@ template <> struct RbVec<4> { typedef f32x4 type; };
 template <> struct RbVec<2> { typedef f32x2 type; };
 
 constexpr int RB_OOB = 0x7f000000;                              // byte offset beyond any num_records here
-// geometry per channel count: <C, column groups, 32-column tiles per wave, waves per SIMD>
+// geometry per channel count: <C, column groups, 32-column tiles per wave, waves per SIMD, parts the window refill is issued in>
+// (measured, tools/rbbench.py, one box, interleaved: the refill started inside GEMM 2 in 3-4 parts gains 4 % at C = 96 and 1-2 % at
+//  C = 128, nothing at C = 64, and costs 8 % at C = 192 in four parts where two are even)
 #ifndef RB_CFG64
-#define RB_CFG64 RB<64, 2, 4, 2>                                // 2 x 2 waves, 252-column windows, two workgroups per CU
+#define RB_CFG64 RB<64, 2, 4, 2, 1>                             // 2 x 2 waves, 252-column windows, two workgroups per CU
 #endif
 #ifndef RB_CFG96
-#define RB_CFG96 RB<96, 4, 2, 3>                                // 3 x 4 waves, 244-column windows
+#define RB_CFG96 RB<96, 4, 2, 3, 3>                             // 3 x 4 waves, 244-column windows
 #endif
 #ifndef RB_CFG128
-#define RB_CFG128 RB<128, 2, 4, 2>                              // 4 x 2 waves, 252-column windows
+#define RB_CFG128 RB<128, 2, 4, 2, 4>                           // 4 x 2 waves, 252-column windows
 #endif
 #ifndef RB_CFG192
-#define RB_CFG192 RB<192, 2, 2, 3>                              // 6 x 2 waves, 124-column windows
+#define RB_CFG192 RB<192, 2, 2, 3, 2>                           // 6 x 2 waves, 124-column windows
 #endif
 #ifndef RB_PD
 #define RB_PD 3                                                 // B rows in flight ahead of their MFMAs
 #endif
 #ifndef RB_AD
-#define RB_AD 1                                                 // A chunks in flight ahead of their MFMAs (ring of RB_AD + 1; 1 or 3)
+#define RB_AD 3                                                 // A chunks in flight ahead of their MFMAs (ring of RB_AD + 1; 1 or 3: the refill issued inside GEMM 2 sits in the
+                                                                // same in-order queue, so the A loads behind it must not be needed soon)
 #endif
 
 #ifndef RB_X
@@ -81,10 +84,11 @@ __device__ __forceinline__ float rb_elu(float x) {
 #define RB_T(i) do {} while (0)
 #endif
 
-// C channels, NG column groups, NT 32-column tiles per wave (interleaved: tile e = columns NT*j + e), WPS waves per SIMD
-template <int C_, int NG_, int NT_, int WPS_>
+// C channels, NG column groups, NT 32-column tiles per wave (interleaved: tile e = columns NT*j + e), WPS waves per SIMD;
+// PARTS: the next window's refill is issued in this many parts, all but the last inside GEMM 2 (1: all of it after GEMM 2)
+template <int C_, int NG_, int NT_, int WPS_, int PARTS_>
 struct RB {
-    static constexpr int C = C_, NG = NG_, NT = NT_, WPS = WPS_;
+    static constexpr int C = C_, NG = NG_, NT = NT_, WPS = WPS_, PARTS = PARTS_;
     static constexpr int WM = C / 32, NWAVES = WM * NG, NTHREADS = 64 * NWAVES;
     static constexpr int GS = 32 * NT - 4;                      // columns a group contributes
     static constexpr int WD = NG * GS + 4;                      // window columns in LDS
@@ -92,9 +96,11 @@ struct RB {
     static constexpr int LD = WD;                               // LDS row stride
     static constexpr int NCH = C / 16;
     static constexpr int W4 = WD / 4, P4 = C * W4;              // 16-byte pieces per row / per window
-    static constexpr int NI = (P4 + NTHREADS - 1) / NTHREADS;   // LDS-DMA instructions per wave and window (64 pieces each)
-    static constexpr size_t SMEM = ((size_t)NI * NTHREADS * 4 + 2 * C * 8) * sizeof(float);   // the last DMA piece may run past C * LD
-    static_assert(C % 32 == 0 && WD % 4 == 0 && (NT == 2 || NT == 4) && NTHREADS >= 2 * C, "geometry");
+    static constexpr int RPI = 64 / W4;                         // whole window rows one LDS-DMA instruction copies
+    static constexpr int NI = (C / RPI + NWAVES - 1) / NWAVES;  // LDS-DMA instructions per wave and window
+    static constexpr size_t SMEM = ((size_t)C * LD + 2 * C * 8) * sizeof(float);
+    static_assert(C % 32 == 0 && WD % 4 == 0 && (NT == 2 || NT == 4) && NTHREADS >= 2 * C && RPI >= 1 && C % RPI == 0 && 16 % RPI == 0 &&
+                  PARTS >= 1 && NCH % PARTS == 0, "geometry");
     static_assert((2 * NCH) % (RB_AD + 1) == 0, "the A ring must close over a tile");
 };
 
@@ -155,9 +161,10 @@ __device__ __forceinline__ void rb_stencil(const f32x16 (&acc)[NT], int r, const
 // ahead of the MFMAs that consume them into a ring of PD + 1 row vectors.  The order is pinned (scheduling barrier per step): left to
 // itself the compiler issues each read right in front of its MFMAs and sinks the A loads to the end of the chunk, so that both
 // latencies are exposed once per step / chunk.
-template <class R, int G0, class LoadA>
+// at_chunk(c) runs at the head of chunk c >= 1 (GEMM 2 frees the window's rows there, in quarters, for the next window's x).
+template <class R, int G0, class LoadA, class AtChunk>
 __device__ __forceinline__ void rb_gemm(f32x16 (&acc)[R::NT], f32x4 (&ar)[RB_AD + 1][2], const float* Bf, LoadA&& load_a,
-                                        const __amdgpu_buffer_rsrc_t& rw, const __amdgpu_buffer_rsrc_t& rw_next) {
+                                        const __amdgpu_buffer_rsrc_t& rw, const __amdgpu_buffer_rsrc_t& rw_next, AtChunk&& at_chunk) {
     typedef typename RbVec<R::NT>::type bvec;
     constexpr int NS = 8 * R::NCH, PD = RB_PD, NB = PD + 1, AD = RB_AD, NA = AD + 1;
     bvec bq[NB];
@@ -168,6 +175,7 @@ __device__ __forceinline__ void rb_gemm(f32x16 (&acc)[R::NT], f32x4 (&ar)[RB_AD 
     for (int s = 0; s < NS; ++s) {
         const int c = s >> 3, j = s & 7;
         if (j == 0) {
+            if (c > 0) at_chunk(c);
             if (c + AD < R::NCH) load_a(rw, c + AD, ar[(G0 + c + AD) % NA]);
             else load_a(rw_next, c + AD - R::NCH, ar[(G0 + c + AD) % NA]);
         }
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
     typedef unsigned uvec __attribute__((ext_vector_type(R::NT)));
     constexpr int NT = R::NT, C = R::C, LD = R::LD, NCH = R::NCH, AD = RB_AD, NA = AD + 1;
     float* S = smem;
-    float* tab = smem + R::NI * R::NTHREADS * 4;                 // [2][C][8]: taps, bias
+    float* tab = smem + C * LD;                                  // [2][C][8]: taps, bias
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int strip = wave % R::WM, grp = wave / R::WM;
@@ -228,34 +236,28 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
     const int hrow = tid >> 1, hpc = tid & 1;
 
     ovec X[16];                                                  // raw x where this lane's outputs lie: the residual operand
-    // ---- window refill by LDS-DMA: instruction i of this wave copies pieces (i * NWAVES + wave) * 64 + lane of the row-major
-    // [C][W4] piece grid (LDS image = the window itself, LD = WD).  Interior windows take precomputed per-lane offsets; the first
-    // and last windows of a clip test every piece against [0,T) (T % 4 == 0: a piece is all inside or all outside; outside
-    // reads an out-of-range offset = zeros, the causal padding).
-    int xo[R::NI];
-#pragma unroll
-    for (int i = 0; i < R::NI; ++i) {
-        const int pc = (i * R::NWAVES + wave) * 64 + lane;
-        const int row = pc / R::W4, c4 = pc - row * R::W4;
-        xo[i] = pc < R::P4 ? (row * T + 4 * c4) * 4 : RB_OOB;
-    }
-    auto refill = [&](int t) {                                   // window of tile t -> S
+    // ---- window refill by LDS-DMA.  One instruction copies a block of RPI whole rows of the window (RPI * W4 <= 64 sixteen-byte pieces:
+    // lane l takes piece l of the block, the few lanes past it are switched off); the LDS image is the window itself (LD = WD), so a
+    // lane's destination is its piece's place and its source is one per-lane offset plus the block's rows as a SCALAR offset.  Block rb
+    // belongs to wave rb % NWAVES.  The first and last windows of a clip test the lane's column against [0,T) (T % 4 == 0: a piece is
+    // all inside or all outside; outside reads an out-of-range offset = zeros, the causal padding).
+    const int xrow = lane / R::W4, xc4 = lane - xrow * R::W4;    // this lane's row inside a block, its piece inside the row
+    const bool xlane = lane < R::RPI * R::W4;
+    auto refill = [&](int t, int row0_, int row1_) {             // rows [row0_, row1_) of tile t's window -> S (t < 0: none)
+        if (t < 0) return;
         const int b = t / num_t, tt = t - b * num_t;
         const int tw0 = tt * R::TTO - 8;
         const __amdgpu_buffer_rsrc_t rX = uniform_rsrc(p.X + (size_t)b * C * T, clip_bytes);
-        if (tw0 >= 0 && tw0 + R::WD <= T) {
+        const int tx = tw0 + 4 * xc4;
+        const int vo = (tx >= 0 && tx < T) ? (xrow * T + tx) * 4 : RB_OOB;
+        if (xlane) {
 #pragma unroll
             for (int i = 0; i < R::NI; ++i) {
-                const int vo = xo[i];          // local copy: a dependent-size array element passed directly makes hipcc's host pass drop the kernel stub
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(S + (i * R::NWAVES + wave) * 256), 16, vo, tw0 * 4, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < R::NI; ++i) {
-                const int pc = (i * R::NWAVES + wave) * 64 + lane;
-                const int row = pc / R::W4, c4 = pc - row * R::W4, tx = tw0 + 4 * c4;
-                const int vo = (pc < R::P4 && tx >= 0 && tx < T) ? (row * T + tx) * 4 : RB_OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(S + (i * R::NWAVES + wave) * 256), 16, vo, 0, 0, 0);
+                const int rb = i * R::NWAVES + wave;              // this wave's i-th block (wave-uniform test: a scalar branch)
+                const int r_ = rb * R::RPI, so = r_ * row_bytes;  // (plain locals: dependent expressions as builtin arguments make hipcc's
+                float* dst = S + r_ * LD;                         //  host pass drop the kernel's stub)
+                if (r_ >= row0_ && r_ < row1_)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)dst, 16, vo, so, 0, 0);
             }
         }
     };
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
-    refill(tile);
+    refill(tile, 0, C);
 #pragma unroll
     for (int c = 0; c < AD; ++c) load_a(rW1, c, ar[c % NA]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
         for (int e = 0; e < NT; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-        rb_gemm<R, 0>(acc, ar, Bf, load_a, rW1, rW2);           // the first chunk(s) of W2 land behind epilogue 1
+        rb_gemm<R, 0>(acc, ar, Bf, load_a, rW1, rW2, [](int) {});   // the first chunk(s) of W2 land behind epilogue 1
         RB_T(2);
         RB_BARRIER();                                            // B2: every wave has read the window (u overwrites it)
         RB_T(3);
@@ -342,7 +344,17 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
         for (int e = 0; e < NT; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-        rb_gemm<R, NCH>(acc, ar, Bf, load_a, rW2, rW1);         // ... and the next tile's first chunk(s) of W1 behind epilogue 2
+        // The next window's x goes into S while this GEMM still runs: once every wave has passed chunk c (a barrier at each quarter), the
+        // rows below 16c of u are dead, and the DMA instructions that lie wholly inside them are issued -- under matrix work, ahead of
+        // epilogue 2's stores (loads and stores share one in-order queue: refill loads issued next to the stores doubled that epilogue).
+        const int next = tile + gridDim.x < ntiles && !((RB_X & 16) && T > 0) ? tile + gridDim.x : -1;
+        rb_gemm<R, NCH>(acc, ar, Bf, load_a, rW2, rW1, [&](int c) {   // ... and the next tile's first chunk(s) of W1 behind epilogue 2
+            if (R::PARTS > 1 && c % (NCH / R::PARTS) == 0) {
+                constexpr int per = NCH / R::PARTS;
+                RB_BARRIER();
+                refill(next, 16 * (c - per), 16 * c);
+            }
+        });
         RB_T(6);
         RB_BARRIER();                                            // B4: every wave has read u (the next window overwrites it)
         RB_T(7);
@@ -353,9 +365,8 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
             const __amdgpu_buffer_rsrc_t rY = uniform_rsrc((OUT & 1) ? p.Y + bo : p.X, (OUT & 1) ? clip_bytes : 0);
             const __amdgpu_buffer_rsrc_t rA = uniform_rsrc((OUT & 2) ? p.Yact + bo : p.X, (OUT & 2) ? clip_bytes : 0);
             const int voff0 = x_off(to0);
-            // the next window of this workgroup: every DMA piece is issued here, ahead of the stores below
-            const int next = tile + gridDim.x;
-            if (next < ntiles && !((RB_X & 16) && T > 0)) refill(next);
+            // what is left of the next window (the rows the last quarter of GEMM 2 still read), ahead of the stores below
+            refill(next, R::PARTS > 1 ? 16 * (NCH - NCH / R::PARTS) : 0, C);
             f32x4 w0n = *reinterpret_cast<const f32x4*>(Wrow2), w1n = *reinterpret_cast<const f32x4*>(Wrow2 + 4);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
