@@ -9,6 +9,11 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from waveverify_amd import _lib                         # noqa: E402
+if "--lib" in sys.argv:                                 # an A/B variant built by tools/variant.sh
+    i = sys.argv.index("--lib")
+    _lib.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 from waveverify_amd import profile                      # noqa: E402
 from waveverify_amd.core import WaveVerify              # noqa: E402
 from waveverify_amd.init import synthetic_clips         # noqa: E402
