@@ -808,7 +808,8 @@ hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
     }
     // The upsample unit computes its B operand (depth-wise ConvTranspose) in the loader, once per m-tile workgroup: 256-row tiles (8 waves)
     // halve that redundant vector work per matrix instruction where the channel count allows (M = 768: 2.27 -> 2.07 ms, 104 -> 117 TFLOP/s).
-    // 192-row tiles (6 waves on 4 SIMDs) were measured and lose: M = 384 3.04 -> 3.93 ms, M = 192 3.17 -> 3.46 ms.
+    // 192-row tiles (6 waves on 4 SIMDs) were measured and lose: M = 384 3.04 -> 3.93 ms, M = 192 3.17 -> 3.46 ms; one 384-row tile
+    // (12 waves, one workgroup per CU) does not win either: 3.04 -> 3.13 ms.
     if (a.ct_w && k5 && !narrow && !a.resid && !a.Yraw && a.res_mode != 2 && a.pw.M % 256 == 0) return k1_pick_ldr<K1<4, 16, 256>, 0, false>(a, s);
     if (bm == 128) return k1_pick_epi<K1<4, 16, 128>>(a, s, k5);
     if (bm == 96) return k1_pick_epi<K1<4, 16, 96>>(a, s, k5);
