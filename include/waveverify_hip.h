@@ -182,6 +182,15 @@ int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const floa
 int wv_op_stft_logmag(const float* wav, const float* host_basis, float* P, int B, int T,
                       int n_fft, int hop, float mean, float std, void* stream);
 
+/* Whole SpecBlock in one launch (modules/seanet.py:463-511 with CausalSTFT modules/conv.py:1036-1086):
+ *   y = x + out_scale * ( W @ P ),  P = (log(max(|STFT(wav)|, 1e-5)) - mean) / std  -- the spectrogram stays in LDS, never in HBM.
+ * For the scales whose whole spectrum is one tile and whose 1x1 has as many rows: n_fft = M in {64, 128}, more than 64 frames,
+ * Tf = ceil(T/hop) a multiple of 4.  wav [B,1,T]; w_pw [M, n_fft/2+1] (HOST pointer, like every wv_op_* weight); x [B,M,Tf];
+ * Y (may alias x) and/or Yact = ELU(act_scale * y).  Bit-identical to wv_op_stft_logmag followed by the accumulate form of wv_op_dw_pw.
+ * Returns WV_EINVAL for shapes the fused kernel does not cover (the nets then run the two kernels). */
+int wv_op_spec_block(const float* wav, const float* basis_or_null, const float* w_pw, const float* x, float* Y, float* Yact, int B, int T,
+                     int n_fft, int hop, int M, float mean, float std, float out_scale, float act_scale, void* stream);
+
 /* conv_pre: Y = Conv1d(1->C,k)(x * in_scale) + bias  (seanet.py:657-664). x [B,1,T], w [C,1,k]. */
 
 /* The same op with the basis packed and uploaded ONCE (a training step computes these features for every scale at every step):

@@ -304,6 +304,50 @@ def test_stft_logmag(ops, n_fft, hop, T):
     assert np.abs(got_np - ref)[~big].max(initial=0) <= 5e-3
 
 
+@pytest.mark.parametrize("n_fft,hop,T", [(64, 1, 16000), (64, 1, 132), (64, 1, 1000), (64, 1, 68), (64, 1, 256), (64, 2, 2024), (64, 4, 1024),
+                                         (128, 2, 16000), (128, 2, 264), (128, 2, 2000), (128, 1, 516), (128, 4, 1040), (128, 2, 263)])
+def test_spec_block_in_one_launch(ops, n_fft, hop, T):
+    """Whole SpecBlock in one launch (STFT -> log-magnitude -> 1x1 -> add; the spectrogram stays in LDS) for the scales whose spectrum
+    is one tile (n_fft = C in {64, 128}): against the oracle's composition (silence in one clip: both clamps), every output mode, in
+    place, tile-edge frame counts (128-frame tiles; ragged waveform lengths), and bit-equal to the two-kernel path it replaces."""
+    rng = np.random.default_rng(n_fft + hop + T)
+    C, F, Tf = n_fft, n_fft // 2 + 1, -(-T // hop)
+    wav = np.clip(rnd(rng, 3, 1, T, scale=0.1), -1, 1)
+    wav[1, 0, : T // 3] = 0.0
+    wav[2] *= 8.0
+    x = rnd(rng, 3, C, Tf)
+    w = rnd(rng, C, F, 1, scale=F ** -0.5)
+    s_out, s_act = np.float32(0.53), np.float32(0.7071)
+    mag = O.causal_stft_mag(wav, n_fft, hop)
+    P = ((np.log(np.maximum(mag, np.float32(1e-5))) - np.float32(-4.3)) / np.float32(2.8)).astype(np.float32)
+    ref = (x + s_out * O.sconv1d(P, w, None)).astype(np.float32)
+    wd, xd = cu(wav), cu(x)
+    got, gact = ops.spec_block(wd, w, xd, n_fft, hop, mean=-4.3, std=2.8, out_scale=float(s_out), act_scale=float(s_act))
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max())) + 5e-3 * float(s_out) * float(np.abs(w).sum(1).max()) * float((mag <= 1e-3).any())
+    assert np.isfinite(got.cpu().numpy()).all() and float(np.abs(got.cpu().numpy() - ref).max()) <= tol
+    assert float(np.abs(gact.cpu().numpy() - O.elu(ref * s_act)).max()) <= tol
+    assert torch.equal(ops.spec_block(wd, w, xd, n_fft, hop, mean=-4.3, std=2.8, out_scale=float(s_out)), got)
+    assert torch.equal(ops.spec_block(wd, w, xd, n_fft, hop, mean=-4.3, std=2.8, out_scale=float(s_out), act_scale=float(s_act), want_raw=False), gact)
+    # the two kernels it replaces: STFT -> P in HBM -> the SpecBlock add (K1, identity stencil)
+    Pd = ops.stft_logmag(wd, n_fft, hop, mean=-4.3, std=2.8)
+    two = xd.clone()
+    if C >= 128:                                   # the op hands out the activated copy on its K1 form (M >= 128) only
+        _, two_act = ops.dw_pw(Pd, w, None, None, mode=0, accumulate_into=two, out_scale=float(s_out), act_scale=float(s_act))
+        assert torch.equal(two_act, gact)
+        assert torch.equal(two, got), f"{float((two - got).abs().max()):.3e}"
+    else:                                          # below 128 rows the op's add is the round-1 1x1 kernel: same sums, another rounding order
+        ops.dw_pw(Pd, w, None, None, mode=0, accumulate_into=two, out_scale=float(s_out))
+        assert float((two - got).abs().max()) <= 2e-6 * max(1.0, float(got.abs().max()))
+
+
+def test_spec_block_refuses_other_shapes(ops):
+    wav, x = torch.zeros(1, 1, 4000).cuda(), torch.zeros(1, 256, 500).cuda()
+    with pytest.raises(RuntimeError):
+        ops.spec_block(wav, np.zeros((256, 129, 1), np.float32), x, 256, 8)          # the spectrum spans several tiles
+    with pytest.raises(RuntimeError):
+        ops.spec_block(torch.zeros(1, 1, 60).cuda(), np.zeros((64, 33, 1), np.float32), torch.zeros(1, 64, 60).cuda(), 64, 1)   # <= 64 frames
+
+
 def test_stft_with_given_basis(ops):
     rng = np.random.default_rng(3)
     wav = rnd(rng, 2, 1, 500, scale=0.1)

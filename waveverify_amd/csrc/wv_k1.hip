@@ -829,8 +829,12 @@ hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
 // log(max(.,1e-5)) -> (y - mean)/std -> one 16-byte (8-byte) store.  Round 1's kernel (generic core, 4-byte
 // scattered stores, 74 TFLOP/s) stays for frame counts that are not a multiple of the vector width.
 // =================================================================================================
-template <class C>
-__global__ __launch_bounds__(C::NTHREADS, C::B_PER > 1 ? 3 : 4) void stft_k1_kernel(StftArgs p) {
+// FUSE: the SpecBlock's 1x1 and its add in the same launch (n_fft = M = BM: the workgroup holds every bin of its frames).  The
+// log-magnitudes go to LDS as P[F][BN] (rows up to the next multiple of 16 zeroed) instead of HBM, a second GEMM W @ P runs on the same
+// 32-row strips with its A fragments loaded straight into registers (3 or 5 chunks of the k-inner layout), and the epilogue forms
+// y = resid + out_scale * (W @ P) [-> ELU(act_scale * y)] -- the values of the two-kernel path, bit for bit.
+template <class C, bool FUSE>
+__global__ __launch_bounds__(C::NTHREADS, (FUSE || C::B_PER > 1) ? 3 : 4) void stft_k1_kernel(StftArgs p, SpecAddArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef typename NVec<C::NT>::type bvec;
     typedef unsigned uvec __attribute__((ext_vector_type(C::NT)));
@@ -962,10 +966,25 @@ __global__ __launch_bounds__(C::NTHREADS, C::B_PER > 1 ? 3 : 4) void stft_k1_ker
     }
     constexpr int NSLOT = C::NTHREADS / C::CG;
     const int clip_bytes = p.F * p.Tf * 4;
-    const __amdgpu_buffer_rsrc_t rP = uniform_rsrc(p.P + (size_t)b * p.F * p.Tf, clip_bytes);
+    const __amdgpu_buffer_rsrc_t rP = uniform_rsrc(FUSE ? p.wav : p.P + (size_t)b * p.F * p.Tf, FUSE ? 0 : clip_bytes);
     const int tq = t0 + C::NT * i31;                            // Tf % NT == 0: the lane's frames are all in or all out
     const bool lane_ok = tq < p.Tf;
     auto logmag = [&](float re, float im) { return stft_logmag(re, im, p.c1, p.c0); };
+    // FUSE: P[F16][BN] in LDS behind the side-row slots (the stages are free now)
+    constexpr int F16 = FUSE ? (C::BM / 2 + 1 + 15) / 16 * 16 : 0, NC2 = F16 / 16;
+    float* Pl = smem + NSLOT * C::BN * 2;
+    f32x4 a2[FUSE ? NC2 : 1][2];
+    if constexpr (FUSE) {
+        // the 1x1's A fragments: chunk c, lane half h: wq[(4c + h)][m], wq[(4c + h + 2)][m], m = 32 wave + i31 -- in flight under the epilogue
+        const __amdgpu_buffer_rsrc_t rW = uniform_rsrc(q.pw.wq, NC2 * 4 * q.pw.Mp * 16);
+        const int avoff = (h * q.pw.Mp + 32 * wave + i31) * 16;
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) {
+            a2[c][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, avoff, c * 4 * q.pw.Mp * 16, 0));
+            a2[c][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, avoff, (c * 4 + 2) * q.pw.Mp * 16, 0));
+        }
+        for (int i = tid; i < (F16 - (C::BM / 2 + 1)) * C::BN; i += C::NTHREADS) Pl[(C::BM / 2 + 1) * C::BN + i] = 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
         const int row = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;          // even: (re, im) rows 2f, 2f + 1
@@ -980,38 +999,109 @@ __global__ __launch_bounds__(C::NTHREADS, C::B_PER > 1 ? 3 : 4) void stft_k1_ker
                 y0[e] = logmag(acc[e][r], s0);
                 y1[e] = logmag(acc[e][r + 1], s1);
             }
-            const int v0 = lane_ok ? tq * 4 : 0x7f000000, v1 = lane_ok ? ((p.F - 1) * p.Tf + tq) * 4 : 0x7f000000;
-            if constexpr (C::NT == 4) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y0), rP, v0, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y1), rP, v1, 0, 0);
+            if constexpr (FUSE) {
+                *reinterpret_cast<bvec*>(Pl + C::NT * i31) = y0;
+                *reinterpret_cast<bvec*>(Pl + (p.F - 1) * C::BN + C::NT * i31) = y1;
             } else {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y0), rP, v0, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y1), rP, v1, 0, 0);
+                const int v0 = lane_ok ? tq * 4 : 0x7f000000, v1 = lane_ok ? ((p.F - 1) * p.Tf + tq) * 4 : 0x7f000000;
+                if constexpr (C::NT == 4) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y0), rP, v0, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y1), rP, v1, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y0), rP, v0, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y1), rP, v1, 0, 0);
+                }
             }
         } else {
             bvec y;
 #pragma unroll
             for (int e = 0; e < C::NT; ++e) y[e] = logmag(acc[e][r], acc[e][r + 1]);
-            const int v = row_ok ? ((row >> 1) * p.Tf + tq) * 4 : 0x7f000000;
-            if constexpr (C::NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y), rP, v, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y), rP, v, 0, 0);
+            if constexpr (FUSE) {
+                *reinterpret_cast<bvec*>(Pl + (row >> 1) * C::BN + C::NT * i31) = y;      // n_fft = BM: every row is a bin row
+            } else {
+                const int v = row_ok ? ((row >> 1) * p.Tf + tq) * 4 : 0x7f000000;
+                if constexpr (C::NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y), rP, v, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y), rP, v, 0, 0);
+            }
+        }
+    }
+    if constexpr (FUSE) {
+        __syncthreads();                                         // P complete
+        // ---- second GEMM: W[M][F] @ P[F][BN] on this wave's 32-row strip (the k order of the K1 core)
+#pragma unroll
+        for (int e = 0; e < C::NT; ++e)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+        const float* Bf = Pl + C::NT * i31 + 4 * h * C::BN;
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bvec bv = *reinterpret_cast<const bvec*>(Bf + (16 * c + (j < 4 ? j : 4 + j)) * C::BN);
+                const float a = a2[c][j >> 2][j & 3];
+#pragma unroll
+                for (int e = 0; e < C::NT; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[e], acc[e], 0, 0, 0);
+            }
+        }
+        // ---- y = resid + out_scale * (W @ P): range-checked buffers over the clip's [M][Tf] block (M = BM: every row exists)
+        const int M = C::BM, blk = M * p.Tf * 4;
+        const size_t bo = (size_t)b * M * p.Tf;
+        const __amdgpu_buffer_rsrc_t rR = uniform_rsrc(q.resid + bo, blk);
+        const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(q.Y ? q.Y + bo : q.resid, q.Y ? blk : 0);
+        const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(q.Yact ? q.Yact + bo : q.resid, q.Yact ? blk : 0);
+        const int voff0 = lane_ok ? ((32 * wave + 4 * h) * p.Tf + tq) * 4 : 0x7f000000;
+        bvec res4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (C::NT == 4) res4[r] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b128(rR, voff0 + ((r & 3) + 8 * (r >> 2)) * p.Tf * 4, 0, 0));
+            else res4[r] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b64(rR, voff0 + ((r & 3) + 8 * (r >> 2)) * p.Tf * 4, 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int off = voff0 + ((r & 3) + 8 * (r >> 2)) * p.Tf * 4;
+            const bvec rr = res4[r & 3];
+            if (r + 4 < 16) {
+                const int o4 = voff0 + (((r + 4) & 3) + 8 * ((r + 4) >> 2)) * p.Tf * 4;
+                if constexpr (C::NT == 4) res4[r & 3] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b128(rR, o4, 0, 0));
+                else res4[r & 3] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b64(rR, o4, 0, 0));
+            }
+            bvec y;
+#pragma unroll
+            for (int e = 0; e < C::NT; ++e) y[e] = fmaf(acc[e][r], q.out_scale, rr[e]);
+            if (q.Y) {
+                if constexpr (C::NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
+            }
+            if (q.Yact) {
+                bvec a;
+#pragma unroll
+                for (int e = 0; e < C::NT; ++e) a[e] = elu1(y[e] * q.act_scale);
+                if constexpr (C::NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, a), rA, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, a), rA, off, 0, 0);
+            }
         }
     }
 }
 
-template <class C>
-static hipError_t stft_k1_run(StftArgs a, hipStream_t s) {
+template <class C, bool FUSE>
+static hipError_t stft_k1_run(StftArgs a, const SpecAddArgs& q, hipStream_t s) {
     a.num_m = (a.n_fft + C::BM - 1) / C::BM;
     a.num_t = (a.Tf + C::BN - 1) / C::BN;
     const long long n_act = (long long)a.num_t * a.B;
     const long long nblk = ((n_act + 7) / 8) * 8 * a.num_m;
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t side_bytes = (size_t)(C::NTHREADS / C::CG) * C::BN * 2 * sizeof(float);
-    const size_t smem = std::max<size_t>(2 * (size_t)C::STAGE4 * 16, side_bytes);
+    constexpr int F16 = (C::BM / 2 + 1 + 15) / 16 * 16;
+    const size_t smem = std::max<size_t>(2 * (size_t)C::STAGE4 * 16, side_bytes + (FUSE ? (size_t)F16 * C::BN * sizeof(float) : 0));
     std::string name;
-    if (prof::enabled()) name = "stft_logmag<" + std::to_string(C::BM) + "," + std::to_string(C::BN) + ",k1>";
-    prof::Scope ps(s, name.c_str(), 2.0 * a.B * (2.0 * a.F) * a.n_fft * a.Tf, 4.0 * a.B * ((double)a.T + (double)a.F * a.Tf));
-    hipLaunchKernelGGL(stft_k1_kernel<C>, dim3((unsigned)nblk), dim3(C::NTHREADS), smem, s, a);
+    if (prof::enabled()) name = std::string(FUSE ? "stft_spec<" : "stft_logmag<") + std::to_string(C::BM) + "," + std::to_string(C::BN) + ",k1>";
+    const double Bd = a.B, T = a.Tf, M = C::BM;
+    const double outs = (q.Y ? 1.0 : 0.0) + (q.Yact ? 1.0 : 0.0);
+    const double flops = 2.0 * Bd * (2.0 * a.F) * a.n_fft * T + (FUSE ? 2.0 * Bd * M * a.F * T : 0.0);
+    const double bytes = FUSE ? 4.0 * Bd * ((double)a.T + M * T * (1.0 + outs)) : 4.0 * Bd * ((double)a.T + (double)a.F * T);
+    prof::Scope ps(s, name.c_str(), flops, bytes);
+    if (FUSE && smem > 64 * 1024) return hipErrorNotSupported;
+    hipLaunchKernelGGL((stft_k1_kernel<C, FUSE>), dim3((unsigned)nblk), dim3(C::NTHREADS), smem, s, a, q);
     return hipGetLastError();
 }
 
@@ -1023,9 +1113,23 @@ hipError_t launch_stft_k1(const StftArgs& a, hipStream_t s) {
     if (a.Tf <= 64 || a.Tf % 4) return hipErrorNotSupported;
     int bm = 128, best = (a.n_fft + 127) / 128 * 128;
     for (int cand : {96, 64}) { const int pd = (a.n_fft + cand - 1) / cand * cand; if (pd < best) { best = pd; bm = cand; } }
-    if (bm == 128) return stft_k1_run<K1<4, 16, 128>>(a, s);
-    if (bm == 96) return stft_k1_run<K1<4, 16, 96>>(a, s);
-    return stft_k1_run<K1<4, 16, 64>>(a, s);
+    const SpecAddArgs none{};
+    if (bm == 128) return stft_k1_run<K1<4, 16, 128>, false>(a, none, s);
+    if (bm == 96) return stft_k1_run<K1<4, 16, 96>, false>(a, none, s);
+    return stft_k1_run<K1<4, 16, 64>, false>(a, none, s);
+}
+
+hipError_t launch_stft_spec(const StftArgs& a_in, const SpecAddArgs& q, hipStream_t s) {
+    StftArgs a = a_in;
+    a.c1 = 0.5f * 0.69314718055994531f * a.inv_std;             // see stft_logmag (wv_dev.h)
+    a.c0 = -a.mean * a.inv_std;
+    if (!a.basis_q || !a.side || !q.pw.wq || !q.resid || (!q.Y && !q.Yact)) return hipErrorNotSupported;
+    if (a.n_fft != q.pw.M || (a.n_fft != 64 && a.n_fft != 128) || q.pw.K != a.F || a.F != a.n_fft / 2 + 1) return hipErrorNotSupported;
+    if (a.Mp % M_ALIGN || a.Mp < a.n_fft || q.pw.Mp % M_ALIGN || a.Tf <= 64 || (a.Tf & 3)) return hipErrorNotSupported;
+    if ((long long)q.pw.M * a.Tf * 4 >= OOB_VOFF) return hipErrorNotSupported;
+    if (!aligned16(q.resid) || (q.Y && !aligned16(q.Y)) || (q.Yact && !aligned16(q.Yact))) return hipErrorNotSupported;
+    if (a.n_fft == 128) return stft_k1_run<K1<4, 16, 128>, true>(a, q, s);
+    return stft_k1_run<K1<4, 16, 64>, true>(a, q, s);
 }
 
 }  // namespace wv

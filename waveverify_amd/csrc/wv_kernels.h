@@ -136,6 +136,17 @@ inline std::vector<float> pack_stft_q(const std::vector<float>& bt, int n_fft, i
     return q;
 }
 hipError_t launch_stft_k1(const StftArgs& a, hipStream_t s);   // wv_k1.hip; hipErrorNotSupported -> round-1 kernel
+// ---- whole SpecBlock in one launch (modules/seanet.py:463-511): y = resid + out_scale * (W @ logmag(STFT(wav))), the spectrogram
+// stays in LDS.  For the scales whose whole spectrum is one m-tile and whose 1x1 has as many rows (n_fft = M = 64 or 128; Tf % 4 == 0,
+// more than 64 frames).  StftArgs::P is not used.  hipErrorNotSupported: run launch_stft_logmag + the SpecBlock add.
+struct SpecAddArgs {
+    PwWeight pw;          // [M, F] 1x1 (no bias); only the k-inner layout wq is read
+    const float* resid;   // [B, M, Tf] x
+    float* Y;             // [B, M, Tf] x + out_scale * (W @ P), or null (may alias resid)
+    float* Yact;          // [B, M, Tf] ELU(act_scale * y), or null
+    float out_scale, act_scale;
+};
+hipError_t launch_stft_spec(const StftArgs& a, const SpecAddArgs& q, hipStream_t s);   // wv_k1.hip
 // host: basis [2F][n_fft] (cos rows, then sin rows; modules/conv.py:1003-1026) -> basis_t, side
 inline void pack_stft_basis(const float* basis, int n_fft, std::vector<float>& bt, std::vector<float>& side, int* Mp_out) {
     const int F = n_fft / 2 + 1, Mp = round_up(n_fft, M_ALIGN), Kp = round_up(n_fft, BK);

@@ -594,6 +594,21 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         sa.Tf = (T + sp.hop - 1) / sp.hop; sa.n_fft = sp.n_fft; sa.hop = sp.hop; sa.F = sp.F; sa.Mp = sp.Mp;
         sa.mean = sp.mean; sa.inv_std = sp.inv_std;
         if (sa.Tf != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");
+        bool fused_spec = false;
+        {
+            // the scales whose whole spectrum is one tile (n_fft = C <= 128): STFT -> log-magnitude -> 1x1 -> add in ONE launch, the
+            // spectrogram never leaves LDS (wv_k1.hip, stft_k1_kernel<.., true>)
+            wv::SpecAddArgs q{};
+            q.pw = sp.pw; q.resid = sm.raw; q.out_scale = sp.scale;
+            q.Y = post ? sm.raw : nullptr;
+            q.Yact = post ? nullptr : sm.other_act(); q.act_scale = post ? 0.f : m->downs[s].pre_scale;
+            const hipError_t e = wv::launch_stft_spec(sa, q, st);
+            if (e == hipSuccess) {
+                if (!post) { sm.act = q.Yact; sm.raw = nullptr; }
+                fused_spec = true;
+            } else if (e != hipErrorNotSupported) return fail(WV_EHIP, std::string("launch_stft_spec: ") + hipGetErrorString(e));
+        }
+        if (!fused_spec) {
         LAUNCH(wv::launch_stft_logmag(sa, st));
         // x += scale * (W @ P)  (seanet.py:500-502).  Runs on K1 with an identity stencil (taps 0,0,0,0,1
         // are exact: fmaf(0,h,0) = 0, fmaf(1,h,0) = h) and x as the residual operand.  Before a
@@ -617,6 +632,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
             acc.spec_add = 1;
             LAUNCH(wv::launch_pw_dw(acc, st));
             if (!post) { sm.act = acc.Yact; sm.raw = nullptr; }
+        }
         }
         if (post) break;
         const DownLayer& d = m->downs[s];

@@ -167,6 +167,26 @@ int wv_op_stft_logmag(const float* wav, const float* basis_or_null, float* P, in
     return done(t, wv::launch_stft_logmag(a, (hipStream_t)stream), (hipStream_t)stream);
 }
 
+int wv_op_spec_block(const float* wav, const float* basis_or_null, const float* w_pw, const float* x, float* Y, float* Yact, int B, int T,
+                     int n_fft, int hop, int M, float mean, float std, float out_scale, float act_scale, void* stream) {
+    if (!wav || !w_pw || !x || (!Y && !Yact) || B < 1 || T < 1 || hop < 1 || M < 1) return WV_EINVAL;
+    if (n_fft < 4 || (n_fft & 1)) return WV_EINVAL;
+    const int F = n_fft / 2 + 1;
+    const std::vector<float> basis = stft_basis_host(basis_or_null, n_fft);
+    std::vector<float> bt, side;
+    int Mp = 0;
+    wv::pack_stft_basis(basis.data(), n_fft, bt, side, &Mp);
+    Tmp t;
+    wv::StftArgs a{};
+    a.wav = wav; a.basis_t = t.upv(bt); a.basis_q = t.upv(wv::pack_stft_q(bt, n_fft, Mp)); a.side = t.upv(side); a.P = nullptr; a.B = B; a.T = T;
+    a.Tf = (T + hop - 1) / hop; a.n_fft = n_fft; a.hop = hop; a.F = F; a.Mp = Mp; a.mean = mean; a.inv_std = 1.f / std;
+    wv::SpecAddArgs q{};
+    q.pw = t.pw(w_pw, M, F); q.resid = x; q.Y = Y; q.Yact = Yact; q.out_scale = out_scale; q.act_scale = act_scale;
+    const hipError_t e = wv::launch_stft_spec(a, q, (hipStream_t)stream);
+    if (e == hipErrorNotSupported) return WV_EINVAL;
+    return done(t, e, (hipStream_t)stream);
+}
+
 }  // extern "C"
 
 // A resident plan of the same op (the basis packed and uploaded once): what a training step calls once per scale and step.

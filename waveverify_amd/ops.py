@@ -113,6 +113,23 @@ def stft_logmag(wav, n_fft, hop, mean=0.0, std=1.0, basis=None) -> torch.Tensor:
     return P
 
 
+def spec_block(wav, w_pw, x, n_fft, hop, mean=0.0, std=1.0, out_scale=1.0, act_scale: Optional[float] = None, want_raw: bool = True,
+               basis=None):
+    """Whole SpecBlock in one launch: y = x + out_scale * (W @ logmag(STFT(wav))) -> Y, (Y, Yact) or Yact alone."""
+    lib = _lib.load()
+    wav, x = _dev(wav), _dev(x)
+    B, T = wav.shape[0], wav.shape[-1]
+    M = x.shape[1]
+    w_pw = _w(w_pw).reshape(M, n_fft // 2 + 1)
+    Y = torch.empty_like(x) if want_raw else None
+    Yact = torch.empty_like(x) if act_scale is not None else None
+    _lib.check(lib.wv_op_spec_block(wav.data_ptr(), _hp(_w(basis)), _hp(w_pw), x.data_ptr(), _dp(Y), _dp(Yact), B, T, n_fft, hop, M,
+                                    mean, std, out_scale, float(act_scale or 0.0), _stream()), "wv_op_spec_block")
+    if Y is None:
+        return Yact
+    return Y if act_scale is None else (Y, Yact)
+
+
 def conv_pre(x, w, bias, in_scale) -> torch.Tensor:
     lib = _lib.load()
     x = _dev(x)
