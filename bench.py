@@ -141,6 +141,7 @@ def train_step(a, dev, dist, world, rank):
     waveform loss, backward through D, L, the augmentation and G with live weight norm, mean all-reduce of the three flat gradient
     arenas (RCCL when N > 1), generator-only clipping, AdamW.  The reference's step also has audio effects, mel / STFT losses and a
     discriminator, which stay on PyTorch and are NOT in this number, so it is not the headline metric."""
+    from waveverify_amd import profile
     from waveverify_amd.config import default_config
     from waveverify_amd.init import random_state_dict, synthetic_clips
     from waveverify_amd.train import WatermarkTrainer
@@ -174,8 +175,30 @@ def train_step(a, dev, dist, world, rank):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # anatomy: a second pass of the same K steps with a hipEvent pair around every instrumented launch (the K1 GEMMs of forward and
+    # backward, the dW GEMM); the stencil / reduction / optimizer kernels of the training library carry no events and make up the rest
+    profile.reset()
+    profile.enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed_prof = time.perf_counter() - t0
+    profile.enable(False)
+    by = {}
+    for e in profile.collect():
+        k = by.setdefault(e["kernel"], dict(ms=0.0, launches=0, flops=0.0))
+        for f in ("ms", "launches", "flops"):
+            k[f] += e[f]
     if rank == 0:
         ms = elapsed / a.steps * 1e3
+        kernels = sorted(({"kernel": k, "ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["launches"] // a.steps,
+                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] else 0.0,
+                           "frac_of_f32_mfma_peak": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3) if v["ms"] else 0.0}
+                          for k, v in by.items()), key=lambda d: -d["ms_per_step"])
+        inst_ms = sum(v["ms"] for v in by.values()) / a.steps
+        inst_fl = sum(v["flops"] for v in by.values()) / a.steps
         pick = lambda o: {k: round(float(o[k].item()), 5) for k in ("dec/loss", "loc/loss", "waveform/loss")}       # noqa: E731
         print(json.dumps(dict(
             metric="clips/sec training step (generator update: G+D+L forward/backward, BCE + waveform losses), 1s@16kHz bs=64 per GPU",
@@ -188,6 +211,14 @@ def train_step(a, dev, dist, world, rank):
                         parallelism=f"dp{world} (three flat gradient arenas, bucketed mean all-reduce)",
                         parameters=dict(generator=int(tr.G.arena.numel()), detector=int(tr.D.arena.numel()), locator=int(tr.L.arena.numel()))),
             losses_first=pick(outs[0]), losses_last=pick(outs[-1]),
+            roofline=dict(bound="mfma", peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                          instrumented_ms_per_step=round(inst_ms, 3), instrumented_tflop_per_step=round(inst_fl / 1e12, 3),
+                          achieved=round(inst_fl / (inst_ms * 1e-3) / 1e12, 2) if inst_ms else None,
+                          frac=round(inst_fl / (inst_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if inst_ms else None,
+                          step_frac=round(inst_fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                          note="matrix kernels only (K1 forward / backward GEMMs, dW GEMM): their flops over their own event time; step_frac = the "
+                               "same flops over the whole step, i.e. with the bandwidth-bound stencil / reduction / optimizer kernels in the denominator"),
+            kernels=kernels[:12], profiled_ms_per_step=round(elapsed_prof / a.steps * 1e3, 3),
             note="backward on saved activations (the blocks' 1x1 outputs kept from forward), activation derivative / residual / scale "
                  "epilogues fused into the K1 GEMMs, parameter gradients written in place into one flat arena per net")), flush=True)
 

@@ -507,6 +507,8 @@ static hipError_t launch_gemm_nt(hipStream_t st, const float* dh, const float* x
     if ((long long)std::max(M, K) * T >= (1LL << 32)) return hipErrorInvalidValue;     // 32-bit row offsets within one clip
     const int R = nt_tile(M, K);
     const dim3 g((M + R - 1) / R, (K + R - 1) / R, S);
+    // event profiler (bench.py --workload train_step): dW = sum over B * T samples of an M x K outer product, both operands read once
+    prof::Scope ps(st, R == 128 ? "gemm_nt<128>" : "gemm_nt<64>", 2.0 * B * (double)T * M * K, 4.0 * B * (double)T * (M + K) + 4.0 * S * (double)M * K);
     if (R == 128) {
         if (vec) hipLaunchKernelGGL((gemm_nt_kernel<2, true>), g, dim3(256), 0, st, dh, x, part, s, elu, B, M, K, T, TC);
         else hipLaunchKernelGGL((gemm_nt_kernel<2, false>), g, dim3(256), 0, st, dh, x, part, s, elu, B, M, K, T, TC);
