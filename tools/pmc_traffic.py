@@ -26,9 +26,10 @@ def short(name: str) -> str:
         base = "convtr_pw" if ldr >= 2 else ("pw_dw_k5" if epi == 0 and res else "pw_dw_k5_nr" if epi == 0 else "pw_dw" if epi == 1 else "pw_dw_s")
         tag = "reg" if ldr else ("dma3" if ns == "3" else "dma")
         return f"{base}<{bm},{32 * int(nt)},{tag}>"          # spec_add launches share the pw_dw_k5 symbol
-    m = re.match(r"void wv::stft_k1_kernel<wv::K1<(\d+), (\d+), (\d+)>", name)
+    m = re.match(r"void wv::stft_k1_kernel<wv::K1<(\d+), (\d+), (\d+)>, (true|false|[01])>", name)
     if m:
-        return f"stft_logmag<{m.group(3)},{32 * int(m.group(1))},k1>"
+        fused = m.group(4) in ("true", "1")
+        return f"{'stft_spec' if fused else 'stft_logmag'}<{m.group(3)},{32 * int(m.group(1))},k1>"
     m = re.search(r"rb_kernel<wv::\(anonymous namespace\)::RB<(\d+), (\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         c, ng, nt = int(m.group(1)), int(m.group(2)), int(m.group(3))
