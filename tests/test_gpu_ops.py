@@ -287,7 +287,10 @@ def test_pointwise_accumulate(ops, F, C, T):
                                          (1024, 320, 16000), (16, 1, 5), (32, 4, 1), (256, 32, 777),
                                          # frame counts that are multiples of the vector width: the LDS-DMA core
                                          (128, 2, 1000), (192, 4, 800), (16, 1, 8), (32, 4, 1024), (512, 40, 4000),
-                                         (64, 2, 2024), (1024, 64, 4096), (256, 16, 16000)])
+                                         (64, 2, 2024), (1024, 64, 4096), (256, 16, 16000),
+                                         # the nets' finer scales at full clip length, tile edges, ragged waveforms
+                                         (64, 1, 16000), (64, 1, 132), (64, 1, 260), (128, 2, 16000), (128, 2, 263), (128, 4, 16000), (128, 4, 1042),
+                                         (256, 8, 16000), (256, 8, 4000), (256, 8, 1049)])
 def test_stft_logmag(ops, n_fft, hop, T):
     rng = np.random.default_rng(n_fft + hop)
     wav = np.clip(rnd(rng, 2, 1, T, scale=0.1), -1, 1)
@@ -299,9 +302,10 @@ def test_stft_logmag(ops, n_fft, hop, T):
     # absolute bound where mag is near the 1e-5 clamp, tight elsewhere
     got_np = got.cpu().numpy()
     assert got_np.shape == ref.shape
-    big = mag > 1e-3
+    big, mid = mag > 1e-2, (mag > 1e-3) & (mag <= 1e-2)
     assert np.abs(got_np - ref)[big].max(initial=0) <= 2e-5 * max(1.0, np.abs(ref).max())
-    assert np.abs(got_np - ref)[~big].max(initial=0) <= 5e-3
+    assert np.abs(got_np - ref)[mid].max(initial=0) <= 1e-4      # |d log m| = |dm| / m: f32 sums of n_fft terms over magnitudes of 1e-3 .. 1e-2
+    assert np.abs(got_np - ref)[mag <= 1e-3].max(initial=0) <= 5e-3
 
 
 @pytest.mark.parametrize("n_fft,hop,T", [(64, 1, 16000), (64, 1, 132), (64, 1, 1000), (64, 1, 68), (64, 1, 256), (64, 2, 2024), (64, 4, 1024),

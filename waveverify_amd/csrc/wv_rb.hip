@@ -68,14 +68,6 @@ constexpr int RB_OOB = 0x7f000000;                              // byte offset b
                                                                 // same in-order queue, so the A loads behind it must not be needed soon)
 #endif
 
-#ifndef RB_X
-#define RB_X 0        // timing ablations for tools/variant.sh builds only (results are WRONG with any bit set): 1 no ELU, 2 plain fma
-#endif                // instead of the DPP multiply-adds, 4 no LDS writes, 8 no stores, 16 no refill loads, 32 no exp in the ELUs
-__device__ __forceinline__ float rb_elu(float x) {
-    if (RB_X & 1) return x;
-    if (RB_X & 32) return __builtin_amdgcn_fmed3f(x, x * 1.4426950408889634f - 1.f, 0.f);
-    return elu1(x);
-}
 // Diagnostic builds only (tools/variant.sh ... -DRB_STAMP): per-phase shader-clock totals of every wave, written over the head of
 // the output tensor at the end (tools/rbbench.py --stamps reads them back; the output is garbage then).
 #ifdef RB_STAMP
@@ -117,7 +109,6 @@ __device__ __forceinline__ float rb_dpp_next(float v) {        // lane i <- lane
 // y += w * (the next lane's h): the lane shift is a DPP operand of the multiply-add itself (v_fmac_f32 is a fused
 // multiply-add, so this rounds like fmaf).  h must not have been written by the instruction right before.
 __device__ __forceinline__ void rb_fma_next(float& y, float h, float w) {
-    if (RB_X & 2) { y = fmaf(w, h, y); return; }
     asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(y) : "v"(h), "v"(w));
 }
 
@@ -281,7 +272,7 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
         if (hthread) {
             f32x4* hp = reinterpret_cast<f32x4*>(S + hrow * LD + 4 * hpc);
             f32x4 v = *hp;
-            v.x = rb_elu(v.x * p.pre_scale); v.y = rb_elu(v.y * p.pre_scale); v.z = rb_elu(v.z * p.pre_scale); v.w = rb_elu(v.w * p.pre_scale);
+            v.x = elu1(v.x * p.pre_scale); v.y = elu1(v.y * p.pre_scale); v.z = elu1(v.z * p.pre_scale); v.w = elu1(v.w * p.pre_scale);
             *hp = v;
         }
         if (own) {
@@ -291,8 +282,8 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
             for (int r = 0; r < 16; ++r) {
                 ovec v;
 #pragma unroll
-                for (int e = 0; e < NT; ++e) v[e] = rb_elu(X[r][e] * p.pre_scale);
-                if (!((RB_X & 4) && T > 0)) *reinterpret_cast<ovec*>(Xrow + ((r & 3) + 8 * (r >> 2)) * LD) = v;
+                for (int e = 0; e < NT; ++e) v[e] = elu1(X[r][e] * p.pre_scale);
+                *reinterpret_cast<ovec*>(Xrow + ((r & 3) + 8 * (r >> 2)) * LD) = v;
             }
         }
         RB_T(0);
@@ -324,8 +315,8 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
                 rb_stencil<NT>(acc, r, w0, w1, y);
                 ovec uv;
 #pragma unroll
-                for (int e = 0; e < NT; ++e) uv[e] = rb_elu(y[e] * 1.f);
-                if (uw && !((RB_X & 4) && T > 0)) *reinterpret_cast<ovec*>(Urow + cr * LD) = uv;
+                for (int e = 0; e < NT; ++e) uv[e] = elu1(y[e] * 1.f);
+                if (uw) *reinterpret_cast<ovec*>(Urow + cr * LD) = uv;
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (tt == 0 && grp == 0 && NT * q < 4) {             // u at times < 0 is the second conv's zero padding
@@ -347,7 +338,7 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
         // The next window's x goes into S while this GEMM still runs: once every wave has passed chunk c (a barrier at each quarter), the
         // rows below 16c of u are dead, and the DMA instructions that lie wholly inside them are issued -- under matrix work, ahead of
         // epilogue 2's stores (loads and stores share one in-order queue: refill loads issued next to the stores doubled that epilogue).
-        const int next = tile + gridDim.x < ntiles && !((RB_X & 16) && T > 0) ? tile + gridDim.x : -1;
+        const int next = tile + gridDim.x < ntiles ? tile + gridDim.x : -1;
         rb_gemm<R, NCH>(acc, ar, Bf, load_a, rW2, rW1, [&](int c) {   // ... and the next tile's first chunk(s) of W1 behind epilogue 2
             if (R::PARTS > 1 && c % (NCH / R::PARTS) == 0) {
                 constexpr int per = NCH / R::PARTS;
@@ -383,14 +374,14 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
 #pragma unroll
                 for (int e = 0; e < NT; ++e) y[e] = fmaf(v[e], p.out_scale, X[r][e]);
                 const int off = voff0 + cr * row_bytes;
-                if ((OUT & 1) != 0 && !((RB_X & 8) && T > 0)) {
+                if constexpr ((OUT & 1) != 0) {
                     if constexpr (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
                 }
                 if constexpr ((OUT & 2) != 0) {
                     ovec a;
 #pragma unroll
-                    for (int e = 0; e < NT; ++e) a[e] = rb_elu(y[e] * p.act_scale);
+                    for (int e = 0; e < NT; ++e) a[e] = elu1(y[e] * p.act_scale);
                     if constexpr (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, a), rA, off, 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, a), rA, off, 0, 0);
                 }
