@@ -425,3 +425,34 @@ def test_one_message_for_the_whole_batch():
         o = tr.step(x, m)
         outs.append((float(o["dec/loss"].item()), float(o["loss"].item()), tr.G.arena.clone()))
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_resume_from_a_checkpoint_continues_the_same_run(tmp_path):
+    """save_checkpoint(parametrized=True) -> WatermarkTrainer.from_checkpoint: weights, AdamW moments and step count come back, and
+    the next step equals the uninterrupted run's bit for bit; from the stripped layout (the reference's own files) the weights are
+    put back under weight norm (original0 = ||w||, original1 = w) -- the same function, a fresh optimizer at the saved step."""
+    from waveverify_amd.train import WatermarkTrainer
+    small = dict(channels_enc=16, dimension=32)
+    cfgs = [default_config("generator", channels_dec=16, n_residual_dec=1, **small), default_config("detector", **small),
+            default_config("locator")]
+    sds = [random_state_dict(c, 3, parametrized=True) for c in cfgs]
+    rng = np.random.default_rng(9)
+    x = _cu((0.1 * rng.standard_normal((2, 1, 16000))).astype(np.float32))
+    msg = _cu(rng.integers(0, 2, (2, 16)).astype(np.float32))
+    a = WatermarkTrainer(cfgs[0], sds[0], cfgs[1], sds[1], cfgs[2], sds[2], lr=5e-4)
+    np.random.seed(0); torch.manual_seed(0)
+    for _ in range(2):
+        a.step(x, msg)
+    a.save_checkpoint(tmp_path / "live", "latest", parametrized=True)
+    a.save_checkpoint(tmp_path / "stripped", "latest")
+    b = WatermarkTrainer.from_checkpoint(tmp_path / "live", lr=5e-4)
+    assert b.G.opt.t == 2 and torch.equal(b.G.arena.cpu(), a.G.arena.cpu()) and torch.equal(b.D.opt.m.cpu(), a.D.opt.m.cpu())
+    for tr in (a, b):
+        np.random.seed(5); torch.manual_seed(5)
+        tr.step(x, msg)
+    assert torch.equal(a.G.arena, b.G.arena) and torch.equal(a.D.arena, b.D.arena) and torch.equal(a.L.arena, b.L.arena)
+    c = WatermarkTrainer.from_checkpoint(tmp_path / "stripped", lr=5e-4)
+    assert c.G.opt.t == 2 and float(c.G.opt.m.abs().max()) == 0.0
+    wm_a = a.__class__.from_checkpoint(tmp_path / "live").G.forward(x, msg)        # the weights of step 2, live layout
+    wm_c = c.G.forward(x, msg)
+    assert float((wm_a - wm_c).abs().max()) <= 2e-6

@@ -334,3 +334,28 @@ def test_stft_basis_is_the_reference_buffer(golden_dir):
     b64 = stft_basis(64)
     assert tuple(b64.shape) == (66, 1, 64) and np.array_equal(b64[:, 0].numpy(), g["n64"])
     assert np.array_equal(stft_basis(1024)[::19, 0].numpy(), g["n1024_rows_every19"])
+
+
+def test_to_parametrized_is_weight_norm_of_the_same_weights():
+    """checkpoint.to_parametrized: original0 = ||w|| over all dimensions but the first, original1 = w (torch's weight_norm applied to an
+    existing weight), so g v / ||v|| gives the weights back; plain tensors and already-parametrized pairs pass through."""
+    import numpy as np
+    import torch
+    from waveverify_amd.checkpoint import to_parametrized
+    from waveverify_amd.config import default_config
+    from waveverify_amd.init import random_state_dict
+    cfg = default_config("locator")
+    plain = random_state_dict(cfg, 4)
+    live = to_parametrized({k: torch.from_numpy(v) for k, v in plain.items()}, cfg)
+    assert set(live) == set(random_state_dict(cfg, 4, parametrized=True))
+    for k, w in plain.items():
+        if k in live:
+            assert np.array_equal(live[k].numpy(), w)
+            continue
+        base = k[: -len("weight")] + "parametrizations.weight.original"
+        g, v = live[base + "0"], live[base + "1"]
+        assert tuple(g.shape) == (w.shape[0], 1, 1) and np.array_equal(v.numpy(), w)
+        back = v * (g / v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1))
+        assert float((back - torch.from_numpy(w)).abs().max()) <= 1e-6 * float(np.abs(w).max())
+    again = to_parametrized(live, cfg)
+    assert all(torch.equal(again[k], live[k]) for k in live)

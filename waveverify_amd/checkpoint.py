@@ -210,6 +210,26 @@ def stft_basis(n_fft: int) -> torch.Tensor:
     return torch.cat([torch.cos(ang), torch.sin(ang)], dim=0) * torch.hann_window(n_fft, dtype=torch.float32)
 
 
+def to_parametrized(sd: Mapping[str, object], cfg: NetConfig) -> Dict[str, torch.Tensor]:
+    """A stripped state dict (plain `...weight`) in the live weight-norm layout a training step updates: what torch's weight_norm
+    parametrization does when it is applied to an existing weight (`_WeightNorm.right_inverse`: original0 = ||w|| over all dimensions
+    but the first, original1 = w), i.e. how the reference resumes from its own checkpoints.  Keys already parametrized pass through;
+    DFT buffers are dropped (the nets recompute them)."""
+    from .params import param_specs
+    out: Dict[str, torch.Tensor] = {}
+    for key, shape, role in param_specs(cfg):
+        base = key[: -len("weight")] + _TAG if role == "wn" else None
+        if role == "wn" and base + "0" in sd:
+            out[base + "0"], out[base + "1"] = torch.as_tensor(sd[base + "0"]).float(), torch.as_tensor(sd[base + "1"]).float()
+        elif role == "wn":
+            w = torch.as_tensor(sd[key]).float()
+            out[base + "0"] = w.reshape(w.shape[0], -1).norm(dim=1).reshape([w.shape[0]] + [1] * (w.dim() - 1))
+            out[base + "1"] = w.clone()
+        else:
+            out[key] = torch.as_tensor(sd[key]).float()
+    return out
+
+
 def argbind_config(cfgs: Mapping[str, NetConfig]) -> Dict[str, object]:
     """The flat 'Class.argument' dict the reference saves next to the weights (scripts/train.py:1652) for the scalars tensor
     shapes cannot tell; `apply_argbind_config` reads it back."""

@@ -808,6 +808,28 @@ class _NetTrainer:
             raise RuntimeError(f"wv_train_fold_weight: {lib.wv_train_last_error().decode()}")
         return w
 
+    def optimizer_state(self) -> Dict[str, object]:
+        """AdamW's state by parameter key (CPU tensors): {step, exp_avg{key}, exp_avg_sq{key}} -- independent of the arena's order."""
+        return {"step": int(self.opt.t),
+                "exp_avg": {k: self.opt.m[lo:hi].detach().cpu().clone() for k, (lo, hi) in self.ranges.items()},
+                "exp_avg_sq": {k: self.opt.v[lo:hi].detach().cpu().clone() for k, (lo, hi) in self.ranges.items()}}
+
+    def load_optimizer_state(self, st) -> bool:
+        """Restore `optimizer_state()` when it names exactly this trainer's parameters (same keys and sizes); else leave the fresh
+        optimizer as it is and return False (e.g. a checkpoint written in the stripped layout: its moments belong to other tensors)."""
+        try:
+            ok = set(st["exp_avg"]) == set(self.ranges) and all(st["exp_avg"][k].numel() == hi - lo == st["exp_avg_sq"][k].numel()
+                                                                 for k, (lo, hi) in self.ranges.items())
+        except (KeyError, TypeError, AttributeError):
+            ok = False
+        if not ok:
+            return False
+        for k, (lo, hi) in self.ranges.items():
+            self.opt.m[lo:hi] = st["exp_avg"][k].reshape(-1).to(self.opt.m.device)
+            self.opt.v[lo:hi] = st["exp_avg_sq"][k].reshape(-1).to(self.opt.v.device)
+        self.opt.t = int(st["step"])
+        return True
+
     def state_dict(self, parametrized: bool = False) -> Dict[str, torch.Tensor]:
         """The net as the reference's `state_dict()` (CPU tensors, every key of /root/reference/modules/seanet.py's modules incl. the
         DFT buffers and, for a detector / locator, the unused message MLP + FiLM tensors it was built with).
@@ -1130,11 +1152,32 @@ class WatermarkTrainer:
         parametrizations removed, temporary file renamed into place) -- the file `WaveVerify(checkpoint=<save_path>)` reads
         (waveverify/core.py:324-426), here and in the reference.  The optimizer moments go along as plain tensors."""
         from .checkpoint import argbind_config, save_atomic_checkpoint
-        opts = {k: {"step": int(n.opt.t), "lr": float(n.opt.lr), "exp_avg": n.opt.m.detach().cpu(), "exp_avg_sq": n.opt.v.detach().cpu()}
-                for k, n in (("generator", self.G), ("detector", self.D), ("locator", self.L))}
+        opts = {k: n.optimizer_state() for k, n in (("generator", self.G), ("detector", self.D), ("locator", self.L))}
         cfgs = {"generator": self.G.cfg, "detector": self.D.cfg, "locator": self.L.cfg}
         return save_atomic_checkpoint(save_path, tag, self.state_dicts(parametrized), self.G.opt.t if step is None else step,
                                       argbind_config(cfgs), {"optimizers": opts})
+
+    @classmethod
+    def from_checkpoint(cls, path, **kwargs) -> "WatermarkTrainer":
+        """Resume from an atomic (or legacy) checkpoint -- the reference's or one `save_checkpoint` wrote.  Stripped weights are put
+        back under weight norm as torch does it (original0 = ||w||, original1 = w: the same function, `checkpoint.to_parametrized`);
+        the optimizer moments are restored when the file holds them for the live layout (`save_checkpoint(parametrized=True)`),
+        else AdamW starts fresh at the saved step count."""
+        from .checkpoint import find_atomic_checkpoint_file, is_atomic_checkpoint, load_checkpoint, to_parametrized, _load
+        sds, cfgs = load_checkpoint(path)
+        missing = [k for k in ("generator", "detector", "locator") if k not in sds]
+        if missing:
+            raise FileNotFoundError(f"checkpoint {path} has no {', '.join(missing)} weights")
+        live = {k: {n: t.numpy() for n, t in to_parametrized(sds[k], cfgs[k]).items()} for k in sds}
+        tr = cls(cfgs["generator"], live["generator"], cfgs["detector"], live["detector"], cfgs["locator"], live["locator"], **kwargs)
+        if is_atomic_checkpoint(path):
+            ck = _load(find_atomic_checkpoint_file(path))
+            step, opts = int(ck.get("step", 0) or 0), ck.get("optimizers") or {}
+            for k, net in (("generator", tr.G), ("detector", tr.D), ("locator", tr.L)):
+                was_live = any("parametrizations.weight.original" in n for n in sds[k])     # moments of (g, v) fit these (g, v) only
+                if not (was_live and isinstance(opts, dict) and net.load_optimizer_state(opts.get(k))):
+                    net.opt.t = step
+        return tr
 
     def _effects(self, wm_aug, mask):
         """-> (audio, mask, effects_applied): the straight-through effects on the first clips (watermarking.py:521-612)."""
