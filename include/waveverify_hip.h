@@ -191,6 +191,29 @@ int wv_op_stft_logmag(const float* wav, const float* host_basis, float* P, int B
 int wv_op_spec_block(const float* wav, const float* basis_or_null, const float* w_pw, const float* x, float* Y, float* Yact, int B, int T,
                      int n_fft, int hop, int M, float mean, float std, float out_scale, float act_scale, void* stream);
 
+/* ---- f16-operand / f32-accumulate mode (BASELINE.json configs[4] "MFMA linears fp16"; csrc/wv_h16.hip): a throughput mode of the
+ * detector next to the exact-f32 path.  Activations are f16 in the "c8" layout [B][roundup(C,16)/8][T][8] (channel groups of eight,
+ * time-major inside a group = the B operand of v_mfma_f32_32x32x16_f16 as it lies in memory); accumulation, stencils, ELU, bias and
+ * residual adds are f32.  Weights: HOST f32 pointers in the reference's layouts, as for every wv_op_*.
+ *   wv_h16_from_f32 / wv_h16_to_f32   [B,C,T] f32 <-> c8 f16 (from: optionally ELU(scale * x) on the way; rows past C are zero)
+ *   wv_h16_conv_pre   conv_pre (seanet.py:657-664) writing c8 f16
+ *   wv_h16_resblock   whole SEANetResnetBlock (seanet.py:245-281), C in {64,128,256,512}, k = 5, dilation 1, any T
+ *   wv_h16_conv       y = out_scale * (bias + Conv1d(x)) + resid with W[m][i][k] = w_dw[m][i] * w_pw[m][k] (w_dw NULL: 1), causal,
+ *                     x = 0 outside [0,Tin), Tout = ceil(Tin/stride): the downsample unit (ks = 2r, stride r, pad r; seanet.py:739-760)
+ *                     and the SpecBlock's 1x1 + add (ks = 1; seanet.py:500-502).  Outputs: Y16 / Yact16 = ELU(act_scale*y) in c8 f16,
+ *                     Yf32 [B,M,Tout] f32 row-major (any of them NULL).
+ *   wv_detector_forward_f16   Detector.forward (model/detector.py:366-391) in this mode: conv_pre .. the last downsample in f16,
+ *                     the STFTs, spec_post, conv_post and the head in f32 (same workspace as wv_detector_forward). */
+int wv_h16_from_f32(const float* X, void* Y16, int B, int C, int T, float scale, int elu, void* stream);
+int wv_h16_to_f32(const void* X16, float* Y, int B, int C, int T, void* stream);
+int wv_h16_conv_pre(const float* x, const float* w, const float* bias, void* Y16, int B, int C, int T, int ks, float in_scale, void* stream);
+int wv_h16_resblock(const void* X16, float pre_scale, const float* w_pw1, const float* w_dw1, const float* b1, const float* w_pw2, const float* w_dw2,
+                    const float* b2, void* Y16, void* Yact16, int B, int C, int T, float out_scale, float act_scale, void* stream);
+int wv_h16_conv(const void* X16, const float* w_pw, const float* w_dw, const float* bias, const void* resid16, void* Y16, void* Yact16, float* Yf32,
+                int B, int K, int M, int Tin, int ks, int stride, int pad, float out_scale, float act_scale, void* stream);
+int wv_detector_forward_f16(wv_model* m, const float* x, float* logits, float* mean_prob,
+                            int B, int T, void* workspace, size_t workspace_bytes, void* stream);
+
 /* conv_pre: Y = Conv1d(1->C,k)(x * in_scale) + bias  (seanet.py:657-664). x [B,1,T], w [C,1,k]. */
 
 /* The same op with the basis packed and uploaded ONCE (a training step computes these features for every scale at every step):

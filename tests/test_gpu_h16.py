@@ -1,0 +1,142 @@
+"""The detector's f16-operand / f32-accumulate mode (csrc/wv_h16.hip), unit by unit through the C ABI against the numpy oracle.
+
+The mode is NOT the exact path: activations cross HBM as f16, weights are f16, sums are f32.  The references below therefore
+restate the same roundings (x, weights, ELU(c*x), u rounded to f16 where the kernel rounds them; float64 sums), so that what is left
+is f32 summation order plus an occasional one-ulp flip of an f16 rounding: tolerance 3 f16 ulps of the result's magnitude
+(3 * 2**-11 relative to max(1, |ref|max)) -- 75 times the f32 suite's bar, stated here because it is a different arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wv_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 3 * 2.0 ** -11
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from waveverify_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return _ops
+
+
+def rnd(rng, *shape, scale=1.0):
+    return (scale * rng.standard_normal(shape)).astype(np.float32)
+
+
+def h(a):
+    """round to f16 and back (what the kernels store)"""
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(got, ref, what="", tol=TOL):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), what
+    err = float(np.abs(got - ref).max()) if ref.size else 0.0
+    lim = tol * max(1.0, float(np.abs(ref).max()) if ref.size else 1.0)
+    assert err <= lim, f"{what}: max|d|={err:.3e} > {lim:.3e}"
+
+
+def c8_to_np(ops, t, C):
+    return ops.h16_to_f32(t, C).cpu().numpy()
+
+
+@pytest.mark.parametrize("B,C,T", [(2, 64, 1000), (3, 33, 17), (1, 8, 1), (2, 129, 300)])
+def test_layout_round_trip(ops, B, C, T):
+    rng = np.random.default_rng(C + T)
+    X = rnd(rng, B, C, T)
+    t = ops.h16_from_f32(cu(X))
+    assert t.dtype == torch.float16 and tuple(t.shape) == (B, (C + 15) // 16 * 2, T, 8)
+    # the layout itself: element (b, c, t) sits at [b, c // 8, t, c % 8]; rows past C are zero
+    ref = np.zeros((B, t.shape[1] * 8, T), np.float32)
+    ref[:, :C] = h(X)
+    lay = t.float().cpu().numpy().transpose(0, 1, 3, 2).reshape(B, -1, T)
+    assert np.array_equal(lay, ref)
+    assert np.array_equal(c8_to_np(ops, t, C), h(X))
+    act = ops.h16_from_f32(cu(X), scale=0.7, elu=True)
+    close(ops.h16_to_f32(act, C), h(O.elu(X * np.float32(0.7))), "ELU on the way", tol=2.0 ** -11)
+
+
+@pytest.mark.parametrize("C,T,ks", [(64, 1000, 7), (64, 5, 7), (32, 300, 5)])
+def test_conv_pre(ops, C, T, ks):
+    rng = np.random.default_rng(C + T)
+    x = rnd(rng, 3, 1, T, scale=0.1)
+    w, b = rnd(rng, C, 1, ks, scale=0.4), rnd(rng, C, scale=0.1)
+    s = np.float32(1.0 / 0.1122080159)
+    ref = O.sconv1d(x * s, w, b)
+    got = ops.h16_conv_pre(cu(x), w, b, in_scale=float(s))
+    close(ops.h16_to_f32(got, C), h(ref), "conv_pre16")
+
+
+# lengths around every tile edge: 244 outputs per tile at C = 64, 120 at C = 128 / 256, 56 at C = 512; one-sample and sub-halo clips
+@pytest.mark.parametrize("C,T", [(64, 16000), (64, 244), (64, 245), (64, 1), (64, 7), (64, 500), (128, 8000), (128, 120), (128, 121), (128, 3),
+                                 (256, 2000), (256, 119), (256, 241), (512, 400), (512, 56), (512, 57), (512, 5)])
+def test_resblock(ops, C, T):
+    rng = np.random.default_rng(C * 3 + T)
+    B = 3
+    X = h(rnd(rng, B, C, T))
+    w1, w2 = h(rnd(rng, C, C, 1, scale=C ** -0.5)), h(rnd(rng, C, C, 1, scale=C ** -0.5))
+    d1, d2 = rnd(rng, C, 1, 5, scale=0.45), rnd(rng, C, 1, 5, scale=0.45)
+    b1, b2 = rnd(rng, C, scale=0.1), rnd(rng, C, scale=0.1)
+    pre, s_out, s_act = np.float32(0.8660254), np.float32(0.41), np.float32(0.7071)
+    xa = h(O.elu(X * pre))
+    u = h(O.elu(O.sconv1d(O.sconv1d(xa.astype(np.float64), w1.astype(np.float64), None), d1.astype(np.float64), b1.astype(np.float64), groups=C)))
+    y = X + s_out * O.sconv1d(O.sconv1d(u.astype(np.float64), w2.astype(np.float64), None), d2.astype(np.float64), b2.astype(np.float64), groups=C)
+    y = y.astype(np.float32)
+    X16 = ops.h16_from_f32(cu(X))
+    got, gact = ops.h16_resblock(X16, w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out), act_scale=float(s_act))
+    close(ops.h16_to_f32(got, C), h(y), "resblock16")
+    close(ops.h16_to_f32(gact, C), h(O.elu(y * s_act)), "resblock16 (activated copy)")
+    only_raw = ops.h16_resblock(X16, w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out))
+    only_act = ops.h16_resblock(X16, w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out), act_scale=float(s_act), want_raw=False)
+    assert torch.equal(only_raw, got) and torch.equal(only_act, gact)
+
+
+@pytest.mark.parametrize("K,M,Tin,r", [(64, 128, 16000, 2), (64, 128, 1001, 2), (128, 256, 8000, 4), (128, 256, 501, 4), (256, 512, 2000, 5), (256, 512, 203, 5),
+                                       (512, 1024, 400, 8), (512, 1024, 37, 8), (64, 128, 1, 2), (32, 64, 70, 8)])
+def test_downsample_as_one_conv(ops, K, M, Tin, r):
+    """ELU -> 1x1 -> depth-wise(2r, stride r) (seanet.py:739-760) with the two convolutions composed into one dense conv; c8 and f32 outputs."""
+    rng = np.random.default_rng(K + M + Tin)
+    B = 3
+    X = rnd(rng, B, K, Tin)
+    w_pw, w_dw, b = rnd(rng, M, K, 1, scale=K ** -0.5), rnd(rng, M, 1, 2 * r, scale=(2 * r) ** -0.5), rnd(rng, M, scale=0.1)
+    pre = np.float32(0.7559)
+    xa = h(O.elu(X * pre))
+    wc = h(w_pw[:, :, 0][:, None, :] * w_dw[:, 0, :][:, :, None])          # [M][2r][K], rounded as the packer rounds it
+    Tout = (Tin + r - 1) // r
+    xp = np.zeros((B, K, r + Tout * r + r), np.float64)
+    xp[:, :, r:r + Tin] = xa
+    ref = np.zeros((B, M, Tout), np.float64)
+    for i in range(2 * r):
+        ref += np.einsum("mk,bkt->bmt", wc[:, i, :].astype(np.float64), xp[:, :, i:i + Tout * r:r])
+    ref = (ref + b[None, :, None]).astype(np.float32)
+    # the composition itself against the reference's two convs in float64 (f16 rounding of the composed weight: a few 1e-4 relative)
+    two = O.sconv1d(O.sconv1d(xa.astype(np.float64), w_pw.astype(np.float64), None), w_dw.astype(np.float64), b.astype(np.float64), stride=r, groups=M)
+    assert np.abs(two - ref).max() <= 4 * 2.0 ** -11 * max(1.0, np.abs(two).max())
+    X16 = ops.h16_from_f32(cu(X), scale=float(pre), elu=True)
+    out = ops.h16_conv(X16, w_pw, w_dw, b, ks=2 * r, stride=r, pad=r, act_scale=0.5, want_f32=True)
+    close(out["f32"], ref, "downsample16 (f32 out)", tol=2e-4)
+    close(ops.h16_to_f32(out["raw"], M), h(ref), "downsample16")
+    close(ops.h16_to_f32(out["act"], M), h(O.elu(ref * np.float32(0.5))), "downsample16 (activated copy)")
+
+
+@pytest.mark.parametrize("F,M,T", [(33, 64, 16000), (33, 64, 77), (65, 128, 8000), (129, 256, 2000), (257, 512, 400), (257, 512, 3)])
+def test_spec_add(ops, F, M, T):
+    """x' = x + scale * (W @ P) (seanet.py:500-502) with the spectrum rows zero-padded to a multiple of 16; only ELU(c * x') is written."""
+    rng = np.random.default_rng(F + M + T)
+    B = 3
+    P, X = rnd(rng, B, F, T, scale=1.5), h(rnd(rng, B, M, T))
+    w = h(rnd(rng, M, F, 1, scale=F ** -0.5))
+    scale, c = np.float32(0.577), np.float32(0.7559)
+    ref = (X + scale * np.einsum("mf,bft->bmt", w[:, :, 0].astype(np.float64), h(P).astype(np.float64))).astype(np.float32)
+    P16, X16 = ops.h16_from_f32(cu(P)), ops.h16_from_f32(cu(X))
+    out = ops.h16_conv(P16, w, None, None, resid16=X16, K=F, out_scale=float(scale), act_scale=float(c))
+    close(ops.h16_to_f32(out["raw"], M), h(ref), "spec add16")
+    close(ops.h16_to_f32(out["act"], M), h(O.elu(ref * c)), "spec add16 (activated copy)")

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libwaveverify_hip.so")
-SOURCES = ["wv_kernels.hip", "wv_k1.hip", "wv_rb.hip", "wv_model.hip", "wv_ops.hip", "wv_train.hip", "wv_aug.hip", "wv_fx.hip"]
+SOURCES = ["wv_kernels.hip", "wv_k1.hip", "wv_rb.hip", "wv_h16.hip", "wv_model.hip", "wv_ops.hip", "wv_train.hip", "wv_aug.hip", "wv_fx.hip"]
 HEADERS = [os.path.join(CSRC, "wv_kernels.h"), os.path.join(CSRC, "wv_dev.h"),
            os.path.join(os.path.dirname(HERE), "include", "waveverify_hip.h")]
 ARCH = "gfx950"
@@ -51,7 +51,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(HERE, "lib", src.replace(".hip", ".o"))
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
-               "-ffp-contract=fast" if src in ("wv_kernels.hip", "wv_k1.hip", "wv_rb.hip") else "-ffp-contract=off"]
+               "-ffp-contract=fast" if src in ("wv_kernels.hip", "wv_k1.hip", "wv_rb.hip", "wv_h16.hip") else "-ffp-contract=off"]
         if src == "wv_model.hip":
             cmd.append(f'-DWV_SRC_HASH="{source_hash()}"')
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]

@@ -1,0 +1,621 @@
+// The detector's f16-operand / f32-accumulate mode (BASELINE.json configs[4]: "MFMA linears fp16"): a throughput mode next to the
+// exact-f32 path, never in place of it.  Activations live in HBM as f16 in the layout the f16 matrix instruction reads its B operand
+// in -- channel groups of eight, time-major inside a group:
+//
+//     X16[b][g = c / 8][t][c % 8]        ("c8": one (group, time) pair = 16 bytes = the 8 consecutive k of a B fragment)
+//
+// so that a lane's B fragment of v_mfma_f32_32x32x16_f16 is ONE 16-byte read (LDS or global), a whole time run of a group is
+// contiguous (LDS-DMA copies it as it lies), and an accumulator lane (4 consecutive rows of a group at one time) stores 8 bytes.
+// Weights are packed as A fragments, wq16[chunk][m][k-half][8] (one 16-byte load per lane and 16-deep chunk).  Accumulation, the
+// depth-wise stencils, ELU, bias, residual add are f32; only what crosses HBM (and the window in LDS) is f16.
+//
+//   rh_kernel      whole SEANetResnetBlock (modules/seanet.py:245-281) in one launch, the structure of wv_rb.hip: persistent
+//                  workgroups, the x window in LDS by LDS-DMA, raw x kept (packed) in registers as the residual, both stencils from
+//                  the accumulators, u never leaves the CU.  Half the bytes of the f32 kernel and 1/16 of its matrix time.
+//   conv16_kernel  dense causal Conv1d as an implicit GEMM straight from global memory (no LDS, no barrier): the downsample unit
+//                  ELU -> 1x1 -> depth-wise(2r, stride r) with the two convolutions composed into one [M][2r][K] weight (twice the
+//                  flops, which this pipe has to spare, and no stencil epilogue at all), and the SpecBlock's 1x1 + add (ks = 1).
+//   conv_pre16, f32_to_c8, c8_to_f32   the layout's entry and exit.
+#include <atomic>
+#include <string>
+#include <type_traits>
+
+#include "wv_dev.h"
+
+namespace wv {
+
+namespace {
+
+typedef _Float16 h16;
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H_OOB = 0x7f000000;                               // byte offset beyond any num_records here
+
+#define RH_BARRIER()                                             \
+    do {                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_s_barrier();                            \
+        asm volatile("" ::: "memory");                           \
+    } while (0)
+
+__device__ __forceinline__ float rh_dpp_next(float v) {        // lane i <- lane i+1 (wave_shl:1), lane 63 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void rh_fma_next(float& y, float h, float w) {
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(y) : "v"(h), "v"(w));
+}
+
+// 5-tap stencil from the accumulators (wv_rb.hip's): y[e] = bias + sum_i w[i] * H[NT*q + e + i], the lane's NT consecutive columns in
+// its NT accumulators, the columns past them from the next lane(s) as DPP operands of the multiply-adds.
+template <int NT>
+__device__ __forceinline__ void rh_stencil(const f32x16 (&acc)[NT], int r, const f32x4& w0, const f32x4& w1, float (&y)[NT]) {
+    const float w[5] = {w0.x, w0.y, w0.z, w0.w, w1.x};
+    float own[NT];
+#pragma unroll
+    for (int e = 0; e < NT; ++e) own[e] = acc[e][r];
+    if constexpr (NT == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = w1.y;
+#pragma unroll
+            for (int i = 0; i + e < 4; ++i) v = fmaf(w[i], own[e + i], v);
+            y[e] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 4 - e; i < 5; ++i) rh_fma_next(y[e], own[e + i - 4], w[i]);
+    } else {
+        float sh[2] = {rh_dpp_next(own[0]), rh_dpp_next(own[1])};        // columns 2q + 2, 2q + 3
+        float v0 = fmaf(w[0], own[0], w1.y), v1 = fmaf(w[0], own[1], w1.y);
+        v0 = fmaf(w[1], own[1], v0);
+        rh_fma_next(v1, own[0], w[1]);
+        rh_fma_next(v0, own[0], w[2]); rh_fma_next(v1, own[1], w[2]);
+        rh_fma_next(v0, own[1], w[3]);
+        asm volatile("" : "+v"(sh[0]), "+v"(sh[1]));
+        rh_fma_next(v1, sh[0], w[3]);
+        rh_fma_next(v0, sh[0], w[4]); rh_fma_next(v1, sh[1], w[4]);
+        y[0] = v0; y[1] = v1;
+    }
+}
+
+// C channels, NG column groups of 32*NT columns (overlapping by the stencil's 4), WPS waves per SIMD.  One wave = one 32-row strip x
+// one column group.  RESIDENT: both weight strips of a wave stay in registers for the kernel's life (C <= 128: 2 * C/16 fragments);
+// wider layers stream them through a ring, A_AHEAD chunks in front of their MFMAs.
+template <int C_, int NG_, int NT_, int WPS_, int RING_ = 8, int PD_ = 2>
+struct RH {
+    static constexpr int C = C_, NG = NG_, NT = NT_, WPS = WPS_, PD = PD_;
+    static constexpr int WM = C / 32, NWAVES = WM * NG, NTHREADS = 64 * NWAVES;
+    static constexpr int GS = 32 * NT - 4, WD = NG * GS + 4, TTO = WD - 8;
+    static constexpr int G = C / 8, NCH = C / 16;
+    static constexpr int PIECES = G * WD;                                  // 16-byte (group, column) pieces of a window
+    static constexpr int NI = (PIECES + 64 * NWAVES - 1) / (64 * NWAVES);  // LDS-DMA instructions per wave and window
+    static constexpr bool RESIDENT = C <= 128;
+    static constexpr int NA = RESIDENT ? 2 * NCH : RING_, AD = NA - 1;
+    static constexpr size_t WBYTES = (size_t)PIECES * 16;
+    static constexpr size_t SMEM = WBYTES + (size_t)2 * C * 8 * sizeof(float);
+    static_assert(C % 32 == 0 && (NT == 2 || NT == 4) && NTHREADS <= 1024 && NTHREADS >= C && (2 * NCH) % NA == 0 && (RESIDENT || AD <= NCH),
+                  "geometry");
+};
+
+// OUT: 1 = Y, 2 = Yact, 3 = both
+template <class R, int OUT>
+__global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::WPS, R::WPS))) void rh_kernel(RhArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NT = R::NT, C = R::C, WD = R::WD, NCH = R::NCH, G = R::G, NA = R::NA, AD = R::AD;
+    h16* S = reinterpret_cast<h16*>(smem_raw);                   // [G][WD][8]
+    float* tab = reinterpret_cast<float*>(smem_raw + R::WBYTES); // [2][C][8]: taps, bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = wave % R::WM, grp = wave / R::WM;
+    const int h = lane >> 5, q = lane & 31;
+    const int T = p.T, ntiles = p.ntiles, num_t = p.num_t;
+    const int clip_bytes = G * T * 16;
+
+    for (int i = tid; i < C * 8; i += R::NTHREADS) { tab[i] = p.tab1[i]; tab[C * 8 + i] = p.tab2[i]; }
+
+    // ---- A fragments: wq16[chunk][C][2][8]; lane (q, h) of strip: 16 bytes at ((32*strip + q) * 2 + h) * 16, chunk as scalar offset
+    const __amdgpu_buffer_rsrc_t rW1 = uniform_rsrc(p.w1.wq, NCH * C * 32);
+    const __amdgpu_buffer_rsrc_t rW2 = uniform_rsrc(p.w2.wq, NCH * C * 32);
+    const int avoff = ((32 * strip + q) * 2 + h) * 16;
+    h16x8 ar[NA];
+    auto load_a = [&](const __amdgpu_buffer_rsrc_t& rw, int c, h16x8& dst) {
+        const int so = c * C * 32;
+        dst = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, avoff, so, 0));
+    };
+
+    // ---- this lane's place in a window (wv_rb.hip): rows 32*strip + 8j + 4h + rr (j, rr = 0..3) = group 4*strip + j, halves 4h + rr;
+    // B / u columns co + e, x columns co + 8 + e
+    const int co = R::GS * grp + NT * q;
+    const bool own = NT * q < R::GS && co < R::TTO;
+    const bool uw = NT * q < R::GS;
+    const int row0 = 32 * strip + 4 * h;
+    const h16* Bf = S + (size_t)(h * WD + co) * 8;               // B fragments of this lane's k-half, its columns (chunk c: + 2c*WD*8)
+    h16* Urow = S + (size_t)(4 * strip * WD + co) * 8 + 4 * h;    // (group 4*strip, column co), this lane's 4 halves (group j: + j*WD*8)
+    h16* Xrow = Urow + 8 * 8;
+    const float* Wrow1 = tab + row0 * 8;
+    const float* Wrow2 = Wrow1 + C * 8;
+    const bool hthread = tid < G * 8;                            // the 8 halo columns in front: one 16-byte piece per thread
+    const int hpiece = (tid >> 3) * WD + (tid & 7);
+
+    // ---- window refill by LDS-DMA: piece p = (group, column) lands at S + 16 p; instruction i of this wave copies pieces
+    // (i * NWAVES + wave) * 64 + lane.  Columns outside [0, T) read an out-of-range offset = zeros (the causal padding).
+    int pk[R::NI];
+#pragma unroll
+    for (int i = 0; i < R::NI; ++i) {
+        const int pi = (i * R::NWAVES + wave) * 64 + lane;
+        pk[i] = pi < R::PIECES ? (((pi / WD) << 16) | (pi % WD)) : -1;
+    }
+    auto refill = [&](int t) {
+        if (t < 0) return;
+        const int b = t / num_t, tt = t - b * num_t;
+        const int tw0 = tt * R::TTO - 8;
+        const __amdgpu_buffer_rsrc_t rX = uniform_rsrc(reinterpret_cast<const h16*>(p.X) + (size_t)b * G * T * 8, clip_bytes);
+#pragma unroll
+        for (int i = 0; i < R::NI; ++i) {
+            const int p0 = (i * R::NWAVES + wave) * 64;
+            const int k_ = pk[i];
+            const int tx = tw0 + (k_ & 0xffff);
+            const int vo = (tx >= 0 && tx < T) ? ((k_ >> 16) * T + tx) * 16 : H_OOB;
+            h16* dst = S + (size_t)p0 * 8;
+            if (p0 < R::PIECES) {
+                if (k_ >= 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)dst, 16, vo, 0, 0, 0);
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    refill(tile);
+    if constexpr (R::RESIDENT) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { load_a(rW1, c, ar[c]); load_a(rW2, c, ar[NCH + c]); }
+    } else {
+#pragma unroll
+        for (int c = 0; c < AD; ++c) load_a(rW1, c, ar[c % NA]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RH_BARRIER();
+
+    h16x4 X[4][NT];                                              // raw x where this lane's outputs lie: the residual operand
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / num_t, tt = tile - b * num_t;
+        const int to0 = tt * R::TTO;
+        // ================= activation pass: X = x (raw), S = ELU(c * x) in place ======================
+        if (hthread) {
+            h16x8* hp = reinterpret_cast<h16x8*>(S + (size_t)hpiece * 8);
+            h16x8 v = *hp;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (h16)elu1((float)v[i] * p.pre_scale);
+            *hp = v;
+        }
+        if (own) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < NT; ++e) X[j][e] = *reinterpret_cast<const h16x4*>(Xrow + (size_t)(j * WD + e) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < NT; ++e) {
+                    h16x4 v;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu1((float)X[j][e][rr] * p.pre_scale);
+                    *reinterpret_cast<h16x4*>(Xrow + (size_t)(j * WD + e) * 8) = v;
+                }
+        }
+        RH_BARRIER();                                            // B1: window complete
+        // ================= GEMM 1: H1 = W1 @ S =======================================================
+        f32x16 acc[NT];
+        auto gemm = [&](auto g0c, const __amdgpu_buffer_rsrc_t& rw, const __amdgpu_buffer_rsrc_t& rw_next) {
+            constexpr int g0 = decltype(g0c)::value;
+#pragma unroll
+            for (int e = 0; e < NT; ++e)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+            constexpr int PD = R::PD, NB = PD + 1;
+            h16x8 bq[NB][NT];
+#pragma unroll
+            for (int c = 0; c < PD && c < NCH; ++c)
+#pragma unroll
+                for (int e = 0; e < NT; ++e) bq[c % NB][e] = *reinterpret_cast<const h16x8*>(Bf + (size_t)(2 * c * WD + e) * 8);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if constexpr (!R::RESIDENT) {
+                    if (c + AD < NCH) load_a(rw, c + AD, ar[(g0 + c + AD) % NA]);
+                    else load_a(rw_next, c + AD - NCH, ar[(g0 + c + AD) % NA]);
+                }
+                if (c + PD < NCH) {
+#pragma unroll
+                    for (int e = 0; e < NT; ++e)
+                        bq[(c + PD) % NB][e] = *reinterpret_cast<const h16x8*>(Bf + (size_t)(2 * (c + PD) * WD + e) * 8);
+                }
+                const h16x8 a = ar[(g0 + c) % NA];
+#pragma unroll
+                for (int e = 0; e < NT; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[c % NB][e], acc[e], 0, 0, 0);
+                // one sequence point per chunk over all NT accumulator chains: left alone the compiler runs the chains one after the
+                // other over the whole GEMM and parks the other chains' operands in scratch
+                if constexpr (NT == 4) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+                else asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        gemm(std::integral_constant<int, 0>{}, rW1, rW2);
+        RH_BARRIER();                                            // B2: every wave has read the window (u overwrites it)
+        // ================= epilogue 1: u = ELU(DW5(H1) + b1) -> S ======================================
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float uu[4][NT];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int cr = rr + 8 * j;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wrow1 + cr * 8), w1 = *reinterpret_cast<const f32x4*>(Wrow1 + cr * 8 + 4);
+                float y[NT];
+                rh_stencil<NT>(acc, 4 * j + rr, w0, w1, y);
+#pragma unroll
+                for (int e = 0; e < NT; ++e) uu[rr][e] = elu1(y[e]);
+            }
+            if (uw) {
+#pragma unroll
+                for (int e = 0; e < NT; ++e) {
+                    h16x4 v;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)uu[rr][e];
+                    *reinterpret_cast<h16x4*>(Urow + (size_t)(j * WD + e) * 8) = v;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tt == 0 && grp == 0 && NT * q < 4) {                 // u at times < 0 is the second conv's zero padding
+            h16x4 z;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) z[rr] = (h16)0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < NT; ++e) *reinterpret_cast<h16x4*>(Urow + (size_t)(j * WD + e) * 8) = z;
+        }
+        RH_BARRIER();                                            // B3: u complete
+        // ================= GEMM 2: H2 = W2 @ u ========================================================
+        gemm(std::integral_constant<int, NCH>{}, rW2, rW1);
+        RH_BARRIER();                                            // B4: every wave has read u (the next window overwrites it)
+        // ================= epilogue 2: y = x + s * (DW5(H2) + b2) -> HBM; refill x ======================
+        {
+            const int next = tile + gridDim.x < ntiles ? tile + gridDim.x : -1;
+            const size_t bo = (size_t)b * G * T * 8;
+            const __amdgpu_buffer_rsrc_t rY = uniform_rsrc((OUT & 1) ? reinterpret_cast<h16*>(p.Y) + bo : reinterpret_cast<const h16*>(p.X), (OUT & 1) ? clip_bytes : 0);
+            const __amdgpu_buffer_rsrc_t rA = uniform_rsrc((OUT & 2) ? reinterpret_cast<h16*>(p.Yact) + bo : reinterpret_cast<const h16*>(p.X), (OUT & 2) ? clip_bytes : 0);
+            int voff[NT];
+#pragma unroll
+            for (int e = 0; e < NT; ++e) {
+                const int t = to0 + co + e;
+                voff[e] = (own && t < T) ? ((4 * strip) * T + t) * 16 + 8 * h : H_OOB;
+            }
+            const int jstep = T * 16;
+            refill(next);                                        // ahead of the stores below (one in-order queue)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float yy[4][NT];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int cr = rr + 8 * j;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wrow2 + cr * 8), w1 = *reinterpret_cast<const f32x4*>(Wrow2 + cr * 8 + 4);
+                    float v[NT];
+                    rh_stencil<NT>(acc, 4 * j + rr, w0, w1, v);
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) yy[rr][e] = fmaf(v[e], p.out_scale, (float)X[j][e][rr]);
+                }
+#pragma unroll
+                for (int e = 0; e < NT; ++e) {
+                    const int off = voff[e] == H_OOB ? H_OOB : voff[e] + j * jstep;
+                    if constexpr ((OUT & 1) != 0) {
+                        h16x4 v;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)yy[rr][e];
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rY, off, 0, 0);
+                    }
+                    if constexpr ((OUT & 2) != 0) {
+                        h16x4 v;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu1(yy[rr][e] * p.act_scale);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rA, off, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the refill is older than this epilogue's stores: wait until only those are outstanding, then meet the other waves
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NT * ((OUT & 1) + (OUT >> 1))) : "memory");
+        RH_BARRIER();                                            // B0: the next window has landed
+    }
+}
+
+int cu_count16() {
+    static std::atomic<int> cached[32];
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 31;
+    int n = cached[d].load(std::memory_order_relaxed);
+    if (n == 0) {
+        hipDeviceProp_t pr;
+        n = hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        cached[d].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+template <class R, int OUT>
+hipError_t rh_launch(RhArgs a, hipStream_t s) {
+    a.num_t = (a.T + R::TTO - 1) / R::TTO;
+    const long long nt = (long long)a.num_t * a.B;
+    if (nt > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.ntiles = (int)nt;
+    static std::atomic<unsigned> attr{0};
+    if (R::SMEM > 64 * 1024) {
+        int d = 0; (void)hipGetDevice(&d);
+        const unsigned bit = 1u << (d & 31);
+        if (!(attr.load(std::memory_order_relaxed) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rh_kernel<R, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::SMEM);
+            if (e != hipSuccess) return e;
+            attr.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    const int per_cu = std::max(1, std::min((int)(160 * 1024 / R::SMEM), 4 * R::WPS / R::NWAVES));
+    const int grid = (int)std::min<long long>(nt, (long long)cu_count16() * per_cu);
+    std::string name;
+    if (prof::enabled()) name = "resblock16<" + std::to_string(R::C) + "," + std::to_string(R::WD) + ">";
+    const double C = a.C, Bd = a.B, T = a.T;
+    prof::Scope ps(s, name.c_str(), 2.0 * 2.0 * Bd * C * (C * T + 5.0 * T), 2.0 * Bd * C * T * (1.0 + ((OUT & 1) ? 1.0 : 0.0) + ((OUT & 2) ? 1.0 : 0.0)));
+    hipLaunchKernelGGL((rh_kernel<R, OUT>), dim3((unsigned)grid), dim3(R::NTHREADS), R::SMEM, s, a);
+    return hipGetLastError();
+}
+
+template <class R>
+hipError_t rh_pick_out(const RhArgs& a, hipStream_t s) {
+    if (a.Y && a.Yact) return rh_launch<R, 3>(a, s);
+    if (a.Y) return rh_launch<R, 1>(a, s);
+    return rh_launch<R, 2>(a, s);
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Dense causal Conv1d on c8 activations as an implicit GEMM, operands straight from global memory:
+//     y[m][to] = out_scale * ( bias[m] + sum_{i < ks} sum_k W[m][i][k] * x[k][to * stride + i - pad] ) + resid[m][to]
+// (x = 0 outside [0, Tin)).  Chunk ch = (tap i, 16 channels kc): A fragment = wq16[ch][m][h][8], B fragment = the 16-byte piece
+// (group 2 kc + h, time to * stride + i - pad) of x.  A wave owns 64 rows x 64 output times (2 x 2 MFMA tiles); the four waves of a
+// workgroup share either the columns (WGM = 4: the B pieces of one wave are L1 hits for the other three) or the rows.  Loads run
+// D chunks ahead of their MFMAs in a register ring; there is no LDS and no barrier.
+template <int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
+    constexpr int D = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WGM, wn = wave / WGM;
+    const int h = lane >> 5, q = lane & 31;
+    const int ncol = (p.Tout + 64 * WGN - 1) / (64 * WGN);
+    const int b = blockIdx.x / ncol, ct = blockIdx.x - b * ncol;
+    const int m0 = (blockIdx.y * WGM + wm) * 64;
+    const int to0 = (ct * WGN + wn) * 64;
+    if (m0 >= p.M || to0 >= p.Tout) return;
+    const int Tin = p.Tin, Tout = p.Tout, Gk = p.w.Kp / 8, Gm = (p.M + 15) / 16 * 2, Mp = p.w.Mp, NKC = p.w.Kp / 16, nch = p.w.nchunks;
+    const __amdgpu_buffer_rsrc_t rX = uniform_rsrc(reinterpret_cast<const h16*>(p.X) + (size_t)b * Gk * Tin * 8, Gk * Tin * 16);
+    const __amdgpu_buffer_rsrc_t rW = uniform_rsrc(p.w.wq, nch * Mp * 32);
+    int avoff[2], tin0[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) avoff[mt] = (m0 + 32 * mt + q < Mp) ? ((m0 + 32 * mt + q) * 2 + h) * 16 : H_OOB;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) tin0[e] = (to0 + 32 * e + q) * p.stride - p.pad;
+    const int nreal = p.ks * NKC;
+
+    h16x8 ra[D][2], rb[D][2];
+    int ich = 0, ii = 0, ikc = 0;                                // the next chunk to load = (tap ii, channel chunk ikc); wave-uniform
+    auto issue = [&](h16x8 (&a)[2], h16x8 (&bb)[2]) {
+        const int so_a = ich * Mp * 32;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a[mt] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, avoff[mt], so_a, 0));
+        const int so_b = 2 * ikc * Tin * 16;                     // (the tap goes into the per-lane offset: that one alone is range-checked and must not be negative)
+        const bool real = ich < nreal;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int t = tin0[e] + ii;
+            const int vo = (real && t >= 0 && t < Tin) ? (h * Tin + t) * 16 : H_OOB;
+            bb[e] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rX, vo, so_b, 0));
+        }
+        ++ich;
+        if (++ikc == NKC) { ikc = 0; ++ii; }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][e][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(ra[d], rb[d]);             // nchunks is a multiple of D (zero-padded weights)
+    for (int ch0 = 0; ch0 < nch; ch0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            h16x8 a[2] = {ra[d][0], ra[d][1]}, bb[2] = {rb[d][0], rb[d][1]};
+            if (ch0 + d + D < nch) issue(ra[d], rb[d]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bb[e], acc[mt][e], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: rows m0 + 32 mt + 8 j + 4 h + rr, times to0 + 32 e + q
+    const __amdgpu_buffer_rsrc_t rR = uniform_rsrc(p.resid ? reinterpret_cast<const h16*>(p.resid) + (size_t)b * Gm * Tout * 8 : reinterpret_cast<const h16*>(p.X),
+                                                   p.resid ? Gm * Tout * 16 : 0);
+    const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(p.Y ? reinterpret_cast<h16*>(p.Y) + (size_t)b * Gm * Tout * 8 : reinterpret_cast<const h16*>(p.X), p.Y ? Gm * Tout * 16 : 0);
+    const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(p.Yact ? reinterpret_cast<h16*>(p.Yact) + (size_t)b * Gm * Tout * 8 : reinterpret_cast<const h16*>(p.X),
+                                                   p.Yact ? Gm * Tout * 16 : 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mrow = m0 + 32 * mt + 8 * j + 4 * h;      // first of this lane's 4 rows
+            float bias[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) bias[rr] = (p.bias && mrow + rr < p.M) ? p.bias[mrow + rr] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int to = to0 + 32 * e + q;
+                const bool ok = to < Tout && mrow < p.M;
+                const int off = ok ? ((mrow >> 3) * Tout + to) * 16 + 8 * h : H_OOB;
+                float y[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) y[rr] = (acc[mt][e][4 * j + rr] + bias[rr]) * p.out_scale;
+                if (p.resid) {
+                    const h16x4 rv = __builtin_bit_cast(h16x4, __builtin_amdgcn_raw_buffer_load_b64(rR, off, 0, 0));
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) y[rr] += (float)rv[rr];
+                }
+                if (p.Y) {
+                    h16x4 v;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)y[rr];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rY, off, 0, 0);
+                }
+                if (p.Yact) {
+                    h16x4 v;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu1(y[rr] * p.act_scale);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rA, off, 0, 0);
+                }
+                if (p.Yf32 && to < Tout) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        if (mrow + rr < p.M) p.Yf32[((size_t)b * p.M + mrow + rr) * Tout + to] = y[rr];
+                }
+            }
+        }
+}
+
+// conv_pre (SConv1d 1 -> C, k taps, causal; modules/seanet.py:657-663) straight into the c8 layout: a thread owns one time step and
+// walks the channel groups (a wave's store of one group is 1 KB contiguous).
+__global__ __launch_bounds__(256) void conv_pre16_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         h16* __restrict__ Y, int C, int T, int ks, float in_scale) {
+    const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const float* xb = x + (size_t)b * T;
+    float xv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ti = t - (ks - 1) + i;
+        xv[i] = (i < ks && ti >= 0) ? xb[ti] * in_scale : 0.f;
+    }
+    const int G = C / 8;
+    for (int g = 0; g < G; ++g) {
+        h16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * g + j;
+            float y = bias ? bias[c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < ks) y = fmaf(w[c * ks + i], xv[i], y);
+            o[j] = (h16)y;
+        }
+        *reinterpret_cast<h16x8*>(Y + (((size_t)b * G + g) * T + t) * 8) = o;
+    }
+}
+
+// [B][C][T] f32 -> c8 f16 with Cp = roundup(C, 16) channels (rows past C are zero), optionally ELU(scale * x) on the way
+__global__ __launch_bounds__(256) void f32_to_c8_kernel(const float* __restrict__ X, h16* __restrict__ Y, int C, int Gp, int T, float scale, int elu) {
+    const int b = blockIdx.z, g = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    h16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = 8 * g + j;
+        float v = c < C ? X[((size_t)b * C + c) * T + t] * scale : 0.f;
+        if (elu) v = elu1(v);
+        o[j] = (h16)v;
+    }
+    *reinterpret_cast<h16x8*>(Y + (((size_t)b * Gp + g) * T + t) * 8) = o;
+}
+
+__global__ __launch_bounds__(256) void c8_to_f32_kernel(const h16* __restrict__ X, float* __restrict__ Y, int C, int Gp, int T) {
+    const int b = blockIdx.z, g = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const h16x8 v = *reinterpret_cast<const h16x8*>(X + (((size_t)b * Gp + g) * T + t) * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = 8 * g + j;
+        if (c < C) Y[((size_t)b * C + c) * T + t] = (float)v[j];
+    }
+}
+
+}  // namespace
+
+bool rh_supported(const RhArgs& a) {
+    if (!(a.C == 64 || a.C == 128 || a.C == 256 || a.C == 512)) return false;
+    if (!a.X || (!a.Y && !a.Yact) || a.T < 1 || a.B < 1 || !a.w1.wq || !a.w2.wq || !a.tab1 || !a.tab2) return false;
+    if (a.w1.M != a.C || a.w1.K != a.C || a.w2.M != a.C || a.w2.K != a.C || a.w1.Mp != a.C || a.w2.Mp != a.C || a.w1.Kp != a.C || a.w2.Kp != a.C) return false;
+    if ((long long)a.C * a.T * 2 >= H_OOB) return false;
+    return al16(a.X) && (!a.Y || al16(a.Y)) && (!a.Yact || al16(a.Yact)) && al16(a.w1.wq) && al16(a.w2.wq);
+}
+
+hipError_t launch_resblock16(const RhArgs& a, hipStream_t s) {
+    if (!rh_supported(a)) return hipErrorNotSupported;
+    switch (a.C) {
+        case 64: return rh_pick_out<RH<64, 2, 4, 2>>(a, s);      // 2 x 2 waves, 252-column windows (32 KB)
+        case 128: return rh_pick_out<RH<128, 1, 4, 2>>(a, s);    // 4 x 1 waves, 128-column windows (32 KB)
+        case 256: return rh_pick_out<RH<256, 1, 4, 2>>(a, s);    // 8 x 1 waves, 128-column windows (64 KB)
+        default: return rh_pick_out<RH<512, 1, 2, 4, 4, 1>>(a, s); // 16 x 1 waves, 64-column windows (64 KB)
+    }
+}
+
+hipError_t launch_conv16(const Conv16Args& a, hipStream_t s) {
+    if (!a.X || !a.w.wq || (!a.Y && !a.Yact && !a.Yf32) || a.B < 1 || a.M < 1 || a.Tin < 1 || a.Tout < 1 || a.ks < 1 || a.stride < 1) return hipErrorInvalidValue;
+    if (a.w.Kp % 16 || a.w.Mp % 32 || a.w.nchunks % 4 || a.w.nchunks < a.ks * (a.w.Kp / 16) || a.w.M != a.M) return hipErrorInvalidValue;
+    if ((long long)a.w.Kp * a.Tin * 2 >= H_OOB || (long long)round_up(a.M, 16) * a.Tout * 2 >= H_OOB || (long long)a.w.nchunks * a.w.Mp * 32 >= H_OOB)
+        return hipErrorInvalidValue;
+    if (!al16(a.X) || !al16(a.w.wq) || (a.Y && !al16(a.Y)) || (a.Yact && !al16(a.Yact)) || (a.resid && !al16(a.resid))) return hipErrorInvalidValue;
+    if ((a.Y || a.Yact || a.resid) && (a.M % 16)) return hipErrorInvalidValue;  // c8 outputs: whole 16-channel group pairs
+    const int wgm = a.M >= 256 ? 4 : (a.M >= 128 ? 2 : 1), wgn = 4 / wgm;
+    const int ncol = (a.Tout + 64 * wgn - 1) / (64 * wgn);
+    const long long gx = (long long)ncol * a.B;
+    if (gx > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)gx, (unsigned)((a.M + 64 * wgm - 1) / (64 * wgm)));
+    std::string name;
+    if (prof::enabled()) name = "conv16<k" + std::to_string(a.ks) + ",s" + std::to_string(a.stride) + "," + std::to_string(a.M) + "x" + std::to_string(a.w.K) + ">";
+    const double Bd = a.B, M = a.M;
+    prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * a.ks * (double)a.w.K * a.Tout,
+                   Bd * (2.0 * a.w.Kp * a.Tin + (a.resid ? 2.0 : 0.0) * M * a.Tout + (a.Y ? 2.0 : 0.0) * M * a.Tout + (a.Yact ? 2.0 : 0.0) * M * a.Tout +
+                         (a.Yf32 ? 4.0 : 0.0) * M * a.Tout));
+    if (wgm == 4) hipLaunchKernelGGL((conv16_kernel<4, 1>), grid, dim3(256), 0, s, a);
+    else if (wgm == 2) hipLaunchKernelGGL((conv16_kernel<2, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv16_kernel<1, 4>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_pre16(const float* x, const float* w, const float* bias, void* Y, int B, int C, int T, int ks, float in_scale, hipStream_t s) {
+    if (!x || !w || !Y || B < 1 || C < 8 || (C % 8) || T < 1 || ks < 1 || ks > 16 || B > 65535) return hipErrorInvalidValue;
+    prof::Scope ps(s, "conv_pre16", 2.0 * B * C * ks * (double)T, (double)B * T * (4.0 + 2.0 * C));
+    hipLaunchKernelGGL(conv_pre16_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, x, w, bias, reinterpret_cast<h16*>(Y), C, T, ks, in_scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_to_c8(const float* X, void* Y, int B, int C, int T, float scale, int elu, hipStream_t s) {
+    const int Gp = round_up(C, 16) / 8;
+    if (!X || !Y || B < 1 || B > 65535 || C < 1 || Gp > 65535 || T < 1) return hipErrorInvalidValue;
+    prof::Scope ps(s, "f32_to_c8", 0.0, (double)B * T * (4.0 * C + 16.0 * Gp));
+    hipLaunchKernelGGL(f32_to_c8_kernel, dim3((T + 255) / 256, Gp, B), dim3(256), 0, s, X, reinterpret_cast<h16*>(Y), C, Gp, T, scale, elu);
+    return hipGetLastError();
+}
+
+hipError_t launch_c8_to_f32(const void* X, float* Y, int B, int C, int T, hipStream_t s) {
+    const int Gp = round_up(C, 16) / 8;
+    if (!X || !Y || B < 1 || B > 65535 || C < 1 || Gp > 65535 || T < 1) return hipErrorInvalidValue;
+    prof::Scope ps(s, "c8_to_f32", 0.0, (double)B * T * (4.0 * C + 16.0 * Gp));
+    hipLaunchKernelGGL(c8_to_f32_kernel, dim3((T + 255) / 256, Gp, B), dim3(256), 0, s, reinterpret_cast<const h16*>(X), Y, C, Gp, T);
+    return hipGetLastError();
+}
+
+}  // namespace wv

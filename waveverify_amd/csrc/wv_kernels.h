@@ -92,6 +92,60 @@ inline std::vector<float> pack_ct_wt(const float* w, int K, int Kp, int ratio) {
     return t;
 }
 
+// ---- f16-operand / f32-accumulate detector mode (wv_h16.hip).  Activations: c8 layout f16 [B][roundup(C,16)/8][T][8] ----------------
+// Weights as A fragments of v_mfma_f32_32x32x16_f16: wq[chunk][Mp][2][8] f16, chunk = tap * (Kp/16) + k/16, element = W[m][tap][16*kc + 8*h + j];
+// Kp = roundup(K, 16), Mp = roundup(M, 32), the chunk count padded to a multiple of 4 with zero chunks.
+struct H16Weight { const void* wq = nullptr; int K = 0, M = 0, Kp = 0, Mp = 0, nchunks = 0; };
+inline uint16_t f32_to_f16_bits(float f) {                      // round to nearest even, overflow -> inf
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);    // rounds to >= 65520 -> inf
+    if (x < 0x38800000u) {                                      // subnormal half (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int e = (int)(x >> 23);
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;                              // 14 .. 24
+        const uint32_t half = m >> shift, rem = m & ((1u << shift) - 1), mid = 1u << (shift - 1);
+        return (uint16_t)(sign | (half + ((rem > mid || (rem == mid && (half & 1))) ? 1u : 0u)));
+    }
+    const uint32_t mant = x & 0x7fffffu, e = (x >> 23) - 112;
+    uint32_t hv = (e << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (hv & 1))) ++hv;
+    return (uint16_t)(sign | hv);
+}
+// host: 1x1 weight pw [M][K] (and, for the composed downsample conv, depth-wise taps dw [M][ks]: W[m][i][k] = dw[m][i] * pw[m][k]) -> A fragments
+inline std::vector<uint16_t> pack_h16(const float* pw, const float* dw, int M, int K, int ks, H16Weight* out) {
+    H16Weight w; w.K = K; w.M = M; w.Kp = round_up(K, 16); w.Mp = round_up(M, 32);
+    const int nkc = w.Kp / 16;
+    w.nchunks = round_up(ks * nkc, 4);
+    std::vector<uint16_t> q((size_t)w.nchunks * w.Mp * 16, 0);
+    for (int i = 0; i < ks; ++i)
+        for (int m = 0; m < M; ++m) {
+            const float t = dw ? dw[(size_t)m * ks + i] : 1.f;
+            for (int k = 0; k < K; ++k)
+                q[(((size_t)(i * nkc + k / 16) * w.Mp + m) * 2 + ((k >> 3) & 1)) * 8 + (k & 7)] = f32_to_f16_bits(pw[(size_t)m * K + k] * t);
+        }
+    *out = w;
+    return q;
+}
+struct RhArgs {               // whole ResnetBlock, c8 f16 in / out (C in {64, 128, 256, 512}, k = 5, dilation 1)
+    const void* X; float pre_scale; H16Weight w1, w2; const float* tab1; const float* tab2;   // tabs: pack_rb_table (f32)
+    void* Y; void* Yact; float out_scale, act_scale; int B, C, T; int num_t, ntiles;
+};
+bool rh_supported(const RhArgs& a);
+hipError_t launch_resblock16(const RhArgs& a, hipStream_t s);
+struct Conv16Args {           // y = out_scale * (bias + conv(x)) + resid; x, resid, Y, Yact c8 f16; Yf32 [B][M][Tout] f32 row-major
+    const void* X; H16Weight w; const float* bias; const void* resid; void* Y; void* Yact; float* Yf32;
+    float out_scale, act_scale; int B, M, Tin, Tout, ks, stride, pad;
+};
+hipError_t launch_conv16(const Conv16Args& a, hipStream_t s);
+hipError_t launch_conv_pre16(const float* x, const float* w, const float* bias, void* Y, int B, int C, int T, int ks, float in_scale, hipStream_t s);
+hipError_t launch_f32_to_c8(const float* X, void* Y, int B, int C, int T, float scale, int elu, hipStream_t s);
+hipError_t launch_c8_to_f32(const void* X, float* Y, int B, int C, int T, hipStream_t s);
+
 // ---- K2: (identity | DW conv) producer -> 1x1 GEMM -> epilogue --------------------------------
 struct DwPwArgs {
     const float* X;       // [B, K, Tin]

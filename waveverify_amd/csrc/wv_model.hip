@@ -84,6 +84,10 @@ struct wv_model {
     // ---- head plan
     const float *head_wc = nullptr, *head_bc = nullptr;
     int head_nb = 0;
+    // ---- f16 mode of the detector (wv_h16.hip): A-fragment weights per encoder stage -- the ResnetBlocks' 1x1 pairs, the SpecBlock's
+    // 1x1 over the zero-padded spectrum rows, the downsample unit's 1x1 and depth-wise conv composed into one [M][2r][K] conv
+    struct H16Stage { std::vector<std::pair<wv::H16Weight, wv::H16Weight>> blocks; wv::H16Weight spec, down; };
+    std::vector<H16Stage> h16;
 
     ~wv_model() { for (void* p : dev) (void)hipFree(p); }
 };
@@ -207,6 +211,20 @@ struct Uploader {
             return nullptr;
         }
         return static_cast<const float*>(d);
+    }
+    wv::H16Weight h16(const std::vector<float>& pw, const float* dw, int M, int K, int ks) {
+        wv::H16Weight w;
+        const std::vector<uint16_t> q = wv::pack_h16(pw.data(), dw, M, K, ks, &w);
+        if (err != WV_OK) return w;
+        void* d = nullptr;
+        if (hipMalloc(&d, q.size() * sizeof(uint16_t)) != hipSuccess) { err = fail(WV_EHIP, "hipMalloc failed while packing f16 weights"); return w; }
+        m->dev.push_back(d);
+        if (hipMemcpy(d, q.data(), q.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
+            err = fail(WV_EHIP, "hipMemcpy failed while packing f16 weights");
+            return w;
+        }
+        w.wq = d;
+        return w;
     }
     const std::vector<float>& host(const std::string& name) {
         static const std::vector<float> empty;
@@ -419,6 +437,25 @@ int pack_model(wv_model* m) {
         }
         m->head_wc = U.up(wc); m->head_bc = U.up(bc); m->head_nb = nb;
     }
+    // f16 mode: only for the detector, and only for layer shapes the f16 kernels cover (else wv_detector_forward_f16 reports WV_ESTATE)
+    bool h16_ok = c.kind == WV_KIND_DETECTOR && c.residual_kernel_size == 5 && c.dilation_base == 1 && c.kernel_size <= 16;
+    for (int s = 0, C = C0; s < S && h16_ok; ++s, C *= 2) h16_ok = C == 64 || C == 128 || C == 256 || C == 512;
+    if (h16_ok) {
+        int C = C0;
+        for (int s = 0; s < S && U.err == WV_OK; ++s, C *= 2) {
+            wv_model::H16Stage st;
+            for (int j = 0; j < c.n_residual_enc; ++j) {
+                const std::string pre = "encoder.blocks." + std::to_string(s) + "." + std::to_string(j);
+                st.blocks.emplace_back(U.h16(U.host(pre + ".block.1.conv.conv.weight"), nullptr, C, C, 1),
+                                       U.h16(U.host(pre + ".block.4.conv.conv.weight"), nullptr, C, C, 1));
+            }
+            const int F = m->specs[s].F, r = ratio_enc(c, s);
+            st.spec = U.h16(U.host("encoder.spec_blocks." + std::to_string(s) + ".layer.conv.conv.weight"), nullptr, C, F, 1);
+            const std::string dp = "encoder.downsample." + std::to_string(s);
+            st.down = U.h16(U.host(dp + ".2.conv.conv.weight"), U.host(dp + ".3.conv.conv.weight").data(), 2 * C, C, 2 * r);
+            m->h16.push_back(std::move(st));
+        }
+    }
     return U.err;
 }
 
@@ -557,8 +594,9 @@ Stream make_stream(char* ws, const WsLayout& L) {
 }
 
 // SEANetEncoder.forward (modules/seanet.py:883-976). Result in `latent` [B, dimension, Fr].
+// first_stage > 0: the stages before it ran elsewhere (the f16 mode); their raw output [B, C, Tl] is in the stream's buffer r[0].
 int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, float* latent, int B,
-                int T, char* ws, const WsLayout& L, hipStream_t st, int* Fr_out) {
+                int T, char* ws, const WsLayout& L, hipStream_t st, int* Fr_out, int first_stage = 0) {
     const wv_config& c = m->cfg;
     Stream sm = make_stream(ws, L);
     float* P = (float*)(ws + L.off_p);
@@ -568,14 +606,19 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
         int rc = run_film(m, msg, msg_rows, film, B, st);
         if (rc) return rc;
     }
-    wv::prof::set_role("enc.conv_pre");
-    sm.raw = sm.r[0];
-    sm.act = (m->enc_blocks[0].empty() || !wants_act_copy(c, c.channels_enc, T)) ? nullptr : sm.a[0];   // also ELU(c1 * y) for the first ResnetBlock
-    LAUNCH(wv::launch_conv_pre(x, m->pre_w, m->pre_b, sm.raw, sm.act, sm.act ? m->enc_blocks[0][0].pre_scale : 0.f,
-                               B, c.channels_enc, T, c.kernel_size, 1.f / c.wav_std, st));
     int Tl = T, C = c.channels_enc;
+    sm.raw = sm.r[0];
+    if (first_stage > 0) {
+        sm.act = nullptr;
+        for (int s = 0; s < first_stage; ++s) { Tl = (Tl + ratio_enc(c, s) - 1) / ratio_enc(c, s); C *= 2; }
+    } else {
+        wv::prof::set_role("enc.conv_pre");
+        sm.act = (m->enc_blocks[0].empty() || !wants_act_copy(c, c.channels_enc, T)) ? nullptr : sm.a[0];   // also ELU(c1 * y) for the first ResnetBlock
+        LAUNCH(wv::launch_conv_pre(x, m->pre_w, m->pre_b, sm.raw, sm.act, sm.act ? m->enc_blocks[0][0].pre_scale : 0.f,
+                                   B, c.channels_enc, T, c.kernel_size, 1.f / c.wav_std, st));
+    }
     const int film_stride = c.n_strides * c.freq_bands * 2;
-    for (int s = 0; s <= c.n_strides; ++s) {
+    for (int s = first_stage; s <= c.n_strides; ++s) {
         const bool post = s == c.n_strides;
         if (!post) {
             const std::vector<ResBlock>& blocks = m->enc_blocks[s];
@@ -890,8 +933,59 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
     return WV_OK;
 }
 
+// The encoder stages of the f16 mode (wv_h16.hip): conv_pre, then per stage 2 ResnetBlocks (one launch each), the SpecBlock (STFT
+// log-magnitude in f32 as in the exact path, its 1x1 + add on the f16 pipe) and the downsample unit (one composed conv).  The last
+// downsample writes f32 [B, C, Tl] into the stream buffer r[0], where run_encoder(first_stage = n_strides) picks up.
+static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, char* ws, const WsLayout& L, hipStream_t st) {
+    const wv_config& c = m->cfg;
+    const int S = c.n_strides;
+    void* R[2] = {ws + L.off_r0, ws + L.off_r1};
+    void* A0 = ws + L.off_a0;
+    float* P = (float*)(ws + L.off_p);
+    void* P16 = ws + L.off_u;
+    int cur = 0, Tl = T, C = c.channels_enc;
+    wv::prof::set_role("enc16.conv_pre");
+    LAUNCH(wv::launch_conv_pre16(x, m->pre_w, m->pre_b, R[0], B, C, T, c.kernel_size, 1.f / c.wav_std, st));
+    for (int s = 0; s < S; ++s) {
+        const wv_model::H16Stage& hs = m->h16[s];
+        wv::prof::set_role("enc16.resblock");
+        for (size_t j = 0; j < m->enc_blocks[s].size(); ++j) {
+            const ResBlock& r = m->enc_blocks[s][j];
+            wv::RhArgs a{};
+            a.X = R[cur]; a.pre_scale = r.pre_scale; a.w1 = hs.blocks[j].first; a.w2 = hs.blocks[j].second; a.tab1 = r.tab1; a.tab2 = r.tab2;
+            a.Y = R[cur ^ 1]; a.Yact = nullptr; a.out_scale = r.out_scale; a.act_scale = 0.f; a.B = B; a.C = C; a.T = Tl;
+            const hipError_t e = wv::launch_resblock16(a, st);
+            if (e != hipSuccess) return fail(e == hipErrorNotSupported ? WV_ESTATE : WV_EHIP, std::string("launch_resblock16: ") + hipGetErrorString(e));
+            cur ^= 1;
+        }
+        wv::prof::set_role("enc16.spec");
+        const SpecLayer& sp = m->specs[s];
+        wv::StftArgs sa{};
+        sa.wav = x; sa.basis_t = sp.basis_t; sa.basis_q = sp.basis_q; sa.side = sp.side; sa.P = P; sa.B = B; sa.T = T;
+        sa.Tf = (T + sp.hop - 1) / sp.hop; sa.n_fft = sp.n_fft; sa.hop = sp.hop; sa.F = sp.F; sa.Mp = sp.Mp;
+        sa.mean = sp.mean; sa.inv_std = sp.inv_std;
+        if (sa.Tf != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");
+        LAUNCH(wv::launch_stft_logmag(sa, st));
+        LAUNCH(wv::launch_f32_to_c8(P, P16, B, sp.F, Tl, 1.f, 0, st));
+        const DownLayer& d = m->downs[s];
+        wv::Conv16Args q{};                                       // x' = x + scale * (W @ P); only ELU(c * x') is consumed
+        q.X = P16; q.w = hs.spec; q.bias = nullptr; q.resid = R[cur]; q.Y = nullptr; q.Yact = A0; q.Yf32 = nullptr;
+        q.out_scale = sp.scale; q.act_scale = d.pre_scale; q.B = B; q.M = C; q.Tin = Tl; q.Tout = Tl; q.ks = 1; q.stride = 1; q.pad = 0;
+        LAUNCH(wv::launch_conv16(q, st));
+        wv::prof::set_role("enc16.down");
+        const bool last = s + 1 == S;
+        wv::Conv16Args g{};
+        g.X = A0; g.w = hs.down; g.bias = d.dw_b; g.resid = nullptr; g.Y = last ? nullptr : R[cur ^ 1]; g.Yact = nullptr;
+        g.Yf32 = last ? (float*)R[0] : nullptr; g.out_scale = 1.f; g.act_scale = 0.f;
+        g.B = B; g.M = 2 * C; g.Tin = Tl; g.Tout = (Tl + d.ratio - 1) / d.ratio; g.ks = 2 * d.ratio; g.stride = d.ratio; g.pad = d.ratio;
+        LAUNCH(wv::launch_conv16(g, st));
+        cur ^= 1; Tl = g.Tout; C *= 2;
+    }
+    return WV_OK;
+}
+
 static int run_head_model(wv_model* m, const float* x, float* logits, float* mean_prob, int B, int T,
-                          void* ws, size_t ws_bytes, void* stream) {
+                          void* ws, size_t ws_bytes, void* stream, bool f16 = false) {
     WsLayout L;
     int rc = check_common(m, B, T, ws, ws_bytes, &L);
     if (rc) return rc;
@@ -900,7 +994,12 @@ static int run_head_model(wv_model* m, const float* x, float* logits, float* mea
     char* w = (char*)ws;
     float* latent = (float*)(w + L.off_lat);
     int Fr = 0;
-    rc = run_encoder(m, x, nullptr, 0, latent, B, T, w, L, st, &Fr);
+    if (f16) {
+        if (m->h16.empty()) return fail(WV_ESTATE, "this model has no f16 plan (detector with 64/128/256/512-channel stages, k = 5, dilation 1)");
+        rc = run_encoder_stages_f16(m, x, B, T, w, L, st);
+        if (rc) return rc;
+    }
+    rc = run_encoder(m, x, nullptr, 0, latent, B, T, w, L, st, &Fr, f16 ? m->cfg.n_strides : 0);
     if (rc) return rc;
     wv::prof::set_role("head");
     wv::HeadArgs h{};
@@ -914,6 +1013,12 @@ int wv_detector_forward(wv_model* m, const float* x, float* logits, float* mean_
                         void* ws, size_t ws_bytes, void* stream) {
     if (m && m->cfg.kind != WV_KIND_DETECTOR) return fail(WV_ESTATE, "not a detector model");
     return run_head_model(m, x, logits, mean_prob, B, T, ws, ws_bytes, stream);
+}
+
+int wv_detector_forward_f16(wv_model* m, const float* x, float* logits, float* mean_prob, int B, int T,
+                            void* ws, size_t ws_bytes, void* stream) {
+    if (m && m->cfg.kind != WV_KIND_DETECTOR) return fail(WV_ESTATE, "not a detector model");
+    return run_head_model(m, x, logits, mean_prob, B, T, ws, ws_bytes, stream, true);
 }
 
 int wv_locator_forward(wv_model* m, const float* x, float* logits, int B, int T, void* ws,

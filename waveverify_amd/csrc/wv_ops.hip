@@ -28,6 +28,20 @@ struct Tmp {                       // scoped device uploads
         return (const float*)p;
     }
     const float* upv(const std::vector<float>& v) { return up(v.data(), v.size()); }
+    const void* upb(const void* h, size_t bytes) {
+        if (!h || !ok) return nullptr;
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) { ok = false; return nullptr; }
+        d.push_back(p);
+        if (bytes && hipMemcpy(p, h, bytes, hipMemcpyHostToDevice) != hipSuccess) { ok = false; return nullptr; }
+        return p;
+    }
+    wv::H16Weight h16(const float* pw, const float* dw, int M, int K, int ks) {
+        wv::H16Weight w;
+        const std::vector<uint16_t> q = wv::pack_h16(pw, dw, M, K, ks, &w);
+        w.wq = upb(q.data(), q.size() * sizeof(uint16_t));
+        return w;
+    }
     wv::PwWeight pw(const float* w, int M, int K) {
         wv::PwWeight p; p.M = M; p.K = K; p.Kp = wv::round_up(K, wv::BK); p.Mp = wv::round_up(M, wv::M_ALIGN);
         std::vector<float> t((size_t)p.Kp * p.Mp, 0.f);
@@ -82,6 +96,43 @@ int wv_op_resblock(const float* X, float pre_scale, const float* w_pw1, const fl
     const hipError_t e = wv::launch_resblock(a, (hipStream_t)stream);
     if (e == hipErrorNotSupported) return WV_EINVAL;
     return done(t, e, (hipStream_t)stream);
+}
+
+// ---- the f16 mode's units (wv_h16.hip): activations in the c8 f16 layout, weights as HOST f32 pointers in the reference's layouts
+int wv_h16_from_f32(const float* X, void* Y16, int B, int C, int T, float scale, int elu, void* stream) {
+    Tmp t;
+    return done(t, wv::launch_f32_to_c8(X, Y16, B, C, T, scale, elu, (hipStream_t)stream), (hipStream_t)stream);
+}
+int wv_h16_to_f32(const void* X16, float* Y, int B, int C, int T, void* stream) {
+    Tmp t;
+    return done(t, wv::launch_c8_to_f32(X16, Y, B, C, T, (hipStream_t)stream), (hipStream_t)stream);
+}
+int wv_h16_conv_pre(const float* x, const float* w, const float* bias, void* Y16, int B, int C, int T, int ks, float in_scale, void* stream) {
+    if (!x || !w || !Y16 || C < 1 || ks < 1) return WV_EINVAL;
+    Tmp t;
+    return done(t, wv::launch_conv_pre16(x, t.up(w, (size_t)C * ks), t.up(bias, C), Y16, B, C, T, ks, in_scale, (hipStream_t)stream), (hipStream_t)stream);
+}
+int wv_h16_resblock(const void* X16, float pre_scale, const float* w_pw1, const float* w_dw1, const float* b1, const float* w_pw2, const float* w_dw2,
+                    const float* b2, void* Y16, void* Yact16, int B, int C, int T, float out_scale, float act_scale, void* stream) {
+    if (!X16 || !w_pw1 || !w_dw1 || !w_pw2 || !w_dw2 || (!Y16 && !Yact16) || B < 1 || C < 1 || T < 1) return WV_EINVAL;
+    Tmp t;
+    wv::RhArgs a{};
+    a.X = X16; a.pre_scale = pre_scale; a.w1 = t.h16(w_pw1, nullptr, C, C, 1); a.w2 = t.h16(w_pw2, nullptr, C, C, 1);
+    a.tab1 = t.upv(wv::pack_rb_table(w_dw1, b1, C)); a.tab2 = t.upv(wv::pack_rb_table(w_dw2, b2, C));
+    a.Y = Y16; a.Yact = Yact16; a.out_scale = out_scale; a.act_scale = act_scale; a.B = B; a.C = C; a.T = T;
+    const hipError_t e = wv::launch_resblock16(a, (hipStream_t)stream);
+    if (e == hipErrorNotSupported) return WV_EINVAL;
+    return done(t, e, (hipStream_t)stream);
+}
+int wv_h16_conv(const void* X16, const float* w_pw, const float* w_dw, const float* bias, const void* resid16, void* Y16, void* Yact16, float* Yf32,
+                int B, int K, int M, int Tin, int ks, int stride, int pad, float out_scale, float act_scale, void* stream) {
+    if (!X16 || !w_pw || B < 1 || K < 1 || M < 1 || Tin < 1 || ks < 1 || stride < 1 || pad < 0) return WV_EINVAL;
+    Tmp t;
+    wv::Conv16Args a{};
+    a.X = X16; a.w = t.h16(w_pw, w_dw, M, K, ks); a.bias = t.up(bias, M); a.resid = resid16; a.Y = Y16; a.Yact = Yact16; a.Yf32 = Yf32;
+    a.out_scale = out_scale; a.act_scale = act_scale; a.B = B; a.M = M; a.Tin = Tin; a.Tout = (Tin + stride - 1) / stride;
+    a.ks = ks; a.stride = stride; a.pad = pad;
+    return done(t, wv::launch_conv16(a, (hipStream_t)stream), (hipStream_t)stream);
 }
 
 int wv_op_dw_pw(const float* X, const float* w_dw, const float* w_pw, const float* bias, float* Y,

@@ -173,7 +173,7 @@ class HipNet:
                 "wv_generator_forward")
         return out
 
-    def _head(self, x, want_logits: bool, want_mean: bool):
+    def _head(self, x, want_logits: bool, want_mean: bool, precision: str = "f32"):
         x = self._prep(x)
         B, _, T = x.shape
         nb = self.cfg.head_bits
@@ -181,11 +181,16 @@ class HipNet:
         mean = torch.empty((B, nb), dtype=torch.float32, device=self.device) if want_mean else None
         with torch.cuda.device(self.device):
             ws = self._workspace(B, T)
+            if precision not in ("f32", "f16"):
+                raise ValueError("precision must be 'f32' or 'f16'")
+            if precision == "f16" and self.cfg.kind != "detector":
+                raise RuntimeError("the f16 mode exists for the detector only")
             if self.cfg.kind == "detector":
-                _lib.check(self._lib.wv_detector_forward(
+                fn = self._lib.wv_detector_forward_f16 if precision == "f16" else self._lib.wv_detector_forward
+                _lib.check(fn(
                     self._h, x.data_ptr(), logits.data_ptr() if want_logits else None,
                     mean.data_ptr() if want_mean else None, B, T, ws.data_ptr(), ws.numel(),
-                    self._stream()), "wv_detector_forward")
+                    self._stream()), "wv_detector_forward" + ("_f16" if precision == "f16" else ""))
             elif self.cfg.kind == "locator":
                 _lib.check(self._lib.wv_locator_forward(
                     self._h, x.data_ptr(), logits.data_ptr(), B, T, ws.data_ptr(), ws.numel(),
@@ -194,15 +199,15 @@ class HipNet:
                 raise RuntimeError("generator has no detection head")
         return logits, mean
 
-    def detector(self, x: torch.Tensor) -> torch.Tensor:
-        """Detector.forward: logits [B, nbits, T]."""
-        return self._head(x, True, False)[0]
+    def detector(self, x: torch.Tensor, precision: str = "f32") -> torch.Tensor:
+        """Detector.forward: logits [B, nbits, T].  precision="f16": the f16-operand / f32-accumulate throughput mode (csrc/wv_h16.hip)."""
+        return self._head(x, True, False, precision)[0]
 
-    def detector_mean_prob(self, x: torch.Tensor) -> torch.Tensor:
+    def detector_mean_prob(self, x: torch.Tensor, precision: str = "f32") -> torch.Tensor:
         """mean_t sigmoid(logits) [B, nbits] without materialising the logits (core.py:577-580)."""
         if self.cfg.kind != "detector":
             raise RuntimeError("not a detector")
-        return self._head(x, False, True)[1]
+        return self._head(x, False, True, precision)[1]
 
     def locator(self, x: torch.Tensor) -> torch.Tensor:
         """Locator.forward: logits [B, 1, T]."""

@@ -169,3 +169,87 @@ def head(Z, w_rev, b_rev, w_last, b_last, T, want_logits=True, want_mean=True):
     _lib.check(lib.wv_op_head(Z.data_ptr(), _hp(w_rev), _hp(b_rev), _hp(w_last), _hp(b_last),
                               _dp(logits), _dp(mean), B, D, O, nb, hop, Fr, T, _stream()), "wv_op_head")
     return logits, mean
+
+
+# ---- the f16 mode's units (csrc/wv_h16.hip).  A "c8" tensor is torch.float16 [B, roundup(C,16)/8, T, 8] --------------------------
+def _c8(t: torch.Tensor) -> torch.Tensor:
+    if not (t.is_cuda and t.dtype == torch.float16 and t.dim() == 4 and t.shape[-1] == 8 and t.is_contiguous()):
+        raise RuntimeError("expected a contiguous CUDA float16 tensor [B, C/8, T, 8]")
+    return t
+
+
+def h16_from_f32(X, scale: float = 1.0, elu: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    X = _dev(X)
+    B, Cc, T = X.shape
+    Y = torch.empty((B, (Cc + 15) // 16 * 2, T, 8), dtype=torch.float16, device=X.device)
+    _lib.check(lib.wv_h16_from_f32(X.data_ptr(), Y.data_ptr(), B, Cc, T, float(scale), int(elu), _stream()), "wv_h16_from_f32")
+    return Y
+
+
+def h16_to_f32(X16, channels: int) -> torch.Tensor:
+    lib = _lib.load()
+    X16 = _c8(X16)
+    B, G, T, _ = X16.shape
+    if (channels + 15) // 16 * 2 != G:
+        raise ValueError("channel count does not match the tensor's groups")
+    Y = torch.empty((B, channels, T), dtype=torch.float32, device=X16.device)
+    _lib.check(lib.wv_h16_to_f32(X16.data_ptr(), Y.data_ptr(), B, channels, T, _stream()), "wv_h16_to_f32")
+    return Y
+
+
+def h16_conv_pre(x, w, bias, in_scale: float = 1.0) -> torch.Tensor:
+    lib = _lib.load()
+    x = _dev(x)
+    B, _, T = x.shape
+    w, bias = _w(w), _w(bias)
+    Cc, ks = w.shape[0], w.shape[-1]
+    Y = torch.empty((B, Cc // 8, T, 8), dtype=torch.float16, device=x.device)
+    _lib.check(lib.wv_h16_conv_pre(x.data_ptr(), _hp(w.reshape(Cc, ks)), _hp(bias), Y.data_ptr(), B, Cc, T, ks, float(in_scale), _stream()),
+               "wv_h16_conv_pre")
+    return Y
+
+
+def h16_resblock(X16, w_pw1, w_dw1, b1, w_pw2, w_dw2, b2, pre_scale=1.0, out_scale=1.0, act_scale: Optional[float] = None,
+                 want_raw: bool = True):
+    lib = _lib.load()
+    X16 = _c8(X16)
+    B, G, T, _ = X16.shape
+    Cc = 8 * G
+    ws = [_w(w_pw1).reshape(Cc, Cc), _w(w_dw1).reshape(Cc, -1), _w(b1), _w(w_pw2).reshape(Cc, Cc), _w(w_dw2).reshape(Cc, -1), _w(b2)]
+    Y = torch.empty_like(X16) if want_raw else None
+    Yact = torch.empty_like(X16) if act_scale is not None else None
+    _lib.check(lib.wv_h16_resblock(X16.data_ptr(), float(pre_scale), *[_hp(w) for w in ws], _dp(Y), _dp(Yact), B, Cc, T, float(out_scale),
+                                   float(act_scale or 0.0), _stream()), "wv_h16_resblock")
+    if Y is None:
+        return Yact
+    return Y if act_scale is None else (Y, Yact)
+
+
+def h16_conv(X16, w_pw, w_dw=None, bias=None, resid16=None, K: Optional[int] = None, ks=1, stride=1, pad=0, out_scale=1.0,
+             act_scale: Optional[float] = None, want_raw: bool = True, want_f32: bool = False):
+    """y = out_scale * (bias + conv(x)) + resid.  -> dict with the requested outputs: "raw" (c8 f16), "act" (c8 f16), "f32" ([B,M,Tout])."""
+    lib = _lib.load()
+    X16 = _c8(X16)
+    B, G, Tin, _ = X16.shape
+    w_pw, w_dw, bias = _w(w_pw), _w(w_dw), _w(bias)
+    M = w_pw.shape[0]
+    K = int(K if K is not None else w_pw.reshape(M, -1).shape[1])
+    if (K + 15) // 16 * 2 != G:
+        raise ValueError("weight columns do not match the tensor's channel groups")
+    w_pw = w_pw.reshape(M, K)
+    Tout = (Tin + stride - 1) // stride
+    Gm = (M + 15) // 16 * 2
+    out = {}
+    if want_raw:
+        out["raw"] = torch.empty((B, Gm, Tout, 8), dtype=torch.float16, device=X16.device)
+    if act_scale is not None:
+        out["act"] = torch.empty((B, Gm, Tout, 8), dtype=torch.float16, device=X16.device)
+    if want_f32:
+        out["f32"] = torch.empty((B, M, Tout), dtype=torch.float32, device=X16.device)
+    if resid16 is not None:
+        _c8(resid16)
+    _lib.check(lib.wv_h16_conv(X16.data_ptr(), _hp(w_pw), _hp(None if w_dw is None else w_dw.reshape(M, ks)), _hp(bias), _dp(resid16),
+                               _dp(out.get("raw")), _dp(out.get("act")), _dp(out.get("f32")), B, K, M, Tin, ks, stride, pad, float(out_scale),
+                               float(act_scale or 0.0), _stream()), "wv_h16_conv")
+    return out
