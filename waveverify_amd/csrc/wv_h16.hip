@@ -385,30 +385,54 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // ------------------------------------------------------------------------------------------------------------------------------
 // Dense causal Conv1d on c8 activations as an implicit GEMM, operands straight from global memory:
 //     y[m][to] = out_scale * ( bias[m] + sum_{i < ks} sum_k W[m][i][k] * x[k][to * stride + i - pad] ) + resid[m][to]
-// (x = 0 outside [0, Tin)).  Chunk ch = (tap i, 16 channels kc): A fragment = wq16[ch][m][h][8], B fragment = the 16-byte piece
+// (x = 0 outside [0, Tin)).  Chunk ch = kc * ks + i (16 channels kc, tap i): A fragment = wq16[ch][m][h][8], B fragment = the 16-byte piece
 // (group 2 kc + h, time to * stride + i - pad) of x.  A wave owns 64 rows x 64 output times (2 x 2 MFMA tiles); the four waves of a
 // workgroup share either the columns (WGM = 4: the B pieces of one wave are L1 hits for the other three) or the rows.  Loads run
 // D chunks ahead of their MFMAs in a register ring; there is no LDS and no barrier.
-template <int WGM, int WGN>
+// FLAT: the columns of all clips in one run (column n = clip n / Tout, time n % Tout) -- layers with few outputs per clip (50 frames
+// after the last downsample) would otherwise leave most of a 64-column wave tile and of the workgroup idle; offsets then span the whole
+// tensor (the launcher checks they fit the sentinel), and the workgroups are dealt so that one XCD keeps the same row blocks of W in
+// its L2 while x streams past.
+template <int WGM, int WGN, bool FLAT>
 __global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
     constexpr int D = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WGM, wn = wave / WGM;
     const int h = lane >> 5, q = lane & 31;
-    const int ncol = (p.Tout + 64 * WGN - 1) / (64 * WGN);
-    const int b = blockIdx.x / ncol, ct = blockIdx.x - b * ncol;
-    const int m0 = (blockIdx.y * WGM + wm) * 64;
-    const int to0 = (ct * WGN + wn) * 64;
-    if (m0 >= p.M || to0 >= p.Tout) return;
     const int Tin = p.Tin, Tout = p.Tout, Gk = p.w.Kp / 8, Gm = (p.M + 15) / 16 * 2, Mp = p.w.Mp, NKC = p.w.Kp / 16, nch = p.w.nchunks;
-    const __amdgpu_buffer_rsrc_t rX = uniform_rsrc(reinterpret_cast<const h16*>(p.X) + (size_t)b * Gk * Tin * 8, Gk * Tin * 16);
+    int bclip = 0, m0, n0;                                       // per-clip mode: the clip, first row, first time; flat: first row, first flat column
+    if constexpr (FLAT) {
+        const int num_m = (p.M + 64 * WGM - 1) / (64 * WGM);
+        const unsigned L = blockIdx.x;
+        unsigned mb, cb;
+        if (num_m % 8 == 0) { const unsigned xcd = L & 7, j = L >> 3, per = num_m / 8; mb = xcd + 8 * (j % per); cb = j / per; }
+        else { mb = L % num_m; cb = L / num_m; }
+        m0 = (mb * WGM + wm) * 64;
+        n0 = (cb * WGN + wn) * 64;
+        if (m0 >= p.M || n0 >= p.B * Tout) return;
+    } else {
+        const int ncol = (Tout + 64 * WGN - 1) / (64 * WGN);
+        bclip = blockIdx.x / ncol;
+        const int ct = blockIdx.x - bclip * ncol;
+        m0 = (blockIdx.y * WGM + wm) * 64;
+        n0 = (ct * WGN + wn) * 64;
+        if (m0 >= p.M || n0 >= Tout) return;
+    }
+    const size_t xclip = (size_t)Gk * Tin * 8, yclip = (size_t)Gm * Tout * 8;      // halves per clip
+    const __amdgpu_buffer_rsrc_t rX = FLAT ? uniform_rsrc(p.X, (int)(xclip * 2 * p.B)) : uniform_rsrc(reinterpret_cast<const h16*>(p.X) + bclip * xclip, (int)(xclip * 2));
     const __amdgpu_buffer_rsrc_t rW = uniform_rsrc(p.w.wq, nch * Mp * 32);
-    int avoff[2], tin0[2];
+    int avoff[2], tin0[2], xb[2], cb_[2], to_[2];
+    bool colok[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) avoff[mt] = (m0 + 32 * mt + q < Mp) ? ((m0 + 32 * mt + q) * 2 + h) * 16 : H_OOB;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) tin0[e] = (to0 + 32 * e + q) * p.stride - p.pad;
+    for (int e = 0; e < 2; ++e) {
+        const int n = n0 + 32 * e + q;
+        if constexpr (FLAT) { cb_[e] = n / Tout; to_[e] = n - cb_[e] * Tout; colok[e] = n < p.B * Tout; xb[e] = cb_[e] * (int)(xclip * 2); }
+        else { cb_[e] = bclip; to_[e] = n; colok[e] = n < Tout; xb[e] = 0; }
+        tin0[e] = to_[e] * p.stride - p.pad;
+    }
     const int nreal = p.ks * NKC;
 
     h16x8 ra[D][2], rb[D][2];
@@ -422,11 +446,11 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int t = tin0[e] + ii;
-            const int vo = (real && t >= 0 && t < Tin) ? (h * Tin + t) * 16 : H_OOB;
+            const int vo = (real && colok[e] && t >= 0 && t < Tin) ? xb[e] + (h * Tin + t) * 16 : H_OOB;
             bb[e] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rX, vo, so_b, 0));
         }
         ++ich;
-        if (++ikc == NKC) { ikc = 0; ++ii; }
+        if (++ii == p.ks) { ii = 0; ++ikc; }                     // taps innermost: a lane's ks pieces of one channel group are contiguous (stride 1) or share cache lines
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -448,12 +472,12 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
                 for (int e = 0; e < 2; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bb[e], acc[mt][e], 0, 0, 0);
         }
     }
-    // ---- epilogue: rows m0 + 32 mt + 8 j + 4 h + rr, times to0 + 32 e + q
-    const __amdgpu_buffer_rsrc_t rR = uniform_rsrc(p.resid ? reinterpret_cast<const h16*>(p.resid) + (size_t)b * Gm * Tout * 8 : reinterpret_cast<const h16*>(p.X),
-                                                   p.resid ? Gm * Tout * 16 : 0);
-    const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(p.Y ? reinterpret_cast<h16*>(p.Y) + (size_t)b * Gm * Tout * 8 : reinterpret_cast<const h16*>(p.X), p.Y ? Gm * Tout * 16 : 0);
-    const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(p.Yact ? reinterpret_cast<h16*>(p.Yact) + (size_t)b * Gm * Tout * 8 : reinterpret_cast<const h16*>(p.X),
-                                                   p.Yact ? Gm * Tout * 16 : 0);
+    // ---- epilogue: rows m0 + 32 mt + 8 j + 4 h + rr, columns n0 + 32 e + q
+    const int ybytes = FLAT ? (int)(yclip * 2 * p.B) : (int)(yclip * 2);
+    const size_t ybase = FLAT ? 0 : bclip * yclip;
+    const __amdgpu_buffer_rsrc_t rR = uniform_rsrc(p.resid ? reinterpret_cast<const h16*>(p.resid) + ybase : reinterpret_cast<const h16*>(p.X), p.resid ? ybytes : 0);
+    const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(p.Y ? reinterpret_cast<h16*>(p.Y) + ybase : reinterpret_cast<const h16*>(p.X), p.Y ? ybytes : 0);
+    const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(p.Yact ? reinterpret_cast<h16*>(p.Yact) + ybase : reinterpret_cast<const h16*>(p.X), p.Yact ? ybytes : 0);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -464,9 +488,9 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
             for (int rr = 0; rr < 4; ++rr) bias[rr] = (p.bias && mrow + rr < p.M) ? p.bias[mrow + rr] : 0.f;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int to = to0 + 32 * e + q;
-                const bool ok = to < Tout && mrow < p.M;
-                const int off = ok ? ((mrow >> 3) * Tout + to) * 16 + 8 * h : H_OOB;
+                const int to = to_[e];
+                const bool ok = colok[e] && mrow < p.M;
+                const int off = ok ? (FLAT ? cb_[e] * (int)(yclip * 2) : 0) + ((mrow >> 3) * Tout + to) * 16 + 8 * h : H_OOB;
                 float y[4];
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) y[rr] = (acc[mt][e][4 * j + rr] + bias[rr]) * p.out_scale;
@@ -487,10 +511,10 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
                     for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu1(y[rr] * p.act_scale);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rA, off, 0, 0);
                 }
-                if (p.Yf32 && to < Tout) {
+                if (p.Yf32 && colok[e]) {
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
-                        if (mrow + rr < p.M) p.Yf32[((size_t)b * p.M + mrow + rr) * Tout + to] = y[rr];
+                        if (mrow + rr < p.M) p.Yf32[((size_t)cb_[e] * p.M + mrow + rr) * Tout + to] = y[rr];
                 }
             }
         }
@@ -578,20 +602,34 @@ hipError_t launch_conv16(const Conv16Args& a, hipStream_t s) {
         return hipErrorInvalidValue;
     if (!al16(a.X) || !al16(a.w.wq) || (a.Y && !al16(a.Y)) || (a.Yact && !al16(a.Yact)) || (a.resid && !al16(a.resid))) return hipErrorInvalidValue;
     if ((a.Y || a.Yact || a.resid) && (a.M % 16)) return hipErrorInvalidValue;  // c8 outputs: whole 16-channel group pairs
+    // few outputs per clip: the clips' columns as one run (flat), four waves side by side on the same rows of W (its fragments are L1 hits
+    // for three of them); else per-clip column tiles with the waves stacked over the rows
+    const long long xbytes = (long long)a.w.Kp * a.Tin * 2 * a.B, ybytes = (long long)round_up(a.M, 16) * a.Tout * 2 * a.B;
+    const bool flat = a.Tout < 512 && xbytes < H_OOB && ybytes < H_OOB;
+    std::string name;
+    if (prof::enabled())
+        name = "conv16<k" + std::to_string(a.ks) + ",s" + std::to_string(a.stride) + "," + std::to_string(a.M) + "x" + std::to_string(a.w.K) + (flat ? ",flat>" : ">");
+    const double Bd = a.B, M = a.M;
+    prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * a.ks * (double)a.w.K * a.Tout,
+                   Bd * (2.0 * a.w.Kp * a.Tin + (a.resid ? 2.0 : 0.0) * M * a.Tout + (a.Y ? 2.0 : 0.0) * M * a.Tout + (a.Yact ? 2.0 : 0.0) * M * a.Tout +
+                         (a.Yf32 ? 4.0 : 0.0) * M * a.Tout));
+    if (flat) {
+        const int wgm = a.M >= 512 ? 1 : (a.M >= 128 ? 2 : 1), wgn = 4 / wgm;
+        const long long ncb = ((long long)a.B * a.Tout + 64 * wgn - 1) / (64 * wgn), nmb = (a.M + 64 * wgm - 1) / (64 * wgm);
+        if (ncb * nmb > 0x7fffffffLL) return hipErrorInvalidValue;
+        dim3 grid((unsigned)(ncb * nmb));
+        if (wgm == 1) hipLaunchKernelGGL((conv16_kernel<1, 4, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv16_kernel<2, 2, true>), grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     const int wgm = a.M >= 256 ? 4 : (a.M >= 128 ? 2 : 1), wgn = 4 / wgm;
     const int ncol = (a.Tout + 64 * wgn - 1) / (64 * wgn);
     const long long gx = (long long)ncol * a.B;
     if (gx > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)gx, (unsigned)((a.M + 64 * wgm - 1) / (64 * wgm)));
-    std::string name;
-    if (prof::enabled()) name = "conv16<k" + std::to_string(a.ks) + ",s" + std::to_string(a.stride) + "," + std::to_string(a.M) + "x" + std::to_string(a.w.K) + ">";
-    const double Bd = a.B, M = a.M;
-    prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * a.ks * (double)a.w.K * a.Tout,
-                   Bd * (2.0 * a.w.Kp * a.Tin + (a.resid ? 2.0 : 0.0) * M * a.Tout + (a.Y ? 2.0 : 0.0) * M * a.Tout + (a.Yact ? 2.0 : 0.0) * M * a.Tout +
-                         (a.Yf32 ? 4.0 : 0.0) * M * a.Tout));
-    if (wgm == 4) hipLaunchKernelGGL((conv16_kernel<4, 1>), grid, dim3(256), 0, s, a);
-    else if (wgm == 2) hipLaunchKernelGGL((conv16_kernel<2, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv16_kernel<1, 4>), grid, dim3(256), 0, s, a);
+    if (wgm == 4) hipLaunchKernelGGL((conv16_kernel<4, 1, false>), grid, dim3(256), 0, s, a);
+    else if (wgm == 2) hipLaunchKernelGGL((conv16_kernel<2, 2, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv16_kernel<1, 4, false>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

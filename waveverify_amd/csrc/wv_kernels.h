@@ -93,7 +93,7 @@ inline std::vector<float> pack_ct_wt(const float* w, int K, int Kp, int ratio) {
 }
 
 // ---- f16-operand / f32-accumulate detector mode (wv_h16.hip).  Activations: c8 layout f16 [B][roundup(C,16)/8][T][8] ----------------
-// Weights as A fragments of v_mfma_f32_32x32x16_f16: wq[chunk][Mp][2][8] f16, chunk = tap * (Kp/16) + k/16, element = W[m][tap][16*kc + 8*h + j];
+// Weights as A fragments of v_mfma_f32_32x32x16_f16: wq[chunk][Mp][2][8] f16, chunk = (k/16) * taps + tap, element = W[m][tap][16*kc + 8*h + j];
 // Kp = roundup(K, 16), Mp = roundup(M, 32), the chunk count padded to a multiple of 4 with zero chunks.
 struct H16Weight { const void* wq = nullptr; int K = 0, M = 0, Kp = 0, Mp = 0, nchunks = 0; };
 inline uint16_t f32_to_f16_bits(float f) {                      // round to nearest even, overflow -> inf
@@ -126,7 +126,7 @@ inline std::vector<uint16_t> pack_h16(const float* pw, const float* dw, int M, i
         for (int m = 0; m < M; ++m) {
             const float t = dw ? dw[(size_t)m * ks + i] : 1.f;
             for (int k = 0; k < K; ++k)
-                q[(((size_t)(i * nkc + k / 16) * w.Mp + m) * 2 + ((k >> 3) & 1)) * 8 + (k & 7)] = f32_to_f16_bits(pw[(size_t)m * K + k] * t);
+                q[(((size_t)((k / 16) * ks + i) * w.Mp + m) * 2 + ((k >> 3) & 1)) * 8 + (k & 7)] = f32_to_f16_bits(pw[(size_t)m * K + k] * t);
         }
     *out = w;
     return q;
