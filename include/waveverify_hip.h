@@ -202,6 +202,9 @@ int wv_op_spec_block(const float* wav, const float* basis_or_null, const float* 
  *                     x = 0 outside [0,Tin), Tout = ceil(Tin/stride): the downsample unit (ks = 2r, stride r, pad r; seanet.py:739-760)
  *                     and the SpecBlock's 1x1 + add (ks = 1; seanet.py:500-502).  Outputs: Y16 / Yact16 = ELU(act_scale*y) in c8 f16,
  *                     Yf32 [B,M,Tout] f32 row-major (any of them NULL).
+ *   wv_h16_spec_block whole SpecBlock in one launch (seanet.py:463-511): the STFT on the f16 pipe with the waveform split in two f16 terms,
+ *                     log-magnitude, the 1x1 and the add; the spectrogram stays in LDS.  (n_fft = M, hop) in {(64,1),(128,2),(256,8),(512,40)}
+ *                     (the default detector's scales), else WV_EINVAL; x16 / Y16 / Yact16 c8 f16 [B, M/8, ceil(T/hop), 8]
  *   wv_detector_forward_f16   Detector.forward (model/detector.py:366-391) in this mode: conv_pre .. the last downsample in f16,
  *                     the STFTs, spec_post, conv_post and the head in f32 (same workspace as wv_detector_forward). */
 int wv_h16_from_f32(const float* X, void* Y16, int B, int C, int T, float scale, int elu, void* stream);
@@ -211,6 +214,8 @@ int wv_h16_resblock(const void* X16, float pre_scale, const float* w_pw1, const 
                     const float* b2, void* Y16, void* Yact16, int B, int C, int T, float out_scale, float act_scale, void* stream);
 int wv_h16_conv(const void* X16, const float* w_pw, const float* w_dw, const float* bias, const void* resid16, void* Y16, void* Yact16, float* Yf32,
                 int B, int K, int M, int Tin, int ks, int stride, int pad, float out_scale, float act_scale, void* stream);
+int wv_h16_spec_block(const float* wav, const float* basis_or_null, const float* w_pw, const void* x16, void* Y16, void* Yact16, int B, int T,
+                      int n_fft, int hop, int M, float mean, float std, float out_scale, float act_scale, void* stream);
 int wv_detector_forward_f16(wv_model* m, const float* x, float* logits, float* mean_prob,
                             int B, int T, void* workspace, size_t workspace_bytes, void* stream);
 

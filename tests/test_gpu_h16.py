@@ -216,3 +216,34 @@ def test_detector_f16_shapes(detector, B, T):
     assert torch.isfinite(mp).all() and float((mp - mp32).abs().max()) <= 2e-2
     one = detector.detector_mean_prob(x[B - 1:B].contiguous(), precision="f16")
     assert torch.equal(one[0], mp[B - 1])
+
+
+@pytest.mark.parametrize("n_fft,hop,T", [(64, 1, 16000), (64, 1, 300), (64, 1, 257), (64, 1, 5), (128, 2, 16000), (128, 2, 255), (128, 2, 3), (256, 8, 16000), (256, 8, 520),
+                                         (256, 8, 7), (512, 40, 16000), (512, 40, 2600), (512, 40, 39)])
+def test_spec_block_in_one_launch(ops, n_fft, hop, T):
+    """STFT (waveform split in two f16 terms, f16 basis) -> log-magnitude -> 1x1 -> add in one launch, against the oracle's exact
+    composition; silence in one clip (both clamps), a loud clip, tile-edge frame counts.  What separates the two: the basis rounded to
+    f16 (leakage around the 1e-5 clamp level, visible only on near-silent bins), P and x' rounded to f16."""
+    rng = np.random.default_rng(n_fft + hop + T)
+    C, F, Tf = n_fft, n_fft // 2 + 1, -(-T // hop)
+    wav = np.clip(rnd(rng, 3, 1, T, scale=0.1), -1, 1)
+    wav[1, 0, : T // 3] = 0.0
+    wav[2] *= 8.0
+    x = h(rnd(rng, 3, C, Tf))
+    w = h(rnd(rng, C, F, 1, scale=F ** -0.5))
+    s_out, s_act = np.float32(0.53), np.float32(0.7071)
+    mag = O.causal_stft_mag(wav, n_fft, hop)
+    P = ((np.log(np.maximum(mag, np.float32(1e-5))) - np.float32(-4.3)) / np.float32(2.8)).astype(np.float32)
+    ref = (x + s_out * O.sconv1d(P, w, None)).astype(np.float32)
+    got, gact = ops.h16_spec_block(cu(wav), w, ops.h16_from_f32(cu(x)), n_fft, hop, mean=-4.3, std=2.8, out_scale=float(s_out), act_scale=float(s_act))
+    g = ops.h16_to_f32(got, C).cpu().numpy()
+    assert np.isfinite(g).all()
+    # frames whose bins all sit clear of the clamp: the f16 bar; frames with near-silent bins (the silent third of clip 1): the clamp region's
+    # log is steep (d log|X| = d|X| / |X|), the exact path's own test allows 5e-3 per unit of |w| there and so does this one
+    quiet = (mag <= 1e-3).any(axis=1, keepdims=True)
+    lim = TOL * max(1.0, float(np.abs(ref).max())) + np.where(quiet, 5e-3 * float(s_out) * float(np.abs(w).sum(1).max()), 0.0)
+    assert (np.abs(g - ref) <= lim).all(), float((np.abs(g - ref) - lim).max())
+    ga = ops.h16_to_f32(gact, C).cpu().numpy()
+    assert (np.abs(ga - O.elu(ref * s_act)) <= lim).all()
+    only_act = ops.h16_spec_block(cu(wav), w, ops.h16_from_f32(cu(x)), n_fft, hop, mean=-4.3, std=2.8, out_scale=float(s_out), act_scale=float(s_act), want_raw=False)
+    assert torch.equal(only_act, gact)

@@ -520,6 +520,244 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Whole SpecBlock in one launch (modules/seanet.py:463-511, CausalSTFT modules/conv.py:1036-1086):
+//     y = x + out_scale * ( W @ P ),   P[f][t] = (log(max(|STFT(wav)|, 1e-5)) - mean) / std
+// GEMM 1 = the windowed DFT as a matrix product on the f16 pipe with BOTH operands split in two f16 terms (v = hi + lo, lo carried times
+// 2^11): hi*hi in one accumulator, hi*lo + lo*hi in a second one scaled back by 2^-11 -- 22 bits of each operand, three matrix
+// instructions where the f32 pipe needs sixteen.  (With the basis rounded to f16 once, strong bins leak into weak ones at ~1e-4 of the
+// frame's level: the real-only DC and Nyquist bins of noise-like frames are often that weak, and their log-magnitude moved by up to 0.6
+// -- measured, tools/h16time.py's first version.)  A frame's B fragment is 8 CONSECUTIVE samples, so the
+// tile's waveform window sits in LDS as f16 in 8 / hop copies shifted by hop samples each (frame t reads copy (t hop) mod 8, a 16-byte
+// aligned piece).  The cos rows f = 0 .. n_fft/2 - 1 and the sin rows are separate A tiles, so that a lane holds re and im of the same
+// bin in the same register slot; sin row 0 (identically zero) carries the Nyquist bin's cos row instead.  P is written to LDS in the c8
+// layout -- the B operand of GEMM 2 = the 1x1 -- and never leaves the CU.  Epilogue 2 adds x (c8 f16 from HBM) and stores y and / or
+// ELU(act_scale * y).  (The exact path's two side rows, sin_0 and sin_{F-1} of a reference-built basis, are rounding-level and dropped.)
+// N = n_fft = rows of the 1x1 (the detector's scales: 64, 128, 256, 512), HOP in {1, 2, 4, 8 k}.  A wave's unit is 64 rows x 64 frames
+// (one cos/sin tile pair in GEMM 1, two row tiles in GEMM 2).
+template <int N_, int HOP_>
+struct SP {
+    static constexpr int N = N_, HOP = HOP_;
+    static constexpr int NP = N / 64;                            // 64-row units
+    static constexpr int NQ = NP >= 4 ? 1 : 4 / NP;              // 64-frame units per tile
+    static constexpr int BN = 64 * NQ, PASSES = NP * NQ / 4;
+    static constexpr int NPL = HOP >= 8 ? 1 : 8 / HOP;           // shifted copies of the window
+    static constexpr int WLEN = (BN - 1) * HOP + N;              // samples a tile's frames cover
+    static constexpr int PP = (WLEN + 7 + 7) / 8;                // 16-byte pieces per copy (the last copy starts 7 samples in)
+    static constexpr int PSP = (PP + 13) / 16 * 16 + 2;          // copy stride in pieces, = 2 (mod 16): the 8 copies x 2 pieces a 16-lane group reads are 16 different banks
+    static constexpr int Fp = N / 2 + 16, G2 = Fp / 8, NC1 = N / 16, NC2 = Fp / 16;
+    static constexpr size_t WIN = (size_t)NPL * PSP * 16;        // bytes of one (hi or lo) window
+    static constexpr size_t SMEM = 2 * WIN + (size_t)G2 * BN * 16;
+    static_assert(N % 64 == 0 && (HOP == 1 || HOP == 2 || HOP == 4 || HOP % 8 == 0) && NP * NQ % 4 == 0, "geometry");
+};
+
+template <class R>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void spec16_kernel(Spec16Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int N = R::N, HOP = R::HOP, BN = R::BN, NP = R::NP;
+    h16* Whi = reinterpret_cast<h16*>(smem_raw);
+    h16* Wlo = reinterpret_cast<h16*>(smem_raw + R::WIN);
+    h16* P16 = reinterpret_cast<h16*>(smem_raw + 2 * R::WIN);    // [G2][BN][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r = lane & 31;
+    const int T = p.T, Tf = p.Tf;
+    const int ntile = (Tf + BN - 1) / BN;
+    const int b = blockIdx.x / ntile, t0 = (blockIdx.x - b * ntile) * BN;
+
+    // ---- the tile's waveform window, split and copied NPL times
+    {
+        const float* wb = p.wav + (size_t)b * T;
+        const int base = t0 * HOP - (N - 1);                     // wav index of window sample 0 (causal: n_fft - 1 zeros in front of the clip, conv.py:1060)
+        for (int i = tid; i < R::NPL * R::PP; i += 256) {
+            const int pi = i / R::PP, v = i - pi * R::PP;
+            h16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int s = base + 8 * v + pi * HOP + j;
+                const float x = (s >= 0 && s < T) ? wb[s] : 0.f;
+                hi[j] = (h16)x;
+                lo[j] = (h16)((x - (float)hi[j]) * 2048.f);
+            }
+            *reinterpret_cast<h16x8*>(Whi + (size_t)(pi * R::PSP + v) * 8) = hi;
+            *reinterpret_cast<h16x8*>(Wlo + (size_t)(pi * R::PSP + v) * 8) = lo;
+        }
+    }
+    RH_BARRIER();
+
+    const __amdgpu_buffer_rsrc_t rC = uniform_rsrc(p.cosw.wq, R::NC1 * (N / 2) * 32);
+    const __amdgpu_buffer_rsrc_t rS = uniform_rsrc(p.sinw.wq, R::NC1 * (N / 2) * 32);
+    const __amdgpu_buffer_rsrc_t rCl = uniform_rsrc(p.cosl.wq, R::NC1 * (N / 2) * 32);
+    const __amdgpu_buffer_rsrc_t rSl = uniform_rsrc(p.sinl.wq, R::NC1 * (N / 2) * 32);
+    // ================= GEMM 1 + log-magnitude -> P16 =================
+#pragma unroll
+    for (int pass = 0; pass < R::PASSES; ++pass) {
+        const int u = wave + 4 * pass, mp = u % NP, nq = u / NP;
+        const int avoff = ((32 * mp + r) * 2 + h) * 16;
+        int boff[2];                                             // piece index of chunk 0's B fragment, per frame tile
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int off = (64 * nq + 32 * e + r) * HOP;
+            boff[e] = ((off & 7) / HOP) * R::PSP + (off >> 3) + h;
+        }
+        f32x16 are[2], aim[2], lre[2], lim[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { are[e][i] = 0.f; aim[e][i] = 0.f; lre[e][i] = 0.f; lim[e][i] = 0.f; }
+        h16x8 ac[2], as[2], lc[2], ls[2];
+        auto lda = [&](int c, h16x8& c_, h16x8& s_, h16x8& cl_, h16x8& sl_) {
+            const int so = c * (N / 2) * 32;
+            c_ = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rC, avoff, so, 0));
+            s_ = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rS, avoff, so, 0));
+            cl_ = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rCl, avoff, so, 0));
+            sl_ = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rSl, avoff, so, 0));
+        };
+        lda(0, ac[0], as[0], lc[0], ls[0]);
+#pragma unroll
+        for (int c = 0; c < R::NC1; ++c) {
+            if (c + 1 < R::NC1) lda(c + 1, ac[(c + 1) & 1], as[(c + 1) & 1], lc[(c + 1) & 1], ls[(c + 1) & 1]);
+            h16x8 bh[2], bl[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                bh[e] = *reinterpret_cast<const h16x8*>(Whi + (size_t)(boff[e] + 2 * c) * 8);
+                bl[e] = *reinterpret_cast<const h16x8*>(Wlo + (size_t)(boff[e] + 2 * c) * 8);
+            }
+            const h16x8 a_c = ac[c & 1], a_s = as[c & 1], l_c = lc[c & 1], l_s = ls[c & 1];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                are[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_c, bh[e], are[e], 0, 0, 0);
+                aim[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_s, bh[e], aim[e], 0, 0, 0);
+                lre[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_c, bl[e], lre[e], 0, 0, 0);
+                lim[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_s, bl[e], lim[e], 0, 0, 0);
+                lre[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(l_c, bh[e], lre[e], 0, 0, 0);
+                lim[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(l_s, bh[e], lim[e], 0, 0, 0);
+            }
+            asm volatile("" : "+v"(are[0]), "+v"(are[1]), "+v"(aim[0]), "+v"(aim[1]));
+            asm volatile("" : "+v"(lre[0]), "+v"(lre[1]), "+v"(lim[0]), "+v"(lim[1]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int col = 64 * nq + 32 * e + r;
+            float nyq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h16x4 v;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float re = fmaf(lre[e][4 * j + rr], 1.f / 2048.f, are[e][4 * j + rr]);
+                    float im = fmaf(lim[e][4 * j + rr], 1.f / 2048.f, aim[e][4 * j + rr]);
+                    if (j == 0 && rr == 0 && mp == 0 && h == 0) { nyq = im; im = 0.f; }      // bin 0: no imaginary part; its sin slot carried the Nyquist bin
+                    v[rr] = (h16)stft_logmag(re, im, p.c1, p.c0);
+                }
+                *reinterpret_cast<h16x4*>(P16 + (size_t)((4 * mp + j) * BN + col) * 8 + 4 * h) = v;
+            }
+            if (mp == 0 && h == 0) {                             // rows n_fft/2 (Nyquist) .. Fp - 1 (zero: the 1x1's padded columns)
+                h16x8 z;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) z[i] = (h16)0.f;
+                *reinterpret_cast<h16x8*>(P16 + (size_t)((N / 16 + 1) * BN + col) * 8) = z;
+                z[0] = (h16)stft_logmag(nyq, 0.f, p.c1, p.c0);
+                *reinterpret_cast<h16x8*>(P16 + (size_t)((N / 16) * BN + col) * 8) = z;
+            }
+        }
+    }
+    RH_BARRIER();
+    // ================= GEMM 2: W @ P, + x =================
+    const __amdgpu_buffer_rsrc_t rW = uniform_rsrc(p.pw.wq, p.pw.nchunks * N * 32);
+    constexpr int Gm = N / 8;
+    const size_t yclip = (size_t)Gm * Tf * 8;
+    const __amdgpu_buffer_rsrc_t rR = uniform_rsrc(reinterpret_cast<const h16*>(p.resid) + b * yclip, (int)(yclip * 2));
+    const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(p.Y ? reinterpret_cast<h16*>(p.Y) + b * yclip : reinterpret_cast<const h16*>(p.resid), p.Y ? (int)(yclip * 2) : 0);
+    const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(p.Yact ? reinterpret_cast<h16*>(p.Yact) + b * yclip : reinterpret_cast<const h16*>(p.resid), p.Yact ? (int)(yclip * 2) : 0);
+#pragma unroll
+    for (int pass = 0; pass < R::PASSES; ++pass) {
+        const int u = wave + 4 * pass, mp = u % NP, nq = u / NP;
+        int avoff[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) avoff[mt] = ((64 * mp + 32 * mt + r) * 2 + h) * 16;
+        const h16* Bp = P16 + (size_t)(h * BN + 64 * nq + r) * 8;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][e][i] = 0.f;
+        h16x8 aw[2][2];
+        auto ldw = [&](int c, h16x8 (&d)[2]) {
+            const int so = c * N * 32;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) d[mt] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, avoff[mt], so, 0));
+        };
+        ldw(0, aw[0]);
+#pragma unroll
+        for (int c = 0; c < R::NC2; ++c) {
+            if (c + 1 < R::NC2) ldw(c + 1, aw[(c + 1) & 1]);
+            h16x8 bb[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) bb[e] = *reinterpret_cast<const h16x8*>(Bp + (size_t)(2 * c * BN + 32 * e) * 8);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw[c & 1][mt], bb[e], acc[mt][e], 0, 0, 0);
+            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int mrow = 64 * mp + 32 * mt + 8 * j + 4 * h;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int t = t0 + 64 * nq + 32 * e + r;
+                    const int off = t < Tf ? ((mrow >> 3) * Tf + t) * 16 + 8 * h : H_OOB;
+                    const h16x4 xv = __builtin_bit_cast(h16x4, __builtin_amdgcn_raw_buffer_load_b64(rR, off, 0, 0));
+                    float y[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) y[rr] = fmaf(acc[mt][e][4 * j + rr], p.out_scale, (float)xv[rr]);
+                    if (p.Y) {
+                        h16x4 v;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)y[rr];
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rY, off, 0, 0);
+                    }
+                    if (p.Yact) {
+                        h16x4 v;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu1(y[rr] * p.act_scale);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rA, off, 0, 0);
+                    }
+                }
+            }
+    }
+}
+
+template <class R>
+hipError_t spec16_launch(const Spec16Args& a, hipStream_t s) {
+    static std::atomic<unsigned> attr{0};
+    if (R::SMEM > 64 * 1024) {
+        int d = 0; (void)hipGetDevice(&d);
+        const unsigned bit = 1u << (d & 31);
+        if (!(attr.load(std::memory_order_relaxed) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spec16_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::SMEM);
+            if (e != hipSuccess) return e;
+            attr.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    const long long grid = (long long)((a.Tf + R::BN - 1) / R::BN) * a.B;
+    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    std::string name;
+    if (prof::enabled()) name = "spec16<" + std::to_string(R::N) + ",hop" + std::to_string(R::HOP) + ">";
+    const double Bd = a.B, Tf = a.Tf, Nn = R::N;
+    prof::Scope ps(s, name.c_str(), Bd * Tf * (2.0 * 2.0 * (Nn + 2.0) * Nn + 2.0 * Nn * (Nn / 2 + 1)),
+                   Bd * (4.0 * a.T + 2.0 * Nn * Tf * (1.0 + (a.Y ? 1.0 : 0.0) + (a.Yact ? 1.0 : 0.0))));
+    hipLaunchKernelGGL((spec16_kernel<R>), dim3((unsigned)grid), dim3(256), R::SMEM, s, a);
+    return hipGetLastError();
+}
+
 // conv_pre (SConv1d 1 -> C, k taps, causal; modules/seanet.py:657-663) straight into the c8 layout: a thread owns one time step and
 // walks the channel groups (a wave's store of one group is 1 KB contiguous).
 __global__ __launch_bounds__(256) void conv_pre16_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -631,6 +869,20 @@ hipError_t launch_conv16(const Conv16Args& a, hipStream_t s) {
     else if (wgm == 2) hipLaunchKernelGGL((conv16_kernel<2, 2, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv16_kernel<1, 4, false>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+hipError_t launch_spec16(const Spec16Args& a, hipStream_t s) {
+    if (!a.wav || !a.resid || (!a.Y && !a.Yact) || !a.cosw.wq || !a.sinw.wq || !a.cosl.wq || !a.sinl.wq || !a.pw.wq || a.B < 1 || a.T < 1) return hipErrorInvalidValue;
+    const int N = a.n_fft;
+    if (a.Tf != (a.T + a.hop - 1) / a.hop || a.pw.M != N || a.pw.K != N / 2 + 1 || a.pw.Mp != N || a.pw.Kp != N / 2 + 16 || a.cosw.M != N / 2 || a.cosw.K != N ||
+        a.sinw.M != N / 2 || a.sinw.K != N || a.cosw.Mp != N / 2 || a.sinw.Mp != N / 2 || a.cosw.nchunks != N / 16 || a.sinw.nchunks != N / 16)
+        return hipErrorNotSupported;
+    if ((long long)N * a.Tf * 2 >= H_OOB || !al16(a.resid) || (a.Y && !al16(a.Y)) || (a.Yact && !al16(a.Yact))) return hipErrorNotSupported;
+    if (N == 64 && a.hop == 1) return spec16_launch<SP<64, 1>>(a, s);
+    if (N == 128 && a.hop == 2) return spec16_launch<SP<128, 2>>(a, s);
+    if (N == 256 && a.hop == 8) return spec16_launch<SP<256, 8>>(a, s);
+    if (N == 512 && a.hop == 40) return spec16_launch<SP<512, 40>>(a, s);
+    return hipErrorNotSupported;
 }
 
 hipError_t launch_conv_pre16(const float* x, const float* w, const float* bias, void* Y, int B, int C, int T, int ks, float in_scale, hipStream_t s) {

@@ -142,6 +142,42 @@ struct Conv16Args {           // y = out_scale * (bias + conv(x)) + resid; x, re
     float out_scale, act_scale; int B, M, Tin, Tout, ks, stride, pad;
 };
 hipError_t launch_conv16(const Conv16Args& a, hipStream_t s);
+// whole SpecBlock (STFT on the f16 pipe with a two-term split of the waveform -> log-magnitude -> 1x1 -> + x), the spectrogram stays in LDS.
+// cosw / sinw: the basis' cos rows f = 0 .. n_fft/2 - 1 and sin rows (row 0 = the Nyquist bin's cos row) as A fragments (pack_stft16);
+// pw: the 1x1 [n_fft][F] with K padded to n_fft/2 + 16.  (n_fft, hop) in {(64,1), (128,2), (256,8), (512,40)}, else hipErrorNotSupported.
+struct Spec16Args {
+    const float* wav; H16Weight cosw, sinw, cosl, sinl, pw; const void* resid; void* Y; void* Yact;   // cosl / sinl: (basis - f16(basis)) * 2^11
+    float out_scale, act_scale, c1, c0; int B, T, Tf, n_fft, hop;
+};
+hipError_t launch_spec16(const Spec16Args& a, hipStream_t s);
+// host: basis [2F][n_fft] (cos rows, then sin rows; modules/conv.py:1003-1026) -> the two A-fragment matrices of launch_spec16
+inline float f16_bits_to_f32(uint16_t hb) {
+    const uint32_t sign = (uint32_t)(hb & 0x8000u) << 16, e = (hb >> 10) & 31u, m = hb & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int sh = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; ++sh; } x = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3ffu) << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f; std::memcpy(&f, &x, 4);
+    return f;
+}
+// q[0..3] = cos hi, sin hi, cos lo, sin lo; w[0..3] their descriptors (wq unset)
+inline void pack_stft16(const float* basis, int n_fft, std::vector<uint16_t> (&q)[4], H16Weight (&w)[4]) {
+    const int F = n_fft / 2 + 1, R = n_fft / 2;
+    std::vector<float> m[4];
+    for (auto& v : m) v.resize((size_t)R * n_fft);
+    for (int f = 0; f < R; ++f)
+        for (int n = 0; n < n_fft; ++n) {
+            const float c = basis[(size_t)f * n_fft + n];
+            const float s = f == 0 ? basis[(size_t)(F - 1) * n_fft + n] : basis[(size_t)(F + f) * n_fft + n];
+            const size_t i = (size_t)f * n_fft + n;
+            m[0][i] = c; m[1][i] = s;
+            m[2][i] = (c - f16_bits_to_f32(f32_to_f16_bits(c))) * 2048.f;
+            m[3][i] = (s - f16_bits_to_f32(f32_to_f16_bits(s))) * 2048.f;
+        }
+    for (int k = 0; k < 4; ++k) q[k] = pack_h16(m[k].data(), nullptr, R, n_fft, 1, &w[k]);
+}
 hipError_t launch_conv_pre16(const float* x, const float* w, const float* bias, void* Y, int B, int C, int T, int ks, float in_scale, hipStream_t s);
 hipError_t launch_f32_to_c8(const float* X, void* Y, int B, int C, int T, float scale, int elu, hipStream_t s);
 hipError_t launch_c8_to_f32(const void* X, float* Y, int B, int C, int T, hipStream_t s);

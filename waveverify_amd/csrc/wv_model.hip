@@ -86,7 +86,7 @@ struct wv_model {
     int head_nb = 0;
     // ---- f16 mode of the detector (wv_h16.hip): A-fragment weights per encoder stage -- the ResnetBlocks' 1x1 pairs, the SpecBlock's
     // 1x1 over the zero-padded spectrum rows, the downsample unit's 1x1 and depth-wise conv composed into one [M][2r][K] conv
-    struct H16Stage { std::vector<std::pair<wv::H16Weight, wv::H16Weight>> blocks; wv::H16Weight spec, down; };
+    struct H16Stage { std::vector<std::pair<wv::H16Weight, wv::H16Weight>> blocks; wv::H16Weight spec, down, cosw, sinw, cosl, sinl; };
     std::vector<H16Stage> h16;
 
     ~wv_model() { for (void* p : dev) (void)hipFree(p); }
@@ -215,6 +215,9 @@ struct Uploader {
     wv::H16Weight h16(const std::vector<float>& pw, const float* dw, int M, int K, int ks) {
         wv::H16Weight w;
         const std::vector<uint16_t> q = wv::pack_h16(pw.data(), dw, M, K, ks, &w);
+        return h16_up(q, w);
+    }
+    wv::H16Weight h16_up(const std::vector<uint16_t>& q, wv::H16Weight w) {
         if (err != WV_OK) return w;
         void* d = nullptr;
         if (hipMalloc(&d, q.size() * sizeof(uint16_t)) != hipSuccess) { err = fail(WV_EHIP, "hipMalloc failed while packing f16 weights"); return w; }
@@ -453,6 +456,15 @@ int pack_model(wv_model* m) {
             st.spec = U.h16(U.host("encoder.spec_blocks." + std::to_string(s) + ".layer.conv.conv.weight"), nullptr, C, F, 1);
             const std::string dp = "encoder.downsample." + std::to_string(s);
             st.down = U.h16(U.host(dp + ".2.conv.conv.weight"), U.host(dp + ".3.conv.conv.weight").data(), 2 * C, C, 2 * r);
+            {
+                const int n_fft = m->specs[s].n_fft;
+                auto ov = m->stft_override.find("encoder.spec_blocks." + std::to_string(s) + ".spec.weight");
+                const std::vector<float> basis = ov != m->stft_override.end() ? ov->second : make_basis(n_fft);
+                std::vector<uint16_t> q4[4];
+                wv::H16Weight w4[4];
+                wv::pack_stft16(basis.data(), n_fft, q4, w4);
+                st.cosw = U.h16_up(q4[0], w4[0]); st.sinw = U.h16_up(q4[1], w4[1]); st.cosl = U.h16_up(q4[2], w4[2]); st.sinl = U.h16_up(q4[3], w4[3]);
+            }
             m->h16.push_back(std::move(st));
         }
     }
@@ -965,13 +977,23 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, cha
         sa.Tf = (T + sp.hop - 1) / sp.hop; sa.n_fft = sp.n_fft; sa.hop = sp.hop; sa.F = sp.F; sa.Mp = sp.Mp;
         sa.mean = sp.mean; sa.inv_std = sp.inv_std;
         if (sa.Tf != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");
-        LAUNCH(wv::launch_stft_logmag(sa, st));
-        LAUNCH(wv::launch_f32_to_c8(P, P16, B, sp.F, Tl, 1.f, 0, st));
         const DownLayer& d = m->downs[s];
-        wv::Conv16Args q{};                                       // x' = x + scale * (W @ P); only ELU(c * x') is consumed
-        q.X = P16; q.w = hs.spec; q.bias = nullptr; q.resid = R[cur]; q.Y = nullptr; q.Yact = A0; q.Yf32 = nullptr;
-        q.out_scale = sp.scale; q.act_scale = d.pre_scale; q.B = B; q.M = C; q.Tin = Tl; q.Tout = Tl; q.ks = 1; q.stride = 1; q.pad = 0;
-        LAUNCH(wv::launch_conv16(q, st));
+        // x' = x + scale * (W @ P); only ELU(c * x') is consumed.  One launch where the scale is one of the fused kernel's (the default
+        // detector's four), else the exact path's STFT kernel -> P in HBM -> f16 copy -> the 1x1 + add as a k = 1 conv
+        wv::Spec16Args f{};
+        f.wav = x; f.cosw = hs.cosw; f.sinw = hs.sinw; f.cosl = hs.cosl; f.sinl = hs.sinl; f.pw = hs.spec; f.resid = R[cur]; f.Y = nullptr; f.Yact = A0;
+        f.out_scale = sp.scale; f.act_scale = d.pre_scale; f.c1 = 0.5f * 0.6931471805599453f * sp.inv_std; f.c0 = -sp.mean * sp.inv_std;
+        f.B = B; f.T = T; f.Tf = Tl; f.n_fft = sp.n_fft; f.hop = sp.hop;
+        const hipError_t fe = C == sp.n_fft ? wv::launch_spec16(f, st) : hipErrorNotSupported;
+        if (fe != hipSuccess && fe != hipErrorNotSupported) return fail(WV_EHIP, std::string("launch_spec16: ") + hipGetErrorString(fe));
+        if (fe == hipErrorNotSupported) {
+            LAUNCH(wv::launch_stft_logmag(sa, st));
+            LAUNCH(wv::launch_f32_to_c8(P, P16, B, sp.F, Tl, 1.f, 0, st));
+            wv::Conv16Args q{};
+            q.X = P16; q.w = hs.spec; q.bias = nullptr; q.resid = R[cur]; q.Y = nullptr; q.Yact = A0; q.Yf32 = nullptr;
+            q.out_scale = sp.scale; q.act_scale = d.pre_scale; q.B = B; q.M = C; q.Tin = Tl; q.Tout = Tl; q.ks = 1; q.stride = 1; q.pad = 0;
+            LAUNCH(wv::launch_conv16(q, st));
+        }
         wv::prof::set_role("enc16.down");
         const bool last = s + 1 == S;
         wv::Conv16Args g{};

@@ -238,6 +238,26 @@ int wv_op_spec_block(const float* wav, const float* basis_or_null, const float* 
     return done(t, e, (hipStream_t)stream);
 }
 
+int wv_h16_spec_block(const float* wav, const float* basis_or_null, const float* w_pw, const void* x16, void* Y16, void* Yact16, int B, int T,
+                      int n_fft, int hop, int M, float mean, float std_, float out_scale, float act_scale, void* stream) {
+    if (!wav || !w_pw || !x16 || (!Y16 && !Yact16) || B < 1 || T < 1 || n_fft < 2 || (n_fft & 1) || hop < 1 || M != n_fft || !(std_ > 0.f)) return WV_EINVAL;
+    Tmp t;
+    const std::vector<float> basis = stft_basis_host(basis_or_null, n_fft);
+    std::vector<uint16_t> q4[4];
+    wv::H16Weight w4[4];
+    wv::Spec16Args a{};
+    wv::pack_stft16(basis.data(), n_fft, q4, w4);
+    for (int k = 0; k < 4; ++k) w4[k].wq = t.upb(q4[k].data(), q4[k].size() * sizeof(uint16_t));
+    a.cosw = w4[0]; a.sinw = w4[1]; a.cosl = w4[2]; a.sinl = w4[3];
+    a.pw = t.h16(w_pw, nullptr, M, n_fft / 2 + 1, 1);
+    a.wav = wav; a.resid = x16; a.Y = Y16; a.Yact = Yact16; a.out_scale = out_scale; a.act_scale = act_scale;
+    a.c1 = 0.5f * 0.69314718055994531f / std_; a.c0 = -mean / std_;
+    a.B = B; a.T = T; a.Tf = (T + hop - 1) / hop; a.n_fft = n_fft; a.hop = hop;
+    const hipError_t e = wv::launch_spec16(a, (hipStream_t)stream);
+    if (e == hipErrorNotSupported) return WV_EINVAL;
+    return done(t, e, (hipStream_t)stream);
+}
+
 }  // extern "C"
 
 // A resident plan of the same op (the basis packed and uploaded once): what a training step calls once per scale and step.

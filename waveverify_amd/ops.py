@@ -253,3 +253,19 @@ def h16_conv(X16, w_pw, w_dw=None, bias=None, resid16=None, K: Optional[int] = N
                                _dp(out.get("raw")), _dp(out.get("act")), _dp(out.get("f32")), B, K, M, Tin, ks, stride, pad, float(out_scale),
                                float(act_scale or 0.0), _stream()), "wv_h16_conv")
     return out
+
+
+def h16_spec_block(wav, w_pw, x16, n_fft, hop, mean=0.0, std=1.0, out_scale=1.0, act_scale: Optional[float] = None, want_raw: bool = True, basis=None):
+    """Whole SpecBlock on the f16 pipe: y = x + out_scale * (W @ logmag(STFT(wav))) -> Y16, (Y16, Yact16) or Yact16 alone (c8 f16)."""
+    lib = _lib.load()
+    wav, x16 = _dev(wav), _c8(x16)
+    B, T = wav.shape[0], wav.shape[-1]
+    M = 8 * x16.shape[1]
+    w_pw = _w(w_pw).reshape(M, n_fft // 2 + 1)
+    Y = torch.empty_like(x16) if want_raw else None
+    Yact = torch.empty_like(x16) if act_scale is not None else None
+    _lib.check(lib.wv_h16_spec_block(wav.data_ptr(), _hp(_w(basis)), _hp(w_pw), x16.data_ptr(), _dp(Y), _dp(Yact), B, T, n_fft, hop, M,
+                                     mean, std, out_scale, float(act_scale or 0.0), _stream()), "wv_h16_spec_block")
+    if Y is None:
+        return Yact
+    return Y if act_scale is None else (Y, Yact)
