@@ -56,6 +56,12 @@ __device__ __forceinline__ void rh_stencil(const f32x16 (&acc)[NT], int r, const
     float own[NT];
 #pragma unroll
     for (int e = 0; e < NT; ++e) own[e] = acc[e][r];
+    // The DPP multiply-adds below are inline asm: the compiler does not see that they read `own` / `sh` from ANOTHER lane and keeps no
+    // distance between a write of those registers (a copy out of an accumulator register, a reload) and the DPP read (2 wait states on
+    // gfx9).  Materialise them here and wait once; nothing writes them after this point.  (Seen live: a 128-register build of this
+    // kernel returned wrong values in one lane pair per row group, differently from run to run.)
+    if constexpr (NT == 4) asm volatile("s_nop 1" : "+v"(own[0]), "+v"(own[1]), "+v"(own[2]), "+v"(own[3]));
+    else asm volatile("s_nop 1" : "+v"(own[0]), "+v"(own[1]));
     if constexpr (NT == 4) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -75,7 +81,7 @@ __device__ __forceinline__ void rh_stencil(const f32x16 (&acc)[NT], int r, const
         rh_fma_next(v1, own[0], w[1]);
         rh_fma_next(v0, own[0], w[2]); rh_fma_next(v1, own[1], w[2]);
         rh_fma_next(v0, own[1], w[3]);
-        asm volatile("" : "+v"(sh[0]), "+v"(sh[1]));
+        asm volatile("s_nop 1" : "+v"(sh[0]), "+v"(sh[1]));              // the shifted copies are complete (and two wait states old) before they are DPP operands
         rh_fma_next(v1, sh[0], w[3]);
         rh_fma_next(v0, sh[0], w[4]); rh_fma_next(v1, sh[1], w[4]);
         y[0] = v0; y[1] = v1;
@@ -85,7 +91,7 @@ __device__ __forceinline__ void rh_stencil(const f32x16 (&acc)[NT], int r, const
 // C channels, NG column groups of 32*NT columns (overlapping by the stencil's 4), WPS waves per SIMD.  One wave = one 32-row strip x
 // one column group.  RESIDENT: both weight strips of a wave stay in registers for the kernel's life (C <= 128: 2 * C/16 fragments);
 // wider layers stream them through a ring, A_AHEAD chunks in front of their MFMAs.
-template <int C_, int NG_, int NT_, int WPS_, int RING_ = 8, int PD_ = 2>
+template <int C_, int NG_, int NT_, int WPS_, int RING_ = 8, int PD_ = 2, bool RES_ = (C_ <= 128)>
 struct RH {
     static constexpr int C = C_, NG = NG_, NT = NT_, WPS = WPS_, PD = PD_;
     static constexpr int WM = C / 32, NWAVES = WM * NG, NTHREADS = 64 * NWAVES;
@@ -93,7 +99,7 @@ struct RH {
     static constexpr int G = C / 8, NCH = C / 16;
     static constexpr int PIECES = G * WD;                                  // 16-byte (group, column) pieces of a window
     static constexpr int NI = (PIECES + 64 * NWAVES - 1) / (64 * NWAVES);  // LDS-DMA instructions per wave and window
-    static constexpr bool RESIDENT = C <= 128;
+    static constexpr bool RESIDENT = RES_;
     static constexpr int NA = RESIDENT ? 2 * NCH : RING_, AD = NA - 1;
     static constexpr size_t WBYTES = (size_t)PIECES * 16;
     static constexpr size_t SMEM = WBYTES + (size_t)2 * C * 8 * sizeof(float);
@@ -826,9 +832,9 @@ bool rh_supported(const RhArgs& a) {
 hipError_t launch_resblock16(const RhArgs& a, hipStream_t s) {
     if (!rh_supported(a)) return hipErrorNotSupported;
     switch (a.C) {
-        case 64: return rh_pick_out<RH<64, 2, 4, 2>>(a, s);      // 2 x 2 waves, 252-column windows (32 KB)
-        case 128: return rh_pick_out<RH<128, 1, 4, 2>>(a, s);    // 4 x 1 waves, 128-column windows (32 KB)
-        case 256: return rh_pick_out<RH<256, 1, 4, 2>>(a, s);    // 8 x 1 waves, 128-column windows (64 KB)
+        case 64: return rh_pick_out<RH<64, 4, 2, 4>>(a, s);      // 2 x 4 waves, 244-column windows
+        case 128: return rh_pick_out<RH<128, 2, 2, 4, 8, 2, false>>(a, s);  // 4 x 2 waves, 124-column windows (32 KB), weights streamed
+        case 256: return rh_pick_out<RH<256, 1, 2, 4, 4, 1>>(a, s); // 8 x 1 waves, 64-column windows (32 KB)
         default: return rh_pick_out<RH<512, 1, 2, 4, 4, 1>>(a, s); // 16 x 1 waves, 64-column windows (64 KB)
     }
 }

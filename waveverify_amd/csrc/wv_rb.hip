@@ -120,6 +120,11 @@ __device__ __forceinline__ void rb_stencil(const f32x16 (&acc)[NT], int r, const
     float own[NT];
 #pragma unroll
     for (int e = 0; e < NT; ++e) own[e] = acc[e][r];
+    // The DPP multiply-adds below are inline asm: the compiler does not see that they read `own` / `sh` from ANOTHER lane and keeps no
+    // distance between a write of those registers (a copy out of an accumulator register, a reload) and the DPP read (2 wait states on
+    // gfx9).  Materialise them here and wait once; nothing writes them after this point.
+    if constexpr (NT == 4) asm volatile("s_nop 1" : "+v"(own[0]), "+v"(own[1]), "+v"(own[2]), "+v"(own[3]));
+    else asm volatile("s_nop 1" : "+v"(own[0]), "+v"(own[1]));
     if constexpr (NT == 4) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -139,7 +144,7 @@ __device__ __forceinline__ void rb_stencil(const f32x16 (&acc)[NT], int r, const
         rb_fma_next(v1, own[0], w[1]);
         rb_fma_next(v0, own[0], w[2]); rb_fma_next(v1, own[1], w[2]);
         rb_fma_next(v0, own[1], w[3]);
-        asm volatile("" : "+v"(sh[0]), "+v"(sh[1]));                     // the shifted copies are complete before they are DPP operands
+        asm volatile("s_nop 1" : "+v"(sh[0]), "+v"(sh[1]));              // the shifted copies are complete (and two wait states old) before they are DPP operands
         rb_fma_next(v1, sh[0], w[3]);
         rb_fma_next(v0, sh[0], w[4]); rb_fma_next(v1, sh[1], w[4]);
         y[0] = v0; y[1] = v1;
