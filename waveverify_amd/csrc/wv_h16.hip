@@ -401,7 +401,7 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // its L2 while x streams past.
 template <int WGM, int WGN, bool FLAT>
 __global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
-    constexpr int D = 4;
+    constexpr int D = 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WGM, wn = wave / WGM;
@@ -764,6 +764,175 @@ hipError_t spec16_launch(const Spec16Args& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same conv for the strided layers (KS = 2 * stride taps, stride >= 4), with x staged through LDS.  Straight from global memory a
+// B fragment load touches one cache line PER LANE (consecutive output times are stride * 16 bytes apart), and the L1's tag rate, not
+// the matrix pipe, sets the pace (measured: 515 / 322 / 220 TFLOP/s at stride 4 / 5 / 8).  Here a workgroup owns 256 rows x 128 output
+// times; per 16-channel step the x window ((127 stride + KS) times x 2 channel groups) is copied by LDS-DMA -- coalesced, each piece
+// fetched once per workgroup -- into a double buffer, skewed by one piece per `stride` pieces so that the fragment reads (lane stride =
+// stride + 1 pieces, odd) are conflict-free: the DMA's destination is lane-linear, but each lane may fetch any piece, so the lanes of
+// an instruction fetch the pieces whose skewed places they write (the holes fetch zeros).  A fragments stream from L2 through a ring of
+// NA taps.  One barrier per 16 channels.  SHORT: layers with at most 64 outputs per clip take two clips per tile (64 columns each).
+template <int KS, bool SHORT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv16s_kernel(Conv16Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int S = KS / 2, NSUB = SHORT ? 2 : 1, CPS = 128 / NSUB;
+    constexpr bool SKEW = (S % 2) == 0;
+    constexpr int W = (CPS - 1) * S + KS;                        // window times of one sub-window
+    constexpr int WP = SKEW ? W + W / S + 1 : W;                  // ... and its places in LDS
+    constexpr int PIECES = 2 * NSUB * WP, ND = (PIECES + 255) / 256;
+    constexpr int NA = KS == 10 ? 5 : 8, AD = NA - 1;
+    static_assert(KS % NA == 0 && PIECES * 16 * 2 <= 160 * 1024, "geometry");
+    h16* S0 = reinterpret_cast<h16*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r = lane & 31;
+    const int Tin = p.Tin, Tout = p.Tout, Gk = p.w.Kp / 8, Gm = (p.M + 15) / 16 * 2, Mp = p.w.Mp, NKC = p.w.Kp / 16, nch = p.w.nchunks;
+    const size_t xclip = (size_t)Gk * Tin * 8, yclip = (size_t)Gm * Tout * 8;      // halves per clip
+    int b0, to0;
+    if constexpr (SHORT) { b0 = 2 * blockIdx.x; to0 = 0; }
+    else { const int ncol = (Tout + 127) / 128; b0 = blockIdx.x / ncol; to0 = (blockIdx.x - b0 * ncol) * 128; }
+    const int m0 = (blockIdx.y * 4 + wave) * 64;
+    const bool rows = m0 < p.M;                                  // (all waves copy and meet at the barriers; a wave past M computes nothing)
+    const __amdgpu_buffer_rsrc_t rX = SHORT ? uniform_rsrc(p.X, (int)(xclip * 2 * p.B)) : uniform_rsrc(reinterpret_cast<const h16*>(p.X) + b0 * xclip, (int)(xclip * 2));
+    const __amdgpu_buffer_rsrc_t rW = uniform_rsrc(p.w.wq, p.w.nchunks * Mp * 32);
+
+    // ---- this thread's ND pieces of a window copy: place q = tid + 256 j of [2 groups][NSUB][WP]
+    int dvo[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const int q = tid + 256 * j;
+        const int gi = q / (NSUB * WP), rem = q - gi * (NSUB * WP), sub = rem / WP, pos = rem - sub * WP;
+        const bool hole = SKEW && (pos % (S + 1)) == S;
+        const int u = SKEW ? pos - pos / (S + 1) : pos;
+        const int t = to0 * S - p.pad + u;
+        const bool ok = q < PIECES && !hole && u < W && t >= 0 && t < Tin && (!SHORT || b0 + sub < p.B);
+        dvo[j] = ok ? (SHORT ? (b0 + sub) * (int)(xclip * 2) : 0) + (gi * Tin + t) * 16 : H_OOB;
+    }
+    auto copy = [&](int kc, int buf) {
+        const int so = 2 * kc * Tin * 16;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int q0 = 256 * j + 64 * wave;                  // wave-uniform first place of this instruction
+            h16* dst = S0 + (size_t)(buf * PIECES + q0) * 8;
+            const int vo = dvo[j];
+            if (q0 < PIECES) {
+                if (q0 + lane < PIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)dst, 16, vo, so, 0, 0);
+            }
+        }
+    };
+    // ---- B fragment places: column 32 e + r -> (sub-window, local time tl): place (h * NSUB + sub) * WP + tl * (S + skew), + tap (+ 1 past the hole)
+    int bpl[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int col = 32 * e + r, sub = SHORT ? col / 64 : 0, tl = SHORT ? col % 64 : col;
+        bpl[e] = (h * NSUB + sub) * WP + tl * (S + (SKEW ? 1 : 0));
+    }
+    int avoff[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) avoff[mt] = (rows && m0 + 32 * mt + r < Mp) ? ((m0 + 32 * mt + r) * 2 + h) * 16 : H_OOB;
+    h16x8 ar[NA][2];
+    auto lda = [&](int chunk, h16x8 (&d)[2]) {
+        const int so = chunk * Mp * 32;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) d[mt] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, avoff[mt], so, 0));
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][e][i] = 0.f;
+
+    copy(0, 0);
+#pragma unroll
+    for (int i = 0; i < AD; ++i) lda(i, ar[i % NA]);
+    for (int kc = 0; kc < NKC; ++kc) {
+        // everything older than the last AD taps' fragments has landed: this step's window (copied a step ago)
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * AD) : "memory");
+        RH_BARRIER();                                            // ... in every wave; and every wave has read the other buffer
+        if (kc + 1 < NKC) copy(kc + 1, (kc + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);                       // the copy stays in front of this step's fragment loads (the wait above counts on it)
+        const h16* Sb = S0 + (size_t)((kc & 1) * PIECES) * 8;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            // chunk kc * KS + i; ring slot = i % NA (KS is a multiple of NA)
+            if (kc * KS + i + AD < nch) lda(kc * KS + i + AD, ar[(i + AD) % NA]);   // (only the last step skips any: nothing waits on a count after it)
+            const int tp = i + (SKEW ? i / S : 0);
+            h16x8 bb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bb[e] = *reinterpret_cast<const h16x8*>(Sb + (size_t)(bpl[e] + tp) * 8);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[i % NA][mt], bb[e], acc[mt][e], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!rows) return;
+    // ---- epilogue: rows m0 + 32 mt + 8 j + 4 h + rr, columns 32 e + r
+    const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(p.Y ? reinterpret_cast<h16*>(p.Y) : reinterpret_cast<const h16*>(p.X), p.Y ? (int)(yclip * 2 * p.B) : 0);
+    const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(p.Yact ? reinterpret_cast<h16*>(p.Yact) : reinterpret_cast<const h16*>(p.X), p.Yact ? (int)(yclip * 2 * p.B) : 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mrow = m0 + 32 * mt + 8 * j + 4 * h;
+            float bias[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) bias[rr] = (p.bias && mrow + rr < p.M) ? p.bias[mrow + rr] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = 32 * e + r;
+                const int clip = SHORT ? b0 + col / 64 : b0, to = SHORT ? col % 64 : to0 + col;
+                const bool ok = to < Tout && clip < p.B && mrow < p.M;
+                const int off = ok ? clip * (int)(yclip * 2) + ((mrow >> 3) * Tout + to) * 16 + 8 * h : H_OOB;
+                float y[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) y[rr] = (acc[mt][e][4 * j + rr] + bias[rr]) * p.out_scale;
+                if (p.Y) {
+                    h16x4 v;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)y[rr];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rY, off, 0, 0);
+                }
+                if (p.Yact) {
+                    h16x4 v;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu1(y[rr] * p.act_scale);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rA, off, 0, 0);
+                }
+                if (p.Yf32 && ok) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        if (mrow + rr < p.M) p.Yf32[((size_t)clip * p.M + mrow + rr) * Tout + to] = y[rr];
+                }
+            }
+        }
+}
+
+template <int KS, bool SHORT>
+hipError_t conv16s_launch(const Conv16Args& a, hipStream_t s) {
+    constexpr int S = KS / 2, NSUB = SHORT ? 2 : 1, CPS = 128 / NSUB, W = (CPS - 1) * S + KS, WP = (S % 2) == 0 ? W + W / S + 1 : W;
+    constexpr int SMEM = 2 * 2 * NSUB * WP * 16;
+    static std::atomic<unsigned> attr{0};
+    if (SMEM > 64 * 1024) {
+        int d = 0; (void)hipGetDevice(&d);
+        const unsigned bit = 1u << (d & 31);
+        if (!(attr.load(std::memory_order_relaxed) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv16s_kernel<KS, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+            if (e != hipSuccess) return e;
+            attr.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    const long long gx = SHORT ? (a.B + 1) / 2 : (long long)((a.Tout + 127) / 128) * a.B;
+    if (gx > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv16s_kernel<KS, SHORT>), dim3((unsigned)gx, (unsigned)((a.M + 255) / 256)), dim3(256), SMEM, s, a);
+    return hipGetLastError();
+}
+
 // conv_pre (SConv1d 1 -> C, k taps, causal; modules/seanet.py:657-663) straight into the c8 layout: a thread owns one time step and
 // walks the channel groups (a wave's store of one group is 1 KB contiguous).
 __global__ __launch_bounds__(256) void conv_pre16_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -841,7 +1010,7 @@ hipError_t launch_resblock16(const RhArgs& a, hipStream_t s) {
 
 hipError_t launch_conv16(const Conv16Args& a, hipStream_t s) {
     if (!a.X || !a.w.wq || (!a.Y && !a.Yact && !a.Yf32) || a.B < 1 || a.M < 1 || a.Tin < 1 || a.Tout < 1 || a.ks < 1 || a.stride < 1) return hipErrorInvalidValue;
-    if (a.w.Kp % 16 || a.w.Mp % 32 || a.w.nchunks % 4 || a.w.nchunks < a.ks * (a.w.Kp / 16) || a.w.M != a.M) return hipErrorInvalidValue;
+    if (a.w.Kp % 16 || a.w.Mp % 32 || a.w.nchunks % 8 || a.w.nchunks < a.ks * (a.w.Kp / 16) || a.w.M != a.M) return hipErrorInvalidValue;
     if ((long long)a.w.Kp * a.Tin * 2 >= H_OOB || (long long)round_up(a.M, 16) * a.Tout * 2 >= H_OOB || (long long)a.w.nchunks * a.w.Mp * 32 >= H_OOB)
         return hipErrorInvalidValue;
     if (!al16(a.X) || !al16(a.w.wq) || (a.Y && !al16(a.Y)) || (a.Yact && !al16(a.Yact)) || (a.resid && !al16(a.resid))) return hipErrorInvalidValue;
@@ -850,13 +1019,23 @@ hipError_t launch_conv16(const Conv16Args& a, hipStream_t s) {
     // for three of them); else per-clip column tiles with the waves stacked over the rows
     const long long xbytes = (long long)a.w.Kp * a.Tin * 2 * a.B, ybytes = (long long)round_up(a.M, 16) * a.Tout * 2 * a.B;
     const bool flat = a.Tout < 512 && xbytes < H_OOB && ybytes < H_OOB;
+    // the strided layers' own kernel (x through LDS): 2 * stride taps, stride 4 / 5 / 8, no residual, at least 256 rows
+    const bool staged = a.ks == 2 * a.stride && a.pad == a.stride && (a.ks == 8 || a.ks == 10 || a.ks == 16) && !a.resid && a.M >= 256 && ybytes < H_OOB &&
+                        (a.Tout > 64 || xbytes < H_OOB);
     std::string name;
     if (prof::enabled())
-        name = "conv16<k" + std::to_string(a.ks) + ",s" + std::to_string(a.stride) + "," + std::to_string(a.M) + "x" + std::to_string(a.w.K) + (flat ? ",flat>" : ">");
+        name = "conv16<k" + std::to_string(a.ks) + ",s" + std::to_string(a.stride) + "," + std::to_string(a.M) + "x" + std::to_string(a.w.K) +
+               (staged ? ",lds>" : (flat ? ",flat>" : ">"));
     const double Bd = a.B, M = a.M;
     prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * a.ks * (double)a.w.K * a.Tout,
                    Bd * (2.0 * a.w.Kp * a.Tin + (a.resid ? 2.0 : 0.0) * M * a.Tout + (a.Y ? 2.0 : 0.0) * M * a.Tout + (a.Yact ? 2.0 : 0.0) * M * a.Tout +
                          (a.Yf32 ? 4.0 : 0.0) * M * a.Tout));
+    if (staged) {
+        const bool sh = a.Tout <= 64;
+        if (a.ks == 8) return sh ? conv16s_launch<8, true>(a, s) : conv16s_launch<8, false>(a, s);
+        if (a.ks == 10) return sh ? conv16s_launch<10, true>(a, s) : conv16s_launch<10, false>(a, s);
+        return sh ? conv16s_launch<16, true>(a, s) : conv16s_launch<16, false>(a, s);
+    }
     if (flat) {
         const int wgm = a.M >= 512 ? 1 : (a.M >= 128 ? 2 : 1), wgn = 4 / wgm;
         const long long ncb = ((long long)a.B * a.Tout + 64 * wgn - 1) / (64 * wgn), nmb = (a.M + 64 * wgm - 1) / (64 * wgm);
@@ -881,7 +1060,7 @@ hipError_t launch_spec16(const Spec16Args& a, hipStream_t s) {
     if (!a.wav || !a.resid || (!a.Y && !a.Yact) || !a.cosw.wq || !a.sinw.wq || !a.cosl.wq || !a.sinl.wq || !a.pw.wq || a.B < 1 || a.T < 1) return hipErrorInvalidValue;
     const int N = a.n_fft;
     if (a.Tf != (a.T + a.hop - 1) / a.hop || a.pw.M != N || a.pw.K != N / 2 + 1 || a.pw.Mp != N || a.pw.Kp != N / 2 + 16 || a.cosw.M != N / 2 || a.cosw.K != N ||
-        a.sinw.M != N / 2 || a.sinw.K != N || a.cosw.Mp != N / 2 || a.sinw.Mp != N / 2 || a.cosw.nchunks != N / 16 || a.sinw.nchunks != N / 16)
+        a.sinw.M != N / 2 || a.sinw.K != N || a.cosw.Mp != N / 2 || a.sinw.Mp != N / 2 || a.cosw.nchunks < N / 16 || a.sinw.nchunks < N / 16 || a.cosl.nchunks < N / 16 || a.sinl.nchunks < N / 16)
         return hipErrorNotSupported;
     if ((long long)N * a.Tf * 2 >= H_OOB || !al16(a.resid) || (a.Y && !al16(a.Y)) || (a.Yact && !al16(a.Yact))) return hipErrorNotSupported;
     if (N == 64 && a.hop == 1) return spec16_launch<SP<64, 1>>(a, s);

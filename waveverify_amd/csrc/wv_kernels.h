@@ -94,7 +94,7 @@ inline std::vector<float> pack_ct_wt(const float* w, int K, int Kp, int ratio) {
 
 // ---- f16-operand / f32-accumulate detector mode (wv_h16.hip).  Activations: c8 layout f16 [B][roundup(C,16)/8][T][8] ----------------
 // Weights as A fragments of v_mfma_f32_32x32x16_f16: wq[chunk][Mp][2][8] f16, chunk = (k/16) * taps + tap, element = W[m][tap][16*kc + 8*h + j];
-// Kp = roundup(K, 16), Mp = roundup(M, 32), the chunk count padded to a multiple of 4 with zero chunks.
+// Kp = roundup(K, 16), Mp = roundup(M, 32), the chunk count padded to a multiple of 8 with zero chunks.
 struct H16Weight { const void* wq = nullptr; int K = 0, M = 0, Kp = 0, Mp = 0, nchunks = 0; };
 inline uint16_t f32_to_f16_bits(float f) {                      // round to nearest even, overflow -> inf
     uint32_t x; std::memcpy(&x, &f, 4);
@@ -120,7 +120,7 @@ inline uint16_t f32_to_f16_bits(float f) {                      // round to near
 inline std::vector<uint16_t> pack_h16(const float* pw, const float* dw, int M, int K, int ks, H16Weight* out) {
     H16Weight w; w.K = K; w.M = M; w.Kp = round_up(K, 16); w.Mp = round_up(M, 32);
     const int nkc = w.Kp / 16;
-    w.nchunks = round_up(ks * nkc, 4);
+    w.nchunks = round_up(ks * nkc, 8);
     std::vector<uint16_t> q((size_t)w.nchunks * w.Mp * 16, 0);
     for (int i = 0; i < ks; ++i)
         for (int m = 0; m < M; ++m) {
