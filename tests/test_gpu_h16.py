@@ -219,7 +219,7 @@ def test_detector_f16_shapes(detector, B, T):
 
 
 @pytest.mark.parametrize("n_fft,hop,T", [(64, 1, 16000), (64, 1, 300), (64, 1, 257), (64, 1, 5), (128, 2, 16000), (128, 2, 255), (128, 2, 3), (256, 8, 16000), (256, 8, 520),
-                                         (256, 8, 7), (512, 40, 16000), (512, 40, 2600), (512, 40, 39)])
+                                         (256, 8, 7), (512, 40, 16000), (512, 40, 2600), (512, 40, 39), (1024, 320, 16000), (1024, 320, 20481), (1024, 320, 100)])
 def test_spec_block_in_one_launch(ops, n_fft, hop, T):
     """STFT (waveform split in two f16 terms, f16 basis) -> log-magnitude -> 1x1 -> add in one launch, against the oracle's exact
     composition; silence in one clip (both clamps), a loud clip, tile-edge frame counts.  What separates the two: the basis rounded to

@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
 // bin in the same register slot; sin row 0 (identically zero) carries the Nyquist bin's cos row instead.  P is written to LDS in the c8
 // layout -- the B operand of GEMM 2 = the 1x1 -- and never leaves the CU.  Epilogue 2 adds x (c8 f16 from HBM) and stores y and / or
 // ELU(act_scale * y).  (The exact path's two side rows, sin_0 and sin_{F-1} of a reference-built basis, are rounding-level and dropped.)
-// N = n_fft = rows of the 1x1 (the detector's scales: 64, 128, 256, 512), HOP in {1, 2, 4, 8 k}.  A wave's unit is 64 rows x 64 frames
+// N = n_fft = rows of the 1x1 (the detector's scales: 64, 128, 256, 512; 1024 = spec_post, whose output goes on in f32), HOP in {1, 2, 4, 8 k}.  A wave's unit is 64 rows x 64 frames
 // (one cos/sin tile pair in GEMM 1, two row tiles in GEMM 2).
 template <int N_, int HOP_>
 struct SP {
@@ -596,7 +596,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const __amdgpu_buffer_rsrc_t rCl = uniform_rsrc(p.cosl.wq, R::NC1 * (N / 2) * 32);
     const __amdgpu_buffer_rsrc_t rSl = uniform_rsrc(p.sinl.wq, R::NC1 * (N / 2) * 32);
     // ================= GEMM 1 + log-magnitude -> P16 =================
-#pragma unroll
     for (int pass = 0; pass < R::PASSES; ++pass) {
         const int u = wave + 4 * pass, mp = u % NP, nq = u / NP;
         const int avoff = ((32 * mp + r) * 2 + h) * 16;
@@ -677,7 +676,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const __amdgpu_buffer_rsrc_t rR = uniform_rsrc(reinterpret_cast<const h16*>(p.resid) + b * yclip, (int)(yclip * 2));
     const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(p.Y ? reinterpret_cast<h16*>(p.Y) + b * yclip : reinterpret_cast<const h16*>(p.resid), p.Y ? (int)(yclip * 2) : 0);
     const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(p.Yact ? reinterpret_cast<h16*>(p.Yact) + b * yclip : reinterpret_cast<const h16*>(p.resid), p.Yact ? (int)(yclip * 2) : 0);
-#pragma unroll
     for (int pass = 0; pass < R::PASSES; ++pass) {
         const int u = wave + 4 * pass, mp = u % NP, nq = u / NP;
         int avoff[2];
@@ -736,6 +734,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu1(y[rr] * p.act_scale);
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rA, off, 0, 0);
                     }
+                    if (p.Yf32 && t < Tf) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) p.Yf32[((size_t)b * N + mrow + rr) * Tf + t] = y[rr];
+                    }
                 }
             }
     }
@@ -759,7 +761,7 @@ hipError_t spec16_launch(const Spec16Args& a, hipStream_t s) {
     if (prof::enabled()) name = "spec16<" + std::to_string(R::N) + ",hop" + std::to_string(R::HOP) + ">";
     const double Bd = a.B, Tf = a.Tf, Nn = R::N;
     prof::Scope ps(s, name.c_str(), Bd * Tf * (2.0 * 2.0 * (Nn + 2.0) * Nn + 2.0 * Nn * (Nn / 2 + 1)),
-                   Bd * (4.0 * a.T + 2.0 * Nn * Tf * (1.0 + (a.Y ? 1.0 : 0.0) + (a.Yact ? 1.0 : 0.0))));
+                   Bd * (4.0 * a.T + 2.0 * Nn * Tf * (1.0 + (a.Y ? 1.0 : 0.0) + (a.Yact ? 1.0 : 0.0) + (a.Yf32 ? 2.0 : 0.0))));
     hipLaunchKernelGGL((spec16_kernel<R>), dim3((unsigned)grid), dim3(256), R::SMEM, s, a);
     return hipGetLastError();
 }
@@ -1057,7 +1059,7 @@ hipError_t launch_conv16(const Conv16Args& a, hipStream_t s) {
 }
 
 hipError_t launch_spec16(const Spec16Args& a, hipStream_t s) {
-    if (!a.wav || !a.resid || (!a.Y && !a.Yact) || !a.cosw.wq || !a.sinw.wq || !a.cosl.wq || !a.sinl.wq || !a.pw.wq || a.B < 1 || a.T < 1) return hipErrorInvalidValue;
+    if (!a.wav || !a.resid || (!a.Y && !a.Yact && !a.Yf32) || !a.cosw.wq || !a.sinw.wq || !a.cosl.wq || !a.sinl.wq || !a.pw.wq || a.B < 1 || a.T < 1) return hipErrorInvalidValue;
     const int N = a.n_fft;
     if (a.Tf != (a.T + a.hop - 1) / a.hop || a.pw.M != N || a.pw.K != N / 2 + 1 || a.pw.Mp != N || a.pw.Kp != N / 2 + 16 || a.cosw.M != N / 2 || a.cosw.K != N ||
         a.sinw.M != N / 2 || a.sinw.K != N || a.cosw.Mp != N / 2 || a.sinw.Mp != N / 2 || a.cosw.nchunks < N / 16 || a.sinw.nchunks < N / 16 || a.cosl.nchunks < N / 16 || a.sinl.nchunks < N / 16)
@@ -1067,6 +1069,7 @@ hipError_t launch_spec16(const Spec16Args& a, hipStream_t s) {
     if (N == 128 && a.hop == 2) return spec16_launch<SP<128, 2>>(a, s);
     if (N == 256 && a.hop == 8) return spec16_launch<SP<256, 8>>(a, s);
     if (N == 512 && a.hop == 40) return spec16_launch<SP<512, 40>>(a, s);
+    if (N == 1024 && a.hop == 320) return spec16_launch<SP<1024, 320>>(a, s);
     return hipErrorNotSupported;
 }
 

@@ -144,9 +144,10 @@ struct Conv16Args {           // y = out_scale * (bias + conv(x)) + resid; x, re
 hipError_t launch_conv16(const Conv16Args& a, hipStream_t s);
 // whole SpecBlock (STFT on the f16 pipe with a two-term split of the waveform -> log-magnitude -> 1x1 -> + x), the spectrogram stays in LDS.
 // cosw / sinw: the basis' cos rows f = 0 .. n_fft/2 - 1 and sin rows (row 0 = the Nyquist bin's cos row) as A fragments (pack_stft16);
-// pw: the 1x1 [n_fft][F] with K padded to n_fft/2 + 16.  (n_fft, hop) in {(64,1), (128,2), (256,8), (512,40)}, else hipErrorNotSupported.
+// pw: the 1x1 [n_fft][F] with K padded to n_fft/2 + 16.  (n_fft, hop) in {(64,1), (128,2), (256,8), (512,40), (1024,320)}, else hipErrorNotSupported.
 struct Spec16Args {
     const float* wav; H16Weight cosw, sinw, cosl, sinl, pw; const void* resid; void* Y; void* Yact;   // cosl / sinl: (basis - f16(basis)) * 2^11
+    float* Yf32;          // [B][n_fft][Tf] f32 row-major copy of y, or null
     float out_scale, act_scale, c1, c0; int B, T, Tf, n_fft, hop;
 };
 hipError_t launch_spec16(const Spec16Args& a, hipStream_t s);

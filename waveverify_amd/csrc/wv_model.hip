@@ -87,7 +87,7 @@ struct wv_model {
     // ---- f16 mode of the detector (wv_h16.hip): A-fragment weights per encoder stage -- the ResnetBlocks' 1x1 pairs, the SpecBlock's
     // 1x1 over the zero-padded spectrum rows, the downsample unit's 1x1 and depth-wise conv composed into one [M][2r][K] conv
     struct H16Stage { std::vector<std::pair<wv::H16Weight, wv::H16Weight>> blocks; wv::H16Weight spec, down, cosw, sinw, cosl, sinl; };
-    std::vector<H16Stage> h16;
+    std::vector<H16Stage> h16;                    // n_strides stages; one more when spec_post runs on the f16 pipe too (only its spec / cos / sin members)
 
     ~wv_model() { for (void* p : dev) (void)hipFree(p); }
 };
@@ -467,6 +467,18 @@ int pack_model(wv_model* m) {
             }
             m->h16.push_back(std::move(st));
         }
+        if (U.err == WV_OK && C == m->specs[S].n_fft && C == 1024 && m->specs[S].hop == 320) {      // spec_post as one launch as well
+            wv_model::H16Stage st;
+            const int n_fft = m->specs[S].n_fft;
+            st.spec = U.h16(U.host("encoder.spec_post.layer.conv.conv.weight"), nullptr, C, m->specs[S].F, 1);
+            auto ov = m->stft_override.find("encoder.spec_post.spec.weight");
+            const std::vector<float> basis = ov != m->stft_override.end() ? ov->second : make_basis(n_fft);
+            std::vector<uint16_t> q4[4];
+            wv::H16Weight w4[4];
+            wv::pack_stft16(basis.data(), n_fft, q4, w4);
+            st.cosw = U.h16_up(q4[0], w4[0]); st.sinw = U.h16_up(q4[1], w4[1]); st.cosl = U.h16_up(q4[2], w4[2]); st.sinl = U.h16_up(q4[3], w4[3]);
+            m->h16.push_back(std::move(st));
+        }
     }
     return U.err;
 }
@@ -606,9 +618,10 @@ Stream make_stream(char* ws, const WsLayout& L) {
 }
 
 // SEANetEncoder.forward (modules/seanet.py:883-976). Result in `latent` [B, dimension, Fr].
-// first_stage > 0: the stages before it ran elsewhere (the f16 mode); their raw output [B, C, Tl] is in the stream's buffer r[0].
+// first_stage > 0: the stages before it ran elsewhere (the f16 mode); their raw output [B, C, Tl] is in the stream's buffer r[0];
+// post_spec_done: so did spec_post (only conv_post is left).
 int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, float* latent, int B,
-                int T, char* ws, const WsLayout& L, hipStream_t st, int* Fr_out, int first_stage = 0) {
+                int T, char* ws, const WsLayout& L, hipStream_t st, int* Fr_out, int first_stage = 0, bool post_spec_done = false) {
     const wv_config& c = m->cfg;
     Stream sm = make_stream(ws, L);
     float* P = (float*)(ws + L.off_p);
@@ -642,6 +655,7 @@ int run_encoder(wv_model* m, const float* x, const float* msg, int msg_rows, flo
                 if (rc) return rc;
             }
         }
+        if (post && post_spec_done) break;
         wv::prof::set_role("enc.spec");
         const SpecLayer& sp = m->specs[s];
         wv::StftArgs sa{};
@@ -948,7 +962,7 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
 // The encoder stages of the f16 mode (wv_h16.hip): conv_pre, then per stage 2 ResnetBlocks (one launch each), the SpecBlock (STFT
 // log-magnitude in f32 as in the exact path, its 1x1 + add on the f16 pipe) and the downsample unit (one composed conv).  The last
 // downsample writes f32 [B, C, Tl] into the stream buffer r[0], where run_encoder(first_stage = n_strides) picks up.
-static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, char* ws, const WsLayout& L, hipStream_t st) {
+static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, char* ws, const WsLayout& L, hipStream_t st, bool* post_done) {
     const wv_config& c = m->cfg;
     const int S = c.n_strides;
     void* R[2] = {ws + L.off_r0, ws + L.off_r1};
@@ -995,13 +1009,36 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, cha
             LAUNCH(wv::launch_conv16(q, st));
         }
         wv::prof::set_role("enc16.down");
-        const bool last = s + 1 == S;
+        const bool last = s + 1 == S, post16 = (int)m->h16.size() > S;
         wv::Conv16Args g{};
-        g.X = A0; g.w = hs.down; g.bias = d.dw_b; g.resid = nullptr; g.Y = last ? nullptr : R[cur ^ 1]; g.Yact = nullptr;
-        g.Yf32 = last ? (float*)R[0] : nullptr; g.out_scale = 1.f; g.act_scale = 0.f;
+        g.X = A0; g.w = hs.down; g.bias = d.dw_b; g.resid = nullptr; g.Y = (last && !post16) ? nullptr : R[cur ^ 1]; g.Yact = nullptr;
+        g.Yf32 = (last && !post16) ? (float*)R[0] : nullptr; g.out_scale = 1.f; g.act_scale = 0.f;
         g.B = B; g.M = 2 * C; g.Tin = Tl; g.Tout = (Tl + d.ratio - 1) / d.ratio; g.ks = 2 * d.ratio; g.stride = d.ratio; g.pad = d.ratio;
         LAUNCH(wv::launch_conv16(g, st));
         cur ^= 1; Tl = g.Tout; C *= 2;
+    }
+    *post_done = false;
+    if ((int)m->h16.size() > S) {
+        // spec_post (seanet.py:781-795) on the f16 pipe as well: x from the c8 buffer, x' = x + scale * (W @ P) out in f32 for conv_post.
+        // (x sits in R[cur]; when that is R[0] the f32 result, twice the bytes, goes through R[1] and is copied over.)
+        wv::prof::set_role("enc16.spec_post");
+        const SpecLayer& sp = m->specs[S];
+        const wv_model::H16Stage& hs = m->h16[S];
+        wv::Spec16Args f{};
+        f.wav = x; f.cosw = hs.cosw; f.sinw = hs.sinw; f.cosl = hs.cosl; f.sinl = hs.sinl; f.pw = hs.spec; f.resid = R[cur]; f.Y = nullptr; f.Yact = nullptr;
+        f.Yf32 = (float*)R[cur ^ 1];
+        f.out_scale = sp.scale; f.act_scale = 0.f; f.c1 = 0.5f * 0.6931471805599453f * sp.inv_std; f.c0 = -sp.mean * sp.inv_std;
+        f.B = B; f.T = T; f.Tf = Tl; f.n_fft = sp.n_fft; f.hop = sp.hop;
+        if ((T + sp.hop - 1) / sp.hop != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");
+        const hipError_t fe = wv::launch_spec16(f, st);
+        if (fe == hipSuccess) {
+            if ((cur ^ 1) != 0) LAUNCH(hipMemcpyAsync(R[0], R[1], (size_t)B * C * Tl * sizeof(float), hipMemcpyDeviceToDevice, st));
+            *post_done = true;
+            return WV_OK;
+        }
+        if (fe != hipErrorNotSupported) return fail(WV_EHIP, std::string("launch_spec16 (post): ") + hipGetErrorString(fe));
+        LAUNCH(wv::launch_c8_to_f32(R[cur], (float*)R[cur ^ 1], B, C, Tl, st));     // the exact path's spec_post takes it from here
+        if ((cur ^ 1) != 0) LAUNCH(hipMemcpyAsync(R[0], R[1], (size_t)B * C * Tl * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     return WV_OK;
 }
@@ -1016,12 +1053,13 @@ static int run_head_model(wv_model* m, const float* x, float* logits, float* mea
     char* w = (char*)ws;
     float* latent = (float*)(w + L.off_lat);
     int Fr = 0;
+    bool post_done = false;
     if (f16) {
         if (m->h16.empty()) return fail(WV_ESTATE, "this model has no f16 plan (detector with 64/128/256/512-channel stages, k = 5, dilation 1)");
-        rc = run_encoder_stages_f16(m, x, B, T, w, L, st);
+        rc = run_encoder_stages_f16(m, x, B, T, w, L, st, &post_done);
         if (rc) return rc;
     }
-    rc = run_encoder(m, x, nullptr, 0, latent, B, T, w, L, st, &Fr, f16 ? m->cfg.n_strides : 0);
+    rc = run_encoder(m, x, nullptr, 0, latent, B, T, w, L, st, &Fr, f16 ? m->cfg.n_strides : 0, post_done);
     if (rc) return rc;
     wv::prof::set_role("head");
     wv::HeadArgs h{};
