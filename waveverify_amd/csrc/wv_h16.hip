@@ -571,34 +571,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ntile = (Tf + BN - 1) / BN;
     const int b = blockIdx.x / ntile, t0 = (blockIdx.x - b * ntile) * BN;
 
-    // ---- the tile's waveform window, split and copied NPL times
-    {
-        const float* wb = p.wav + (size_t)b * T;
-        const int base = t0 * HOP - (N - 1);                     // wav index of window sample 0 (causal: n_fft - 1 zeros in front of the clip, conv.py:1060)
-        for (int i = tid; i < R::NPL * R::PP; i += 256) {
-            const int pi = i / R::PP, v = i - pi * R::PP;
-            h16x8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int s = base + 8 * v + pi * HOP + j;
-                const float x = (s >= 0 && s < T) ? wb[s] : 0.f;
-                hi[j] = (h16)x;
-                lo[j] = (h16)((x - (float)hi[j]) * 2048.f);
-            }
-            *reinterpret_cast<h16x8*>(Whi + (size_t)(pi * R::PSP + v) * 8) = hi;
-            *reinterpret_cast<h16x8*>(Wlo + (size_t)(pi * R::PSP + v) * 8) = lo;
-        }
-    }
-    RH_BARRIER();
-
     const __amdgpu_buffer_rsrc_t rC = uniform_rsrc(p.cosw.wq, R::NC1 * (N / 2) * 32);
     const __amdgpu_buffer_rsrc_t rS = uniform_rsrc(p.sinw.wq, R::NC1 * (N / 2) * 32);
     const __amdgpu_buffer_rsrc_t rCl = uniform_rsrc(p.cosl.wq, R::NC1 * (N / 2) * 32);
     const __amdgpu_buffer_rsrc_t rSl = uniform_rsrc(p.sinl.wq, R::NC1 * (N / 2) * 32);
+    // basis fragments: a ring NA1 chunks deep (the short GEMMs of the fine scales would otherwise pay one L2 round trip per chunk); the
+    // first pass's leading chunks are requested before the window is built
+    constexpr int NA1 = 4, AD1 = NA1 - 1;
+    h16x8 ac[NA1], as[NA1], lc[NA1], ls[NA1];
+    int avoff = ((32 * (wave % NP) + r) * 2 + h) * 16;
+    auto lda = [&](int c, int slot) {
+        const int so = c * (N / 2) * 32;
+        ac[slot] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rC, avoff, so, 0));
+        as[slot] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rS, avoff, so, 0));
+        lc[slot] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rCl, avoff, so, 0));
+        ls[slot] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rSl, avoff, so, 0));
+    };
+#pragma unroll
+    for (int c = 0; c < AD1 && c < R::NC1; ++c) lda(c, c % NA1);
+
+    // ---- the tile's waveform window, split and copied NPL times
+    {
+        const float* wb = p.wav + (size_t)b * T;
+        const int base = t0 * HOP - (N - 1);                     // wav index of window sample 0 (causal: n_fft - 1 zeros in front of the clip, conv.py:1060)
+        if constexpr (R::NPL > 1) {
+            // every sample lands in NPL copies: fetch the window once (coalesced) into the P16 area, build the copies from there
+            float* tmp = reinterpret_cast<float*>(P16);
+            static_assert((size_t)(R::WLEN + 16) * 4 <= (size_t)R::G2 * R::BN * 16, "staging area");
+            for (int i = tid; i < R::WLEN + 16; i += 256) {
+                const int s = base + i;
+                tmp[i] = (s >= 0 && s < T) ? wb[s] : 0.f;
+            }
+            RH_BARRIER();
+            for (int i = tid; i < R::NPL * R::PP; i += 256) {
+                const int pi = i / R::PP, v = i - pi * R::PP;
+                h16x8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 8 * v + pi * HOP + j;
+                    const float x = k < R::WLEN + 16 ? tmp[k] : 0.f;
+                    hi[j] = (h16)x;
+                    lo[j] = (h16)((x - (float)hi[j]) * 2048.f);
+                }
+                *reinterpret_cast<h16x8*>(Whi + (size_t)(pi * R::PSP + v) * 8) = hi;
+                *reinterpret_cast<h16x8*>(Wlo + (size_t)(pi * R::PSP + v) * 8) = lo;
+            }
+        } else {
+            for (int i = tid; i < R::PP; i += 256) {
+                h16x8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int s = base + 8 * i + j;
+                    const float x = (s >= 0 && s < T) ? wb[s] : 0.f;
+                    hi[j] = (h16)x;
+                    lo[j] = (h16)((x - (float)hi[j]) * 2048.f);
+                }
+                *reinterpret_cast<h16x8*>(Whi + (size_t)i * 8) = hi;
+                *reinterpret_cast<h16x8*>(Wlo + (size_t)i * 8) = lo;
+            }
+        }
+    }
+    RH_BARRIER();
+
     // ================= GEMM 1 + log-magnitude -> P16 =================
     for (int pass = 0; pass < R::PASSES; ++pass) {
         const int u = wave + 4 * pass, mp = u % NP, nq = u / NP;
-        const int avoff = ((32 * mp + r) * 2 + h) * 16;
+        if (pass > 0) {
+            avoff = ((32 * mp + r) * 2 + h) * 16;
+#pragma unroll
+            for (int c = 0; c < AD1 && c < R::NC1; ++c) lda(c, c % NA1);
+        }
         int boff[2];                                             // piece index of chunk 0's B fragment, per frame tile
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -610,25 +652,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { are[e][i] = 0.f; aim[e][i] = 0.f; lre[e][i] = 0.f; lim[e][i] = 0.f; }
-        h16x8 ac[2], as[2], lc[2], ls[2];
-        auto lda = [&](int c, h16x8& c_, h16x8& s_, h16x8& cl_, h16x8& sl_) {
-            const int so = c * (N / 2) * 32;
-            c_ = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rC, avoff, so, 0));
-            s_ = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rS, avoff, so, 0));
-            cl_ = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rCl, avoff, so, 0));
-            sl_ = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rSl, avoff, so, 0));
-        };
-        lda(0, ac[0], as[0], lc[0], ls[0]);
 #pragma unroll
         for (int c = 0; c < R::NC1; ++c) {
-            if (c + 1 < R::NC1) lda(c + 1, ac[(c + 1) & 1], as[(c + 1) & 1], lc[(c + 1) & 1], ls[(c + 1) & 1]);
+            if (c + AD1 < R::NC1) lda(c + AD1, (c + AD1) % NA1);
             h16x8 bh[2], bl[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 bh[e] = *reinterpret_cast<const h16x8*>(Whi + (size_t)(boff[e] + 2 * c) * 8);
                 bl[e] = *reinterpret_cast<const h16x8*>(Wlo + (size_t)(boff[e] + 2 * c) * 8);
             }
-            const h16x8 a_c = ac[c & 1], a_s = as[c & 1], l_c = lc[c & 1], l_s = ls[c & 1];
+            const h16x8 a_c = ac[c % NA1], a_s = as[c % NA1], l_c = lc[c % NA1], l_s = ls[c % NA1];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 are[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_c, bh[e], are[e], 0, 0, 0);
@@ -678,9 +711,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(p.Yact ? reinterpret_cast<h16*>(p.Yact) + b * yclip : reinterpret_cast<const h16*>(p.resid), p.Yact ? (int)(yclip * 2) : 0);
     for (int pass = 0; pass < R::PASSES; ++pass) {
         const int u = wave + 4 * pass, mp = u % NP, nq = u / NP;
-        int avoff[2];
+        int avw[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) avoff[mt] = ((64 * mp + 32 * mt + r) * 2 + h) * 16;
+        for (int mt = 0; mt < 2; ++mt) avw[mt] = ((64 * mp + 32 * mt + r) * 2 + h) * 16;
         const h16* Bp = P16 + (size_t)(h * BN + 64 * nq + r) * 8;
         f32x16 acc[2][2];
 #pragma unroll
@@ -689,23 +722,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][e][i] = 0.f;
-        h16x8 aw[2][2];
+        constexpr int NA2 = 4, AD2 = NA2 - 1;
+        h16x8 aw[NA2][2];
         auto ldw = [&](int c, h16x8 (&d)[2]) {
             const int so = c * N * 32;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) d[mt] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, avoff[mt], so, 0));
+            for (int mt = 0; mt < 2; ++mt) d[mt] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, avw[mt], so, 0));
         };
-        ldw(0, aw[0]);
+#pragma unroll
+        for (int c = 0; c < AD2 && c < R::NC2; ++c) ldw(c, aw[c % NA2]);
 #pragma unroll
         for (int c = 0; c < R::NC2; ++c) {
-            if (c + 1 < R::NC2) ldw(c + 1, aw[(c + 1) & 1]);
+            if (c + AD2 < R::NC2) ldw(c + AD2, aw[(c + AD2) % NA2]);
             h16x8 bb[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) bb[e] = *reinterpret_cast<const h16x8*>(Bp + (size_t)(2 * c * BN + 32 * e) * 8);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw[c & 1][mt], bb[e], acc[mt][e], 0, 0, 0);
+                for (int e = 0; e < 2; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw[c % NA2][mt], bb[e], acc[mt][e], 0, 0, 0);
             asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -936,15 +971,19 @@ hipError_t conv16s_launch(const Conv16Args& a, hipStream_t s) {
 }
 
 // conv_pre (SConv1d 1 -> C, k taps, causal; modules/seanet.py:657-663) straight into the c8 layout: a thread owns one time step and
-// walks the channel groups (a wave's store of one group is 1 KB contiguous).
+// walks the channel groups (a wave's store of one group is 1 KB contiguous).  KS > 0: the tap count at compile time (the taps of a
+// group arrive as a few wide scalar loads instead of one load and one wait per tap).
+template <int KS>
 __global__ __launch_bounds__(256) void conv_pre16_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                         h16* __restrict__ Y, int C, int T, int ks, float in_scale) {
+                                                         h16* __restrict__ Y, int C, int T, int ks_rt, float in_scale) {
+    const int ks = KS > 0 ? KS : ks_rt;
+    constexpr int NX = KS > 0 ? KS : 16;
     const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
     const float* xb = x + (size_t)b * T;
-    float xv[16];
+    float xv[NX];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NX; ++i) {
         const int ti = t - (ks - 1) + i;
         xv[i] = (i < ks && ti >= 0) ? xb[ti] * in_scale : 0.f;
     }
@@ -956,7 +995,7 @@ __global__ __launch_bounds__(256) void conv_pre16_kernel(const float* __restrict
             const int c = 8 * g + j;
             float y = bias ? bias[c] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
+            for (int i = 0; i < NX; ++i)
                 if (i < ks) y = fmaf(w[c * ks + i], xv[i], y);
             o[j] = (h16)y;
         }
@@ -1076,7 +1115,9 @@ hipError_t launch_spec16(const Spec16Args& a, hipStream_t s) {
 hipError_t launch_conv_pre16(const float* x, const float* w, const float* bias, void* Y, int B, int C, int T, int ks, float in_scale, hipStream_t s) {
     if (!x || !w || !Y || B < 1 || C < 8 || (C % 8) || T < 1 || ks < 1 || ks > 16 || B > 65535) return hipErrorInvalidValue;
     prof::Scope ps(s, "conv_pre16", 2.0 * B * C * ks * (double)T, (double)B * T * (4.0 + 2.0 * C));
-    hipLaunchKernelGGL(conv_pre16_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, x, w, bias, reinterpret_cast<h16*>(Y), C, T, ks, in_scale);
+    if (ks == 7) hipLaunchKernelGGL(conv_pre16_kernel<7>, dim3((T + 255) / 256, B), dim3(256), 0, s, x, w, bias, reinterpret_cast<h16*>(Y), C, T, ks, in_scale);
+    else if (ks == 5) hipLaunchKernelGGL(conv_pre16_kernel<5>, dim3((T + 255) / 256, B), dim3(256), 0, s, x, w, bias, reinterpret_cast<h16*>(Y), C, T, ks, in_scale);
+    else hipLaunchKernelGGL(conv_pre16_kernel<0>, dim3((T + 255) / 256, B), dim3(256), 0, s, x, w, bias, reinterpret_cast<h16*>(Y), C, T, ks, in_scale);
     return hipGetLastError();
 }
 
