@@ -22,7 +22,9 @@ the launch stream, ~190 pairs per step), whose own wall time is reported as `pro
 
 Other workloads (--workload): longform (configs[3]), detector_stress (configs[4]) and grad_allreduce
 (configs[2]: the training step's only exchange, a bucketed RCCL all-reduce of 56.1 + 170.1 MB of fp32
-gradients; reports ms per all-reduce and bus GB/s).
+gradients; reports ms per all-reduce and bus GB/s).  `--workload detector_stress --precision f16` runs the
+detector's f16-operand / f32-accumulate mode (configs[4] as BASELINE words it) and prints ITS OWN line: dtype "f16",
+the exact-f32 mode timed beside it, both modes' mean probabilities against each other and against the oracle.
 """
 from __future__ import annotations
 
@@ -40,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16 / bf16 (v_mfma_f32_32x32x16_f16, 32 cycles per SIMD)
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
@@ -59,6 +62,9 @@ def parse():
                          "only); grad_allreduce = configs[2]'s gradient exchange (no model compute); train_step = the "
                          "part of configs[2]'s training step that runs on the HIP training units (G+D+L, 64 clips per GPU)")
     ap.add_argument("--bucket-mb", type=float, default=25.0, help="grad_allreduce: bucket size")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
+                    help="detector_stress only: f16 = the detector's f16-operand / f32-accumulate mode (csrc/wv_h16.hip), its own line with "
+                         "its own parity block and roofs; the headline and every other workload are exact f32")
     return ap.parse_args()
 
 
@@ -320,6 +326,9 @@ def main():
         a.batch, a.seconds = (32 if a.batch == 256 else a.batch), (30.0 if a.seconds == 1.0 else a.seconds)
     elif a.workload == "detector_stress":
         a.batch = 1024 if a.batch == 256 else a.batch
+    if a.precision != "f32" and a.workload != "detector_stress":
+        raise SystemExit("--precision f16 exists for --workload detector_stress only (BASELINE.json configs[4]); the headline is exact f32")
+    f16 = a.precision == "f16"
     T = int(round(a.seconds * 16000))
     B = a.batch
     cfgG, cfgD = default_config("generator"), default_config("detector")
@@ -334,7 +343,7 @@ def main():
 
     def step():
         if a.workload == "detector_stress":
-            mp = D.detector_mean_prob(x)
+            mp = D.detector_mean_prob(x, precision=a.precision)
             return x, mp, mp >= 0.5
         wm = G.generator(x, msg, add_input=True)
         if Lnet is not None:
@@ -412,11 +421,15 @@ def main():
 
     # which roof bounds the dominant kernel: its algorithmic arithmetic intensity against the f32-matrix ridge
     dom_ai = dom["flops"] / max(dom["bytes"], 1.0)
-    ridge = PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)          # 19.7 FLOP/B
+    # the matrix roof of the pipe the dominant kernel runs on: the f16 mode's own kernels (conv_pre16, resblock16, spec16, conv16) on the
+    # f16 pipe, everything else (incl. the f32 tail of the f16 mode) on the f32 pipe
+    on_f16 = f16 and ("16" in dom_name.split("<")[0])
+    peak_mfma = PEAK_F16_MFMA_TFLOPS if on_f16 else PEAK_F32_MFMA_TFLOPS
+    ridge = peak_mfma * 1e12 / (PEAK_HBM_GBS * 1e9)                    # 19.7 FLOP/B (f32), 312 FLOP/B (f16)
     gbs_dom = dom["bytes"] / dom["launches"] / dom_avg_s / 1e9
     if dom_ai >= ridge:
-        roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4))
+        roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak_mfma, unit="TFLOP/s",
+                    frac=round(ach / peak_mfma, 4))
     else:
         roof = dict(bound="hbm", achieved=round(gbs_dom, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                     frac=round(gbs_dom / PEAK_HBM_GBS, 4))
@@ -458,11 +471,13 @@ def main():
     metric = {"embed_detect": "clips/sec embed+detect, 1s@16kHz bs=256",
               "longform": "clips/sec embed+locate+detect, 30s@16kHz bs=32",
               "detector_stress": "clips/sec detect, 1s@16kHz bs=1024"}[a.workload]
+    if f16:
+        metric = "clips/sec detect (f16-operand / f32-accumulate mode), 1s@16kHz bs=1024"
     step_flops = sum(v["flops"] for v in by_kernel.values()) / a.steps
     out = dict(metric=metric, value=round(world * B * a.steps / elapsed, 2),
                unit="clips/s", n_gpus=world, rccl_ranks=dist.get_world_size() if dist else 0, steps=a.steps, warmup=a.warmup,
                ms_per_step=round(elapsed / a.steps * 1e3, 3), higher_is_better=True, scaling="weak",
-               vs_baseline=None, dtype="f32", data="synthetic",
+               vs_baseline=None, dtype="f16" if f16 else "f32", data="synthetic",
                config=dict(workload=f"{a.workload}: {B} clips x {a.seconds:g} s @ 16 kHz per GPU "
                                     f"(BASELINE.json configs[{dict(embed_detect=1, longform=3, detector_stress=4)[a.workload]}]), "
                                     "seeded random weights",
@@ -483,6 +498,35 @@ def main():
             wm_max_abs_err=float(np.abs(wm[:n].cpu().numpy() - wm_ref).max()),
             mean_prob_max_abs_err=float(np.abs(mp[:n].cpu().numpy() - mp_ref).max()),
             ber_vs_oracle=float(((mp_ref >= 0.5) != bits[:n].cpu().numpy()).mean()))
+    if f16:
+        # The mode's own evidence: the exact-f32 detector of this library on the same K steps (same input, same weights), the two modes'
+        # mean probabilities against each other on the whole batch, and both against the torch-CPU port of the reference on a sample.
+        def step32():
+            return D.detector_mean_prob(x)
+        step32()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(a.steps):
+            mp32 = step32()
+        torch.cuda.synchronize(); e32 = time.perf_counter() - t0
+        d = (mp - mp32).abs()
+        margin = (mp32 - 0.5).abs()
+        out["vs_f32_mode"] = dict(f32_clips_per_s=round(B * a.steps / e32, 2), f32_ms_per_step=round(e32 / a.steps * 1e3, 3),
+                                  speedup=round(e32 / elapsed, 3), mean_prob_max_abs_diff=float(d.max()),
+                                  bits_compared=int(mp.numel()), bits_differ=int(((mp >= 0.5) != (mp32 >= 0.5)).sum()),
+                                  min_margin_f32=float(margin.min()),
+                                  bits_with_margin_above_4x_diff=int((margin > 4 * float(d.max())).sum()))
+        if not a.no_cpu_baseline and world == 1:
+            from oracle import wv_oracle_torch as OT
+            n = min(a.cpu_clips, B)
+            torch.set_num_threads(min(os.cpu_count() or 1, 16))
+            mp_ref = OT.mean_probabilities(OT.detector_logits(OT.Net(cfgD, sdD), x_np[:n])).numpy()
+            got = mp[:n].cpu().numpy()
+            err = float(np.abs(got - mp_ref).max())
+            mg = np.abs(mp_ref - 0.5)
+            out["parity"] = dict(clips_checked=n, mean_prob_max_abs_err=err, ber_vs_oracle=float(((mp_ref >= 0.5) != (got >= 0.5)).mean()),
+                                 bits_decidable_at_4x_err=int((mg > 4 * err).sum()), bits=int(mg.size),
+                                 note="torch-CPU port of the reference detector on the first clips of the batch; the golden-fixture checks "
+                                      "(reference outputs, incl. the narrow-margin detector) are tests/test_gpu_h16.py")
     print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
