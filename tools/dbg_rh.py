@@ -1,3 +1,5 @@
+"""resblock16 (csrc/wv_h16.hip): its three output variants against each other, run to run -- how the DPP wait-state hazard in the
+stencils was found (a 128-register build differed in one lane pair per row group, differently each run).  python tools/dbg_rh.py <C> <T>"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

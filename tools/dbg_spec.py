@@ -1,3 +1,5 @@
+"""spec16 (csrc/wv_h16.hip) with an identity 1x1: the log-magnitude feature P per bin and frame against the oracle -- how the two-term
+split's leakage into weak DC / Nyquist bins and the n_fft - hop padding slip were found.  python tools/dbg_spec.py <n_fft> <hop>"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
