@@ -207,6 +207,7 @@ int wv_op_spec_block(const float* wav, const float* basis_or_null, const float* 
  *                     (the default detector's scales), else WV_EINVAL; x16 / Y16 / Yact16 c8 f16 [B, M/8, ceil(T/hop), 8]
  *   wv_detector_forward_f16   Detector.forward (model/detector.py:366-391) in this mode: conv_pre .. the last downsample in f16,
  *                     the STFTs, spec_post, conv_post and the head in f32 (same workspace as wv_detector_forward). */
+int wv_h16_round_host(const float* in, uint16_t* out, int64_t n);   /* HOST pointers: the weight packers' f32 -> f16 rounding (nearest even) */
 int wv_h16_from_f32(const float* X, void* Y16, int B, int C, int T, float scale, int elu, void* stream);
 int wv_h16_to_f32(const void* X16, float* Y, int B, int C, int T, void* stream);
 int wv_h16_conv_pre(const float* x, const float* w, const float* bias, void* Y16, int B, int C, int T, int ks, float in_scale, void* stream);

@@ -359,3 +359,26 @@ def test_to_parametrized_is_weight_norm_of_the_same_weights():
         assert float((back - torch.from_numpy(w)).abs().max()) <= 1e-6 * float(np.abs(w).max())
     again = to_parametrized(live, cfg)
     assert all(torch.equal(again[k], live[k]) for k in live)
+
+
+def test_f16_rounding_of_the_weight_packers():
+    """The f16 mode packs its weights on the host: f32 -> f16 round-to-nearest-even, bit for bit numpy's (normals, ties, subnormals,
+    overflow to inf, signed zeros, inf / nan)."""
+    import ctypes as C
+    from waveverify_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    vals = [rng.standard_normal(20000).astype(np.float32), (rng.standard_normal(5000) * 1e-5).astype(np.float32),
+            (rng.standard_normal(5000) * 3e4).astype(np.float32), (rng.standard_normal(2000) * 1e-7).astype(np.float32)]
+    halves = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16).astype(np.float32)          # every finite f16 ...
+    ties = (halves[:-1] + halves[1:]) * np.float32(0.5)                                        # ... and every midpoint between neighbours
+    special = np.array([0.0, -0.0, np.inf, -np.inf, 65504.0, 65519.99, 65520.0, 1e9, -1e9, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.0001, 6.1e-5], np.float32)
+    x = np.concatenate(vals + [halves, -halves, ties, -ties, special])
+    out = np.empty(x.size, np.uint16)
+    assert lib.wv_h16_round_host(x.ctypes.data, out.ctypes.data, C.c_int64(x.size)) == 0
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(out, ref), np.flatnonzero(out != ref)[:10]
+    nan = np.array([np.nan], np.float32)
+    o = np.empty(1, np.uint16)
+    assert lib.wv_h16_round_host(nan.ctypes.data, o.ctypes.data, C.c_int64(1)) == 0 and np.isnan(o.view(np.float16)[0])

@@ -143,6 +143,7 @@ SIGNATURES = {
     "wv_train_last_error": (C.c_char_p, []),
     "wv_train_fold_weight": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP]),
     "wv_op_spec_block": (C.c_int, [_VP] * 6 + [C.c_int] * 5 + [C.c_float] * 4 + [_VP]),
+    "wv_h16_round_host": (C.c_int, [_VP, _VP, C.c_int64]),
     "wv_h16_from_f32": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _VP]),
     "wv_h16_to_f32": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP]),
     "wv_h16_conv_pre": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _VP]),

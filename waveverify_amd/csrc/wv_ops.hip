@@ -99,6 +99,12 @@ int wv_op_resblock(const float* X, float pre_scale, const float* w_pw1, const fl
 }
 
 // ---- the f16 mode's units (wv_h16.hip): activations in the c8 f16 layout, weights as HOST f32 pointers in the reference's layouts
+// host-side f32 -> f16 rounding the weight packers use (round to nearest even; no device needed)
+int wv_h16_round_host(const float* in, uint16_t* out, int64_t n) {
+    if (!in || !out || n < 0) return WV_EINVAL;
+    for (int64_t i = 0; i < n; ++i) out[i] = wv::f32_to_f16_bits(in[i]);
+    return WV_OK;
+}
 int wv_h16_from_f32(const float* X, void* Y16, int B, int C, int T, float scale, int elu, void* stream) {
     Tmp t;
     return done(t, wv::launch_f32_to_c8(X, Y16, B, C, T, scale, elu, (hipStream_t)stream), (hipStream_t)stream);
