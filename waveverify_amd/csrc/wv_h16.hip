@@ -722,6 +722,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][e][i] = 0.f;
+        // the residual operand, requested ahead of the matrix loop (nothing it depends on): its latency passes under GEMM 2
+        h16x4 xr[2][4][2];
+        int xoff[2][4][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int mrow = 64 * mp + 32 * mt + 8 * j + 4 * h, t = t0 + 64 * nq + 32 * e + r;
+                    const int off = t < Tf ? ((mrow >> 3) * Tf + t) * 16 + 8 * h : H_OOB;
+                    xoff[mt][j][e] = off;
+                    xr[mt][j][e] = __builtin_bit_cast(h16x4, __builtin_amdgcn_raw_buffer_load_b64(rR, off, 0, 0));
+                }
         constexpr int NA2 = 4, AD2 = NA2 - 1;
         h16x8 aw[NA2][2];
         auto ldw = [&](int c, h16x8 (&d)[2]) {
@@ -752,8 +766,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int t = t0 + 64 * nq + 32 * e + r;
-                    const int off = t < Tf ? ((mrow >> 3) * Tf + t) * 16 + 8 * h : H_OOB;
-                    const h16x4 xv = __builtin_bit_cast(h16x4, __builtin_amdgcn_raw_buffer_load_b64(rR, off, 0, 0));
+                    const int off = xoff[mt][j][e];
+                    const h16x4 xv = xr[mt][j][e];
                     float y[4];
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) y[rr] = fmaf(acc[mt][e][4 * j + rr], p.out_scale, (float)xv[rr]);
