@@ -2,8 +2,8 @@
 # All rocprofv3 / bench evidence of a round in one go (run on the GPU box from the repo root):
 #   tools/profile_round.sh <outdir under gpurun_out/>
 # headline: kernel stats + separate FETCH_SIZE / WRITE_SIZE / SQ counter passes (tools/profile_bench.sh); training step: bench line +
-# kernel stats; the other workloads' bench lines; the detector's f16 mode (bench line, kernel stats, per-kernel table); the one-launch
-# ResnetBlock kernels alone (times, traffic, phase shares).
+# kernel stats; the other workloads' bench lines; the one-launch ResnetBlock kernels alone (times, traffic, phase shares).
+# (The detector's f16 mode: tools/profile_f16.sh, its own call.)
 set -e
 out=$GRAFT_REPO_ROOT/$1
 mkdir -p $out
@@ -24,11 +24,6 @@ python3 bench.py --workload train_step --steps 10 --warmup 3 > $out/train_step_b
   echo "## grad_allreduce, one rank (no collective is issued with one rank)"; python3 bench.py --workload grad_allreduce --steps 5 --warmup 2 2>/dev/null
 } > $out/workloads.txt
 echo "workloads done"
-# the detector's f16 mode: its bench line, kernel stats of the same command, the per-kernel table next to the exact mode
-python3 bench.py --workload detector_stress --precision f16 --steps 10 --warmup 3 > $out/bench_f16.json 2> $out/bench_f16.err
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/f16_stats -- python3 $R/bench.py --workload detector_stress --precision f16 --steps 10 --warmup 3 --no-cpu-baseline > $out/f16_stats.log 2>&1 )
-python3 tools/h16time.py > $out/h16time.txt 2>/dev/null
-echo "f16 mode done"
 python3 tools/rbbench.py > $out/rbbench.txt 2>/dev/null
 tools/rbtraffic.sh $1/rbtraffic > $out/rbtraffic.txt 2>&1
 python3 tools/pmc_traffic.py traffic $out/pmc_fetch $out/pmc_write > $out/pmc_traffic.json
