@@ -247,3 +247,27 @@ def test_spec_block_in_one_launch(ops, n_fft, hop, T):
     assert (np.abs(ga - O.elu(ref * s_act)) <= lim).all()
     only_act = ops.h16_spec_block(cu(wav), w, ops.h16_from_f32(cu(x)), n_fft, hop, mean=-4.3, std=2.8, out_scale=float(s_out), act_scale=float(s_act), want_raw=False)
     assert torch.equal(only_act, gact)
+
+
+def test_detector_f16_captures_into_a_hip_graph(detector):
+    """Like the exact path: plain launches on the caller's stream (no allocation, no sync), so the f16 forward captures into a HIP graph
+    and replays bit-identically; and it is deterministic from run to run."""
+    from waveverify_amd.init import synthetic_clips
+    x = torch.from_numpy(synthetic_clips(3, 16000, seed=9)[0]).cuda()
+    p0 = detector.detector_mean_prob(x, precision="f16")
+    assert torch.equal(detector.detector_mean_prob(x, precision="f16"), p0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        detector.detector_mean_prob(x, precision="f16")
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        p1 = detector.detector_mean_prob(x, precision="f16")
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p0)
+    p1.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p0)

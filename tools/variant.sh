@@ -10,12 +10,12 @@ objs=""
 declare -A repl
 for spec in "$@"; do
   src=${spec%%:*}; flags=${spec#*:}
-  fp=fast; case $src in wv_kernels.hip|wv_k1.hip|wv_rb.hip) fp=fast;; *) fp=off;; esac
+  fp=fast; case $src in wv_kernels.hip|wv_k1.hip|wv_rb.hip|wv_h16.hip) fp=fast;; *) fp=off;; esac
   o=tools/bin/${name}_${src%.hip}.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=$fp $flags -c waveverify_amd/csrc/$src -o $o
   repl[$src]=$o
 done
-for src in wv_kernels.hip wv_k1.hip wv_rb.hip wv_model.hip wv_ops.hip wv_train.hip wv_aug.hip wv_fx.hip; do
+for src in wv_kernels.hip wv_k1.hip wv_rb.hip wv_h16.hip wv_model.hip wv_ops.hip wv_train.hip wv_aug.hip wv_fx.hip; do
   if [ -n "${repl[$src]}" ]; then objs="$objs ${repl[$src]}"; else objs="$objs waveverify_amd/lib/${src%.hip}.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/bin/libwv_$name.so $objs

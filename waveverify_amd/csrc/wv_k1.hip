@@ -833,8 +833,11 @@ hipError_t launch_k1(const PwDwArgs& a0, hipStream_t s) {
 // log-magnitudes go to LDS as P[F][BN] (rows up to the next multiple of 16 zeroed) instead of HBM, a second GEMM W @ P runs on the same
 // 32-row strips with its A fragments loaded straight into registers (3 or 5 chunks of the k-inner layout), and the epilogue forms
 // y = resid + out_scale * (W @ P) [-> ELU(act_scale * y)] -- the values of the two-kernel path, bit for bit.
+// FUSE at 64 rows: the residual operand of the add is requested BEFORE the second GEMM (16 rows in registers, two waves per SIMD): 814 ->
+// 712 us per launch at n_fft = 64; at 128 rows the third wave per SIMD is worth more than the prefetch (1071 vs 1083 us).
 template <class C, bool FUSE>
-__global__ __launch_bounds__(C::NTHREADS, (FUSE || C::B_PER > 1) ? 3 : 4) void stft_k1_kernel(StftArgs p, SpecAddArgs q) {
+__global__ __launch_bounds__(C::NTHREADS, (FUSE && C::BM == 64) ? 2 : ((FUSE || C::B_PER > 1) ? 3 : 4)) void stft_k1_kernel(StftArgs p, SpecAddArgs q) {
+    constexpr bool PRE_RES = FUSE && C::BM == 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef typename NVec<C::NT>::type bvec;
     typedef unsigned uvec __attribute__((ext_vector_type(C::NT)));
@@ -1026,6 +1029,18 @@ __global__ __launch_bounds__(C::NTHREADS, (FUSE || C::B_PER > 1) ? 3 : 4) void s
         }
     }
     if constexpr (FUSE) {
+        bvec resA[PRE_RES ? 16 : 1];
+        if constexpr (PRE_RES) {
+            const int M_ = C::BM, blk_ = M_ * p.Tf * 4;
+            const __amdgpu_buffer_rsrc_t rR_ = uniform_rsrc(q.resid + (size_t)b * M_ * p.Tf, blk_);
+            const int voff_ = lane_ok ? ((32 * wave + 4 * h) * p.Tf + tq) * 4 : 0x7f000000;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o_ = voff_ + ((r & 3) + 8 * (r >> 2)) * p.Tf * 4;
+                if constexpr (C::NT == 4) resA[r] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b128(rR_, o_, 0, 0));
+                else resA[r] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b64(rR_, o_, 0, 0));
+            }
+        }
         __syncthreads();                                         // P complete
         // ---- second GEMM: W[M][F] @ P[F][BN] on this wave's 32-row strip (the k order of the K1 core)
 #pragma unroll
@@ -1051,19 +1066,25 @@ __global__ __launch_bounds__(C::NTHREADS, (FUSE || C::B_PER > 1) ? 3 : 4) void s
         const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(q.Yact ? q.Yact + bo : q.resid, q.Yact ? blk : 0);
         const int voff0 = lane_ok ? ((32 * wave + 4 * h) * p.Tf + tq) * 4 : 0x7f000000;
         bvec res4[4];
+        if constexpr (!PRE_RES) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if constexpr (C::NT == 4) res4[r] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b128(rR, voff0 + ((r & 3) + 8 * (r >> 2)) * p.Tf * 4, 0, 0));
-            else res4[r] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b64(rR, voff0 + ((r & 3) + 8 * (r >> 2)) * p.Tf * 4, 0, 0));
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (C::NT == 4) res4[r] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b128(rR, voff0 + ((r & 3) + 8 * (r >> 2)) * p.Tf * 4, 0, 0));
+                else res4[r] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b64(rR, voff0 + ((r & 3) + 8 * (r >> 2)) * p.Tf * 4, 0, 0));
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int off = voff0 + ((r & 3) + 8 * (r >> 2)) * p.Tf * 4;
-            const bvec rr = res4[r & 3];
-            if (r + 4 < 16) {
-                const int o4 = voff0 + (((r + 4) & 3) + 8 * ((r + 4) >> 2)) * p.Tf * 4;
-                if constexpr (C::NT == 4) res4[r & 3] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b128(rR, o4, 0, 0));
-                else res4[r & 3] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b64(rR, o4, 0, 0));
+            bvec rr;
+            if constexpr (PRE_RES) rr = resA[r];
+            else {
+                rr = res4[r & 3];
+                if (r + 4 < 16) {
+                    const int o4 = voff0 + (((r + 4) & 3) + 8 * ((r + 4) >> 2)) * p.Tf * 4;
+                    if constexpr (C::NT == 4) res4[r & 3] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b128(rR, o4, 0, 0));
+                    else res4[r & 3] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b64(rR, o4, 0, 0));
+                }
             }
             bvec y;
 #pragma unroll
