@@ -271,3 +271,20 @@ def test_detector_f16_captures_into_a_hip_graph(detector):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(p1, p0)
+
+
+def test_waveverify_api_opt_in():
+    """WaveVerify.detect_batch through the f16 mode when the caller opts in (attribute `detector_precision`); the default stays exact."""
+    from waveverify_amd.core import WaveVerify
+    from waveverify_amd.init import synthetic_clips
+    wv = WaveVerify.random_init(seed=0, device="cuda:0")
+    assert wv.detector_precision == "f32"
+    x_np, msg_np = synthetic_clips(4, 16000, seed=11)
+    wm = wv.embed_batch(torch.from_numpy(x_np).cuda(), torch.from_numpy(msg_np).cuda())
+    bits32, mp32 = wv.detect_batch(wm)
+    wv.detector_precision = "f16"
+    bits16, mp16 = wv.detect_batch(wm)
+    assert torch.equal(bits16, bits32) and float((mp16 - mp32).abs().max()) <= 2e-2 and not torch.equal(mp16, mp32)
+    wv.detector_precision = "bf16"
+    with pytest.raises(ValueError):
+        wv.detect_batch(wm)

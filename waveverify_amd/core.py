@@ -67,6 +67,9 @@ class WaveVerify:
     def _build(self, sds, cfgs) -> None:
         nets = {k: HipNet(cfgs[k], sds[k], self.device) for k in sds}
         self.configs = cfgs
+        # NOT in the reference: "f16" routes detect / detect_batch / verify through the detector's f16-operand / f32-accumulate mode
+        # (csrc/wv_h16.hip; the same bits on every fixture, ~3x the clips per second).  Opt-in only; the default is the exact path.
+        self.detector_precision = "f32"
         # .model.generator / .detector / .locator like the reference's AudioWatermarking
         self.model = SimpleNamespace(generator=nets.get("generator"), detector=nets.get("detector"),
                                      locator=nets.get("locator"))
@@ -93,7 +96,7 @@ class WaveVerify:
     @torch.no_grad()
     def detect_batch(self, audio: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (bits [B,16] int32, mean_prob [B,16]); bits = time-averaged sigmoid >= 0.5."""
-        mp = self._need("detector").detector_mean_prob(audio)
+        mp = self._need("detector").detector_mean_prob(audio, precision=self.detector_precision)
         return (mp >= 0.5).to(torch.int32), mp
 
     @torch.no_grad()
