@@ -206,7 +206,7 @@ def test_detector_f16_refuses_other_nets():
         L._head(torch.zeros(1, 1, 800, device="cuda"), True, False, precision="f16")
 
 
-@pytest.mark.parametrize("B,T", [(1, 16000), (5, 12345), (3, 333)])
+@pytest.mark.parametrize("B,T", [(1, 16000), (5, 12345), (3, 333), (1, 1), (2, 5), (2, 321), (1, 48001)])
 def test_detector_f16_shapes(detector, B, T):
     """Ragged lengths and batch sizes: finite, close to the exact path, and independent of the batch a clip sits in."""
     from waveverify_amd.init import synthetic_clips
