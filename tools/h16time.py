@@ -4,6 +4,9 @@ python tools/h16time.py"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from waveverify_amd import _lib
+if "--lib" in sys.argv:                      # an A/B variant built by tools/variant.sh
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from waveverify_amd.config import default_config
 from waveverify_amd.init import random_state_dict, synthetic_clips
 from waveverify_amd.nets import HipNet
