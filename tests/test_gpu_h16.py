@@ -288,3 +288,68 @@ def test_waveverify_api_opt_in():
     wv.detector_precision = "bf16"
     with pytest.raises(ValueError):
         wv.detect_batch(wm)
+
+
+# ---- seeded sweep of geometries the detector does not use: the generic conv (any taps / stride / pad, ragged channel counts on the f32
+# output, residual + both c8 outputs), the ResnetBlock at random lengths and batch sizes
+def _dense_conv_ref(xa, wc, bias, stride, pad, Tout):
+    """y[b][m][to] = bias[m] + sum_i sum_k wc[m][i][k] * xa[b][k][to * stride + i - pad], x = 0 outside (float64)."""
+    B, K, Tin = xa.shape
+    M, ks, _ = wc.shape
+    xp = np.zeros((B, K, pad + Tout * stride + ks + stride), np.float64)
+    xp[:, :, pad:pad + Tin] = xa
+    ref = np.zeros((B, M, Tout), np.float64)
+    for i in range(ks):
+        ref += np.einsum("mk,bkt->bmt", wc[:, i, :].astype(np.float64), xp[:, :, i:i + Tout * stride:stride][:, :, :Tout])
+    return ref + (0.0 if bias is None else bias[None, :, None])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_conv16_generic_geometries(ops, seed):
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 6))
+    K = int(rng.choice([8, 16, 24, 40, 64, 100, 144, 272]))
+    ks = int(rng.choice([1, 2, 3, 5, 7, 8, 10, 16]))
+    stride = int(rng.choice([1, 1, 2, 3, 4, 5, 8]))
+    pad = int(rng.integers(0, ks))
+    Tin = int(rng.choice([1, 2, 17, 50, 63, 64, 65, 200, 513, 1000]))
+    c8_out = bool(rng.integers(0, 2))
+    M = int(rng.choice([16, 32, 64, 96, 128, 320])) if c8_out else int(rng.choice([1, 7, 16, 33, 64, 130, 256]))
+    X = rnd(rng, B, K, Tin)
+    w_pw, w_dw = rnd(rng, M, K, 1, scale=K ** -0.5), (rnd(rng, M, 1, ks, scale=ks ** -0.5) if ks > 1 else None)
+    bias = rnd(rng, M, scale=0.1) if rng.integers(0, 2) else None
+    Tout = (Tin + stride - 1) // stride
+    wc = h(w_pw[:, :, 0][:, None, :] * (w_dw[:, 0, :][:, :, None] if w_dw is not None else 1.0))
+    xa = h(X)
+    s_out = np.float32(0.7)
+    ref = _dense_conv_ref(xa, wc, bias, stride, pad, Tout) * s_out
+    X16 = ops.h16_from_f32(cu(X))
+    if c8_out:
+        R = h(rnd(rng, B, M, Tout))
+        ref = (ref + R).astype(np.float32)
+        out = ops.h16_conv(X16, w_pw, w_dw, bias, resid16=ops.h16_from_f32(cu(R)), ks=ks, stride=stride, pad=pad, out_scale=float(s_out), act_scale=0.9,
+                           want_f32=True)
+        close(ops.h16_to_f32(out["raw"], M), h(ref), f"conv16 raw (K={K} M={M} ks={ks} s={stride} pad={pad} Tin={Tin})")
+        close(ops.h16_to_f32(out["act"], M), h(O.elu(ref * np.float32(0.9))), "conv16 act")
+        close(out["f32"], ref, "conv16 f32", tol=2e-4)
+    else:
+        out = ops.h16_conv(X16, w_pw, w_dw, bias, ks=ks, stride=stride, pad=pad, out_scale=float(s_out), want_raw=False, want_f32=True)
+        close(out["f32"], ref.astype(np.float32), f"conv16 f32 (K={K} M={M} ks={ks} s={stride} pad={pad} Tin={Tin})", tol=2e-4)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_resblock16_random_lengths(ops, seed):
+    rng = np.random.default_rng(2000 + seed)
+    C = int(rng.choice([64, 128, 256, 512]))
+    T = int(rng.integers(1, 700))
+    B = int(rng.integers(1, 5))
+    X = h(rnd(rng, B, C, T))
+    w1, w2 = h(rnd(rng, C, C, 1, scale=C ** -0.5)), h(rnd(rng, C, C, 1, scale=C ** -0.5))
+    d1, d2 = rnd(rng, C, 1, 5, scale=0.45), rnd(rng, C, 1, 5, scale=0.45)
+    b1, b2 = rnd(rng, C, scale=0.1), rnd(rng, C, scale=0.1)
+    pre, s_out = np.float32(rng.uniform(0.5, 1.0)), np.float32(rng.uniform(0.2, 0.6))
+    xa = h(O.elu(X * pre))
+    u = h(O.elu(O.sconv1d(O.sconv1d(xa, w1, None), d1, b1, groups=C)))
+    y = (X + s_out * O.sconv1d(O.sconv1d(u, w2, None), d2, b2, groups=C)).astype(np.float32)
+    got = ops.h16_resblock(ops.h16_from_f32(cu(X)), w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out))
+    close(ops.h16_to_f32(got, C), h(y), f"resblock16 C={C} T={T} B={B}")
