@@ -280,6 +280,8 @@ def rendezvous(a, dist, world, rank, backend):
 
 def main():
     a = parse()
+    if a.precision != "f32" and a.workload != "detector_stress":   # before any GPU call
+        raise SystemExit("--precision f16 exists for --workload detector_stress only (BASELINE.json configs[4]); the headline is exact f32")
     env_world = os.environ.get("WORLD_SIZE")
     if a.gpus > 1 and env_world is None:
         raise SystemExit(self_launch(a))                          # before any GPU call
@@ -326,8 +328,6 @@ def main():
         a.batch, a.seconds = (32 if a.batch == 256 else a.batch), (30.0 if a.seconds == 1.0 else a.seconds)
     elif a.workload == "detector_stress":
         a.batch = 1024 if a.batch == 256 else a.batch
-    if a.precision != "f32" and a.workload != "detector_stress":
-        raise SystemExit("--precision f16 exists for --workload detector_stress only (BASELINE.json configs[4]); the headline is exact f32")
     f16 = a.precision == "f16"
     T = int(round(a.seconds * 16000))
     B = a.batch

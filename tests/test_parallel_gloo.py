@@ -168,6 +168,14 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr
 
 
+def test_bench_keeps_the_f16_mode_off_the_headline():
+    """`--precision f16` is the detector_stress workload's own line; every other workload (the headline first of all) refuses it, before
+    any GPU call."""
+    for wl in ("embed_detect", "longform", "train_step", "grad_allreduce"):
+        r = _bench(["--workload", wl, "--precision", "f16"])
+        assert r.returncode != 0 and "detector_stress only" in r.stderr, (wl, r.stderr[-300:])
+
+
 def _overlap_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
