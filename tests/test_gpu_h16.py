@@ -353,3 +353,17 @@ def test_resblock16_random_lengths(ops, seed):
     y = (X + s_out * O.sconv1d(O.sconv1d(u, w2, None), d2, b2, groups=C)).astype(np.float32)
     got = ops.h16_resblock(ops.h16_from_f32(cu(X)), w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out))
     close(ops.h16_to_f32(got, C), h(y), f"resblock16 C={C} T={T} B={B}")
+
+
+@pytest.mark.parametrize("B,T", [(3, 16000), (2, 12345), (1, 333), (2, 48000)])
+def test_detector_f16_mean_only_tail(detector, B, T):
+    """Asked for the mean probabilities only, the f16 mode runs conv_post and the head on the f16 pipe too (L2Norm, head GEMM, sigmoid and
+    the time mean in one kernel; the logits never exist).  Against the same mode's logits output (f32 conv_post + head): the same numbers
+    to the f16 rounding of the latent."""
+    from waveverify_amd.init import synthetic_clips
+    x = torch.from_numpy(synthetic_clips(B, T, seed=3 * B + T)[0]).cuda()
+    mp = detector.detector_mean_prob(x, precision="f16")
+    lg = detector.detector(x, precision="f16")
+    ref = torch.sigmoid(lg.double()).mean(dim=-1).float()
+    assert float((mp - ref).abs().max()) <= 2e-4, float((mp - ref).abs().max())
+    assert torch.equal(mp, detector.detector_mean_prob(x, precision="f16"))            # deterministic

@@ -984,6 +984,106 @@ hipError_t conv16s_launch(const Conv16Args& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Detector head for the mean-probability output (detector.py:300-310 + core.py:577-580): L2Norm over the latent's channels
+// (seanet.py:288-318: y / max(||y||, 1e-12) * sqrt(D)), the composed ConvTranspose1d(k = s = hop) -> Conv1d(O -> nb, 1) as one GEMM per
+// frame tile against wc[D][nb * hop], sigmoid, mean over time -- the [B, nb, T] logits never exist.  One workgroup per clip (fixed
+// summation order: deterministic); wave w owns bits nb/4 * w ..; the B fragments of a 64-frame tile (D <= 128: 16 of them) stay in
+// registers over all of a wave's row tiles, A fragments stream from L2.  hop % 32 == 0, nb % 4 == 0, D % 16 == 0.
+struct Head16Args { const float* Y; H16Weight w; const float* bc; float* mean_prob; int B, D, nb, hop, Fr, T; };
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void head16_kernel(Head16Args p) {
+    __shared__ __attribute__((aligned(16))) float ys[128 * 64];       // y tile [D][64] f32
+    __shared__ __attribute__((aligned(16))) h16 zs[16 * 64 * 8];       // z tile, c8 [D/8][64][8]
+    __shared__ float inv[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r = lane & 31;
+    const int b = blockIdx.x, D = p.D, Fr = p.Fr, NC = D / 16, bpw = p.nb / 4, mtb = p.hop / 32;
+    const float* Yb = p.Y + (size_t)b * D * Fr;
+    const __amdgpu_buffer_rsrc_t rW = uniform_rsrc(p.w.wq, p.w.nchunks * p.w.Mp * 32);
+    const int Mp = p.w.Mp;
+    float total[8];                                              // per bit of this wave (bpw <= 8), lane-partial
+#pragma unroll
+    for (int i = 0; i < 8; ++i) total[i] = 0.f;
+    for (int f0 = 0; f0 < Fr; f0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < D * 64; i += 256) {
+            const int m = i >> 6, c = i & 63;
+            ys[i] = f0 + c < Fr ? Yb[(size_t)m * Fr + f0 + c] : 0.f;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float ss = 0.f;
+            for (int m = 0; m < D; ++m) ss = fmaf(ys[m * 64 + tid], ys[m * 64 + tid], ss);
+            inv[tid] = sqrtf((float)D) / fmaxf(sqrtf(ss), 1e-12f);
+        }
+        __syncthreads();
+        for (int i = tid; i < (D / 8) * 64; i += 256) {
+            const int g = i >> 6, c = i & 63;
+            h16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (h16)(ys[(8 * g + j) * 64 + c] * inv[c]);
+            *reinterpret_cast<h16x8*>(zs + (size_t)i * 8) = o;
+        }
+        __syncthreads();
+        h16x8 bf[8][2];                                          // B fragments: chunk c, frame tile e (D <= 128)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (c < NC) bf[c][e] = *reinterpret_cast<const h16x8*>(zs + (size_t)((2 * c + h) * 64 + 32 * e + r) * 8);
+        for (int bi = 0; bi < bpw; ++bi) {
+            const int bit = wave * bpw + bi;
+            const float bcv = p.bc[bit];
+            float s = 0.f;
+            for (int mt = 0; mt < mtb; ++mt) {
+                const int m0 = bit * p.hop + 32 * mt;
+                const int avoff = ((m0 + r) * 2 + h) * 16;
+                h16x8 a[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int so = c * Mp * 32;
+                    if (c < NC) a[c] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, avoff, so, 0));
+                }
+                f32x16 acc[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[e][i] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (c < NC) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[c], bf[c][e], acc[e], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int f = f0 + 32 * e + r;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int j = 32 * mt + 8 * (i >> 2) + 4 * h + (i & 3);
+                        const bool ok = f < Fr && f * p.hop + j < p.T;
+                        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-(acc[e][i] + bcv)));   // 1-ulp reciprocal: a full-precision divide is ten more instructions per logit
+                        s += ok ? sg : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i == bi) total[i] += s;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i < bpw) {
+            float v = total[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) p.mean_prob[(size_t)b * p.nb + wave * bpw + i] = v / (float)p.T;
+        }
+    }
+}
+
 // conv_pre (SConv1d 1 -> C, k taps, causal; modules/seanet.py:657-663) straight into the c8 layout: a thread owns one time step and
 // walks the channel groups (a wave's store of one group is 1 KB contiguous).  KS > 0: the tap count at compile time (the taps of a
 // group arrive as a few wide scalar loads instead of one load and one wait per tap).
@@ -1124,6 +1224,15 @@ hipError_t launch_spec16(const Spec16Args& a, hipStream_t s) {
     if (N == 512 && a.hop == 40) return spec16_launch<SP<512, 40>>(a, s);
     if (N == 1024 && a.hop == 320) return spec16_launch<SP<1024, 320>>(a, s);
     return hipErrorNotSupported;
+}
+
+hipError_t launch_head16(const float* Y, const H16Weight& w, const float* bc, float* mean_prob, int B, int D, int nb, int hop, int Fr, int T, hipStream_t s) {
+    if (!Y || !w.wq || !bc || !mean_prob || B < 1 || Fr < 1 || T < 1) return hipErrorInvalidValue;
+    if (D % 16 || D > 128 || nb % 4 || nb > 32 || hop % 32 || w.M != nb * hop || w.K != D || w.Kp != D || w.Mp != nb * hop || w.nchunks < D / 16) return hipErrorNotSupported;
+    prof::Scope ps(s, "head16", 2.0 * B * D * (double)nb * hop * Fr, (double)B * (4.0 * D * Fr + 4.0 * nb));
+    Head16Args a{Y, w, bc, mean_prob, B, D, nb, hop, Fr, T};
+    hipLaunchKernelGGL(head16_kernel, dim3((unsigned)B), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv_pre16(const float* x, const float* w, const float* bias, void* Y, int B, int C, int T, int ks, float in_scale, hipStream_t s) {

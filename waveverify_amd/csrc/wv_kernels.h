@@ -117,16 +117,19 @@ inline uint16_t f32_to_f16_bits(float f) {                      // round to near
     return (uint16_t)(sign | hv);
 }
 // host: 1x1 weight pw [M][K] (and, for the composed downsample conv, depth-wise taps dw [M][ks]: W[m][i][k] = dw[m][i] * pw[m][k]) -> A fragments
-inline std::vector<uint16_t> pack_h16(const float* pw, const float* dw, int M, int K, int ks, H16Weight* out) {
+// dw_by_k: the taps belong to the INPUT channels (a depth-wise conv in front of the 1x1: dw [K][ks], W[m][i][k] = pw[m][k] * dw[k][i])
+inline std::vector<uint16_t> pack_h16(const float* pw, const float* dw, int M, int K, int ks, H16Weight* out, bool dw_by_k = false) {
     H16Weight w; w.K = K; w.M = M; w.Kp = round_up(K, 16); w.Mp = round_up(M, 32);
     const int nkc = w.Kp / 16;
     w.nchunks = round_up(ks * nkc, 8);
     std::vector<uint16_t> q((size_t)w.nchunks * w.Mp * 16, 0);
     for (int i = 0; i < ks; ++i)
         for (int m = 0; m < M; ++m) {
-            const float t = dw ? dw[(size_t)m * ks + i] : 1.f;
-            for (int k = 0; k < K; ++k)
-                q[(((size_t)((k / 16) * ks + i) * w.Mp + m) * 2 + ((k >> 3) & 1)) * 8 + (k & 7)] = f32_to_f16_bits(pw[(size_t)m * K + k] * t);
+            const float t = (dw && !dw_by_k) ? dw[(size_t)m * ks + i] : 1.f;
+            for (int k = 0; k < K; ++k) {
+                const float tk = (dw && dw_by_k) ? dw[(size_t)k * ks + i] : t;
+                q[(((size_t)((k / 16) * ks + i) * w.Mp + m) * 2 + ((k >> 3) & 1)) * 8 + (k & 7)] = f32_to_f16_bits(pw[(size_t)m * K + k] * tk);
+            }
         }
     *out = w;
     return q;
@@ -179,6 +182,9 @@ inline void pack_stft16(const float* basis, int n_fft, std::vector<uint16_t> (&q
         }
     for (int k = 0; k < 4; ++k) q[k] = pack_h16(m[k].data(), nullptr, R, n_fft, 1, &w[k]);
 }
+// detector head, mean-probability output only: L2Norm over channels of Y [B][D][Fr] (f32), composed head GEMM (w: [nb * hop][D] as A
+// fragments), sigmoid, mean over time.  hipErrorNotSupported outside D % 16 == 0, D <= 128, nb % 4 == 0, hop % 32 == 0.
+hipError_t launch_head16(const float* Y, const H16Weight& w, const float* bc, float* mean_prob, int B, int D, int nb, int hop, int Fr, int T, hipStream_t s);
 hipError_t launch_conv_pre16(const float* x, const float* w, const float* bias, void* Y, int B, int C, int T, int ks, float in_scale, hipStream_t s);
 hipError_t launch_f32_to_c8(const float* X, void* Y, int B, int C, int T, float scale, int elu, hipStream_t s);
 hipError_t launch_c8_to_f32(const void* X, float* Y, int B, int C, int T, hipStream_t s);

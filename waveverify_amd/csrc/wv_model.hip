@@ -86,7 +86,7 @@ struct wv_model {
     int head_nb = 0;
     // ---- f16 mode of the detector (wv_h16.hip): A-fragment weights per encoder stage -- the ResnetBlocks' 1x1 pairs, the SpecBlock's
     // 1x1 over the zero-padded spectrum rows, the downsample unit's 1x1 and depth-wise conv composed into one [M][2r][K] conv
-    struct H16Stage { std::vector<std::pair<wv::H16Weight, wv::H16Weight>> blocks; wv::H16Weight spec, down, cosw, sinw, cosl, sinl; };
+    struct H16Stage { std::vector<std::pair<wv::H16Weight, wv::H16Weight>> blocks; wv::H16Weight spec, down, cosw, sinw, cosl, sinl, post, head; };   // post / head: the last entry only (conv_post as one composed conv, the head GEMM)
     std::vector<H16Stage> h16;                    // n_strides stages; one more when spec_post runs on the f16 pipe too (only its spec / cos / sin members)
 
     ~wv_model() { for (void* p : dev) (void)hipFree(p); }
@@ -314,6 +314,7 @@ int ipow(int b, int e) { int r = 1; while (e-- > 0) r *= b; return r; }
 int pack_model(wv_model* m) {
     const wv_config& c = m->cfg;
     Uploader U{m};
+    std::vector<float> head_wc_host;                              // composed head weight [D][nb * hop] (detector / locator), for the f16 packer
     const int S = c.n_strides, C0 = c.channels_enc;
     const float rs = c.res_scale_enc;
     m->pre_w = U.plain("encoder.conv_pre.1.conv.conv.weight");
@@ -439,6 +440,7 @@ int pack_model(wv_model* m) {
             bc[nn] = (float)acc;
         }
         m->head_wc = U.up(wc); m->head_bc = U.up(bc); m->head_nb = nb;
+        head_wc_host = wc;
     }
     // f16 mode: only for the detector, and only for layer shapes the f16 kernels cover (else wv_detector_forward_f16 reports WV_ESTATE)
     bool h16_ok = c.kind == WV_KIND_DETECTOR && c.residual_kernel_size == 5 && c.dilation_base == 1 && c.kernel_size <= 16;
@@ -477,6 +479,19 @@ int pack_model(wv_model* m) {
             wv::H16Weight w4[4];
             wv::pack_stft16(basis.data(), n_fft, q4, w4);
             st.cosw = U.h16_up(q4[0], w4[0]); st.sinw = U.h16_up(q4[1], w4[1]); st.cosl = U.h16_up(q4[2], w4[2]); st.sinl = U.h16_up(q4[3], w4[3]);
+            // conv_post (ELU -> depth-wise k -> 1x1 + bias, seanet.py:797-823) as one dense conv: W[m][i][k] = pw[m][k] * dw[k][i];
+            // the head's composed weight wc[D][nb * hop] transposed into A fragments [nb * hop][D]
+            {
+                wv::H16Weight w;
+                const std::vector<uint16_t> q = wv::pack_h16(U.host("encoder.conv_post.2.conv.conv.weight").data(), U.host("encoder.conv_post.1.conv.conv.weight").data(),
+                                                             c.dimension, C, c.last_kernel_size, &w, true);
+                st.post = U.h16_up(q, w);
+                const int D = c.dimension, rows = m->head_nb * hop_of(c);
+                std::vector<float> wt((size_t)rows * D);
+                for (int d = 0; d < D; ++d)
+                    for (int r = 0; r < rows; ++r) wt[(size_t)r * D + d] = head_wc_host[(size_t)d * rows + r];
+                st.head = U.h16(wt, nullptr, rows, D, 1);
+            }
             m->h16.push_back(std::move(st));
         }
     }
@@ -962,7 +977,9 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
 // The encoder stages of the f16 mode (wv_h16.hip): conv_pre, then per stage 2 ResnetBlocks (one launch each), the SpecBlock (STFT
 // log-magnitude in f32 as in the exact path, its 1x1 + add on the f16 pipe) and the downsample unit (one composed conv).  The last
 // downsample writes f32 [B, C, Tl] into the stream buffer r[0], where run_encoder(first_stage = n_strides) picks up.
-static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, char* ws, const WsLayout& L, hipStream_t st, bool* post_done) {
+// mean_prob != null: the caller wants the mean probabilities only -- conv_post and the head run on the f16 pipe as well and *head_done is set.
+static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, char* ws, const WsLayout& L, hipStream_t st, bool* post_done,
+                                  float* mean_prob, bool* head_done) {
     const wv_config& c = m->cfg;
     const int S = c.n_strides;
     void* R[2] = {ws + L.off_r0, ws + L.off_r1};
@@ -1017,7 +1034,7 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, cha
         LAUNCH(wv::launch_conv16(g, st));
         cur ^= 1; Tl = g.Tout; C *= 2;
     }
-    *post_done = false;
+    *post_done = false; *head_done = false;
     if ((int)m->h16.size() > S) {
         // spec_post (seanet.py:781-795) on the f16 pipe as well: x from the c8 buffer, x' = x + scale * (W @ P) out in f32 for conv_post.
         // (x sits in R[cur]; when that is R[0] the f32 result, twice the bytes, goes through R[1] and is copied over.)
@@ -1030,6 +1047,27 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, cha
         f.out_scale = sp.scale; f.act_scale = 0.f; f.c1 = 0.5f * 0.6931471805599453f * sp.inv_std; f.c0 = -sp.mean * sp.inv_std;
         f.B = B; f.T = T; f.Tf = Tl; f.n_fft = sp.n_fft; f.hop = sp.hop;
         if ((T + sp.hop - 1) / sp.hop != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");
+        const int D = c.dimension, hop = hop_of(c);
+        if (mean_prob && D % 16 == 0 && D <= 128 && m->head_nb % 4 == 0 && hop % 32 == 0 && c.last_kernel_size <= 16) {
+            // mean probabilities only: ELU(x') in c8 -> conv_post as one composed conv (f32 out) -> L2Norm + head GEMM + sigmoid + mean
+            f.Yf32 = nullptr; f.Yact = A0; f.act_scale = 1.f;
+            const hipError_t e1 = wv::launch_spec16(f, st);
+            if (e1 == hipSuccess) {
+                wv::prof::set_role("enc16.conv_post");
+                wv::Conv16Args g{};
+                g.X = A0; g.w = hs.post; g.bias = m->post_b; g.resid = nullptr; g.Y = nullptr; g.Yact = nullptr; g.Yf32 = (float*)(ws + L.off_lat);
+                g.out_scale = 1.f; g.act_scale = 0.f; g.B = B; g.M = D; g.Tin = Tl; g.Tout = Tl; g.ks = c.last_kernel_size; g.stride = 1;
+                g.pad = c.last_kernel_size - 1;
+                LAUNCH(wv::launch_conv16(g, st));
+                wv::prof::set_role("head16");
+                const hipError_t e2 = wv::launch_head16(g.Yf32, hs.head, m->head_bc, mean_prob, B, D, m->head_nb, hop, Tl, T, st);
+                if (e2 != hipSuccess) return fail(WV_EHIP, std::string("launch_head16: ") + hipGetErrorString(e2));
+                *post_done = true; *head_done = true;
+                return WV_OK;
+            }
+            if (e1 != hipErrorNotSupported) return fail(WV_EHIP, std::string("launch_spec16 (post): ") + hipGetErrorString(e1));
+            f.Yf32 = (float*)R[cur ^ 1]; f.Yact = nullptr; f.act_scale = 0.f;
+        }
         const hipError_t fe = wv::launch_spec16(f, st);
         if (fe == hipSuccess) {
             if ((cur ^ 1) != 0) LAUNCH(hipMemcpyAsync(R[0], R[1], (size_t)B * C * Tl * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1056,8 +1094,10 @@ static int run_head_model(wv_model* m, const float* x, float* logits, float* mea
     bool post_done = false;
     if (f16) {
         if (m->h16.empty()) return fail(WV_ESTATE, "this model has no f16 plan (detector with 64/128/256/512-channel stages, k = 5, dilation 1)");
-        rc = run_encoder_stages_f16(m, x, B, T, w, L, st, &post_done);
+        bool head_done = false;
+        rc = run_encoder_stages_f16(m, x, B, T, w, L, st, &post_done, logits ? nullptr : mean_prob, &head_done);
         if (rc) return rc;
+        if (head_done) return WV_OK;
     }
     rc = run_encoder(m, x, nullptr, 0, latent, B, T, w, L, st, &Fr, f16 ? m->cfg.n_strides : 0, post_done);
     if (rc) return rc;
