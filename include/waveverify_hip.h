@@ -205,8 +205,10 @@ int wv_op_spec_block(const float* wav, const float* basis_or_null, const float* 
  *   wv_h16_spec_block whole SpecBlock in one launch (seanet.py:463-511): the STFT on the f16 pipe with the waveform split in two f16 terms,
  *                     log-magnitude, the 1x1 and the add; the spectrogram stays in LDS.  (n_fft = M, hop) in {(64,1),(128,2),(256,8),(512,40)}
  *                     (the default detector's scales), else WV_EINVAL; x16 / Y16 / Yact16 c8 f16 [B, M/8, ceil(T/hop), 8]
- *   wv_detector_forward_f16   Detector.forward (model/detector.py:366-391) in this mode: conv_pre .. the last downsample in f16,
- *                     the STFTs, spec_post, conv_post and the head in f32 (same workspace as wv_detector_forward). */
+ *   wv_detector_forward_f16   Detector.forward (model/detector.py:366-391) in this mode: conv_pre, the ResnetBlocks, the SpecBlocks
+ *                     (STFT as a split-f16 matrix product) incl. spec_post and the downsample units on the f16 pipe; with logits == NULL
+ *                     (mean probabilities only) conv_post and the head as well, otherwise those two by the exact path's f32 kernels.
+ *                     Same arguments and workspace as wv_detector_forward; WV_ESTATE for a model without an f16 plan. */
 int wv_h16_round_host(const float* in, uint16_t* out, int64_t n);   /* HOST pointers: the weight packers' f32 -> f16 rounding (nearest even) */
 int wv_h16_from_f32(const float* X, void* Y16, int B, int C, int T, float scale, int elu, void* stream);
 int wv_h16_to_f32(const void* X16, float* Y, int B, int C, int T, void* stream);

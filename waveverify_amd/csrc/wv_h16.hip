@@ -15,6 +15,10 @@
 //   conv16_kernel  dense causal Conv1d as an implicit GEMM straight from global memory (no LDS, no barrier): the downsample unit
 //                  ELU -> 1x1 -> depth-wise(2r, stride r) with the two convolutions composed into one [M][2r][K] weight (twice the
 //                  flops, which this pipe has to spare, and no stencil epilogue at all), and the SpecBlock's 1x1 + add (ks = 1).
+//   conv16s_kernel the same conv for stride >= 4 with the x window staged through LDS (skewed LDS-DMA copy).
+//   spec16_kernel  whole SpecBlock in one launch: the windowed DFT with both operands split in two f16 terms, log-magnitude, the 1x1
+//                  and the add; the spectrogram stays in LDS.  All five scales of the detector incl. spec_post.
+//   head16_kernel  mean-probability output: L2Norm, the composed head GEMM, sigmoid and the time mean; the logits never exist.
 //   conv_pre16, f32_to_c8, c8_to_f32   the layout's entry and exit.
 #include <atomic>
 #include <string>
