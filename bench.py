@@ -44,6 +44,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16 / bf16 (v_mfma_f32_32x32x16_f16, 32 cycles per SIMD)
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_FILE_F16 = os.path.join(ROOT, "profiles", "r03_pmc_traffic_f16.json")   # the same passes over the f16 mode's command (tools/profile_f16.sh)
 
 
 def parse():
@@ -405,13 +406,13 @@ def main():
     ach = dom["flops"] / dom["launches"] / dom_avg_s / 1e12
     pmc = None
     try:        # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command (profiles/), valid for the
-        pmc = json.load(open(PMC_FILE))          # library build they were taken on only: dropped when the kernel sources changed since
+        pmc = json.load(open(PMC_FILE_F16 if f16 else PMC_FILE))   # library build they were taken on only: dropped when the kernel sources changed since
         from waveverify_amd import _lib
         if pmc.get("library") != _lib.load().wv_version().decode():
             pmc = None
     except Exception:
         pmc = None
-    headline = a.workload == "embed_detect" and B == 256 and T == 16000
+    headline = (a.workload == "embed_detect" and B == 256 and T == 16000) or (f16 and B == 1024 and T == 16000)   # the shapes the passes ran on
 
     def traffic_of(kernel):
         kernel = kernel.replace(",flat", "")       # flat tiling is a launch-time property of the same kernel symbol
@@ -434,7 +435,7 @@ def main():
         roof = dict(bound="hbm", achieved=round(gbs_dom, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                     frac=round(gbs_dom / PEAK_HBM_GBS, 4))
     roofline = dict(kernel=dom_name, **roof, traffic=traffic_of(dom_name),
-                    traffic_source=("profiles/r03_pmc_traffic.json: GB per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, "
+                    traffic_source=(f"profiles/{os.path.basename(PMC_FILE_F16 if f16 else PMC_FILE)}: GB per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, "
                                     "separate rocprofv3 --pmc passes over this command") if traffic_of(dom_name) else None,
                     arithmetic_intensity_flop_per_byte=round(dom_ai, 1), ridge_flop_per_byte=round(ridge, 1),
                     tflops=round(ach, 2), hbm_gbs=round(gbs_dom, 1),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Reduce rocprofv3 counter passes over the headline bench command (tools/profile_bench.sh) to per-kernel figures.
 
-    python tools/pmc_traffic.py traffic <pmc_fetch dir> <pmc_write dir>  > profiles/rNN_pmc_traffic.json
+    python tools/pmc_traffic.py traffic <pmc_fetch dir> <pmc_write dir> ["<command> (<script>)"]  > profiles/rNN_pmc_traffic.json
     python tools/pmc_traffic.py busy    <pmc_sq dir>                     > profiles/rNN_mfma_busy.json
 
 traffic: HBM bytes per launch.  Counters are KiB; on gfx950 FETCH_SIZE counts 64 B requests as 32 B, hence
@@ -34,6 +34,21 @@ def short(name: str) -> str:
     if m:
         c, ng, nt = int(m.group(1)), int(m.group(2)), int(m.group(3))
         return f"resblock<{c},{ng * (32 * nt - 4) + 4}>"
+    # the f16 mode's kernels (csrc/wv_h16.hip), named as the library's profiler names them where the symbol allows
+    m = re.search(r"rh_kernel<wv::\(anonymous namespace\)::RH<(\d+), (\d+), (\d+),", name)
+    if m:
+        c, ng, nt = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        return f"resblock16<{c},{ng * (32 * nt - 4) + 4}>"
+    m = re.search(r"spec16_kernel<wv::\(anonymous namespace\)::SP<(\d+), (\d+)>", name)
+    if m:
+        return f"spec16<{m.group(1)},hop{m.group(2)}>"
+    m = re.search(r"conv16s_kernel<(\d+), (true|false|[01])>", name)
+    if m:
+        return f"conv16<k{m.group(1)},lds>"                     # one symbol per tap count (the profiler's name also carries M x K)
+    m = re.search(r"conv16_kernel<(\d+), (\d+), (true|false|[01])>", name)
+    if m:
+        return f"conv16<{m.group(1)}x{m.group(2)}{',flat' if m.group(3) in ('true', '1') else ''}>"   # several layers share a symbol
+    name = name.replace("(anonymous namespace)::", "")
     m = re.match(r"void wv::(\w+)_kernel<wv::Tile<(\d+), (\d+), (\d+), (\d+)>((?:, [-\w]+)*)\s*>", name)
     if not m:
         m2 = re.match(r"(?:void )?wv::(\w+)_kernel", name)
@@ -94,12 +109,11 @@ def durations(d: str):
     return t, n
 
 
-def traffic(fetch_dir, write_dir):
+def traffic(fetch_dir, write_dir, command="bench.py --steps 5 --warmup 2 --no-cpu-baseline` (tools/profile_bench.sh)"):
     f, nf = reduce_pass(fetch_dir, ["FETCH_SIZE"])
     w, nw = reduce_pass(write_dir, ["WRITE_SIZE"])
     f, nf, w, nw = f["FETCH_SIZE"], nf["FETCH_SIZE"], w["WRITE_SIZE"], nw["WRITE_SIZE"]
-    out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 5 --warmup 2 "
-                   "--no-cpu-baseline` (tools/profile_bench.sh); counters are KiB; gfx950 correction per "
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `" + command + "; counters are KiB; gfx950 correction per "
                    "MI355X_MICROARCH.md section HBM: traffic = 2*FETCH_SIZE + WRITE_SIZE",
            "library": library_version(), "kernels": {}}
     for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0.0))):
@@ -143,7 +157,7 @@ def busy(sq_dir):
 
 if __name__ == "__main__":
     if sys.argv[1] == "traffic":
-        json.dump(traffic(sys.argv[2], sys.argv[3]), sys.stdout, indent=1)
+        json.dump(traffic(sys.argv[2], sys.argv[3], *sys.argv[4:5]), sys.stdout, indent=1)
     else:
         json.dump(busy(sys.argv[2]), sys.stdout, indent=1)
     print()
