@@ -197,7 +197,7 @@ int wv_op_spec_block(const float* wav, const float* basis_or_null, const float* 
  * residual adds are f32.  Weights: HOST f32 pointers in the reference's layouts, as for every wv_op_*.
  *   wv_h16_from_f32 / wv_h16_to_f32   [B,C,T] f32 <-> c8 f16 (from: optionally ELU(scale * x) on the way; rows past C are zero)
  *   wv_h16_conv_pre   conv_pre (seanet.py:657-664) writing c8 f16
- *   wv_h16_resblock   whole SEANetResnetBlock (seanet.py:245-281), C in {64,128,256,512}, k = 5, dilation 1, any T
+ *   wv_h16_resblock   whole SEANetResnetBlock (seanet.py:245-281), C in {32,64,96,128,192,256,384,512,768}, k = 5, dilation 1, any T
  *   wv_h16_conv       y = out_scale * (bias + Conv1d(x)) + resid with W[m][i][k] = w_dw[m][i] * w_pw[m][k] (w_dw NULL: 1), causal,
  *                     x = 0 outside [0,Tin), Tout = ceil(Tin/stride): the downsample unit (ks = 2r, stride r, pad r; seanet.py:739-760)
  *                     and the SpecBlock's 1x1 + add (ks = 1; seanet.py:500-502).  Outputs: Y16 / Yact16 = ELU(act_scale*y) in c8 f16,
@@ -208,7 +208,21 @@ int wv_op_spec_block(const float* wav, const float* basis_or_null, const float* 
  *   wv_detector_forward_f16   Detector.forward (model/detector.py:366-391) in this mode: conv_pre, the ResnetBlocks, the SpecBlocks
  *                     (STFT as a split-f16 matrix product) incl. spec_post and the downsample units on the f16 pipe; with logits == NULL
  *                     (mean probabilities only) conv_post and the head as well, otherwise those two by the exact path's f32 kernels.
- *                     Same arguments and workspace as wv_detector_forward; WV_ESTATE for a model without an f16 plan. */
+ *                     Same arguments and workspace as wv_detector_forward; WV_ESTATE for a model without an f16 plan.
+ *   wv_locator_forward_f16    Locator.forward (model/locator.py:268-299) in this mode: the encoder stages on the f16 pipe (32- and
+ *                     64-channel ResnetBlocks, composed downsample convs; its SpecBlocks, whose n_fft != C, by the exact path's STFT
+ *                     kernel + the 1x1 on the f16 pipe), spec_post / conv_post / head by the exact f32 kernels.  Arguments of wv_locator_forward.
+ *   wv_generator_forward_f16  Generator.forward (model/generator.py:360-423; modules/seanet.py:883-976, 1067-1226) in this mode: the
+ *                     encoder as above with FiLM in the downsample convs' epilogues, conv_post as one composed conv, L2Norm, then
+ *                     the decoder: first conv pair as one composed conv, every upsample unit (ELU -> depth-wise ConvTranspose1d ->
+ *                     1x1, seanet.py:1147-1170) as ONE two-tap conv over (phase, channel) rows, ResnetBlocks of 768 / 384 / 192 / 96
+ *                     channels in one launch each, the tail (f32 sums, tanh, + x) on the c8 stream.  Message MLP / FiLM scalars in f32.
+ *                     Arguments and workspace of wv_generator_forward; WV_ESTATE for a model without an f16 plan.
+ *   wv_h16_upsample   the decoder's upsample unit as that conv: x16 = the PRE-ACTIVATED input c8 [B, K/8, Tin, 8]; w_ct [K,1,2r], w_pw
+ *                     [M,K,1], bias [M] HOST; Y16 / Yact16 c8 [B, M/8, Tin*r, 8] (either may be NULL)
+ *   wv_h16_tail       decoder tail on the pre-activated c8 stream: out[B,1,T] = tanh(out_scale * (b + Conv1d(C -> 1, ks)(a16))) (+ x)
+ *   wv_h16_l2norm     L2Norm over channels of lat [B,D,Fr] f32 (seanet.py:288-318) -> c8 f16
+ *   wv_h16_conv_film  wv_h16_conv with FiLM behind it (film [B, bands, 2] DEVICE: gamma, beta per clip and band of M / bands rows) */
 int wv_h16_round_host(const float* in, uint16_t* out, int64_t n);   /* HOST pointers: the weight packers' f32 -> f16 rounding (nearest even) */
 int wv_h16_from_f32(const float* X, void* Y16, int B, int C, int T, float scale, int elu, void* stream);
 int wv_h16_to_f32(const void* X16, float* Y, int B, int C, int T, void* stream);
@@ -221,6 +235,18 @@ int wv_h16_spec_block(const float* wav, const float* basis_or_null, const float*
                       int n_fft, int hop, int M, float mean, float std, float out_scale, float act_scale, void* stream);
 int wv_detector_forward_f16(wv_model* m, const float* x, float* logits, float* mean_prob,
                             int B, int T, void* workspace, size_t workspace_bytes, void* stream);
+int wv_locator_forward_f16(wv_model* m, const float* x, float* logits, int B, int T,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int wv_generator_forward_f16(wv_model* m, const float* x, const float* msg, int msg_rows,
+                             float* out, int add_input, int B, int T,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int wv_h16_upsample(const void* X16, const float* w_ct, const float* w_pw, const float* bias, void* Y16, void* Yact16,
+                    int B, int K, int M, int Tin, int ratio, float act_scale, void* stream);
+int wv_h16_tail(const void* A16, const float* w, const float* bias, const float* x, float* out, int B, int C, int Tin, int T, int ks,
+                float out_scale, void* stream);
+int wv_h16_l2norm(const float* lat, void* Y16, int B, int D, int Fr, void* stream);
+int wv_h16_conv_film(const void* X16, const float* w_pw, const float* w_dw, const float* bias, const float* film, int bands, void* Y16, void* Yact16,
+                     int B, int K, int M, int Tin, int ks, int stride, int pad, float act_scale, void* stream);
 
 /* conv_pre: Y = Conv1d(1->C,k)(x * in_scale) + bias  (seanet.py:657-664). x [B,1,T], w [C,1,k]. */
 

@@ -48,6 +48,21 @@ def c8_to_np(ops, t, C):
     return ops.h16_to_f32(t, C).cpu().numpy()
 
 
+L2E = 1.4426950408889634
+
+
+def resblock16_ref(X, w1, d1, b1, w2, d2, b2, pre, s_out):
+    """The block with the kernel's roundings restated (csrc/wv_h16.hip rh_kernel): both activations are kept TIMES log2(e) and rounded
+    to f16 there, the 1x1 weights are packed DIVIDED by log2(e) and rounded to f16 (pack_rh_pw), sums in float64."""
+    C = X.shape[1]
+    w1s, w2s = h(w1.astype(np.float64) / L2E), h(w2.astype(np.float64) / L2E)
+    xa = h(L2E * O.elu((X * np.float32(pre)).astype(np.float64)))
+    y1 = O.sconv1d(O.sconv1d(xa.astype(np.float64), w1s.astype(np.float64), None), d1.astype(np.float64), b1.astype(np.float64), groups=C)
+    u = h(L2E * O.elu(y1))
+    y = X + np.float64(s_out) * O.sconv1d(O.sconv1d(u.astype(np.float64), w2s.astype(np.float64), None), d2.astype(np.float64), b2.astype(np.float64), groups=C)
+    return y.astype(np.float32)
+
+
 @pytest.mark.parametrize("B,C,T", [(2, 64, 1000), (3, 33, 17), (1, 8, 1), (2, 129, 300)])
 def test_layout_round_trip(ops, B, C, T):
     rng = np.random.default_rng(C + T)
@@ -75,28 +90,37 @@ def test_conv_pre(ops, C, T, ks):
     close(ops.h16_to_f32(got, C), h(ref), "conv_pre16")
 
 
-# lengths around every tile edge: 244 outputs per tile at C = 64, 120 at C = 128 / 256, 56 at C = 512; one-sample and sub-halo clips
+# lengths around every tile edge: 244 outputs per tile at C = 64, 120 at C = 96 / 128 / 192, 56 at C = 256 / 384 / 512 / 768, 476 at C = 32;
+# one-sample and sub-halo clips.  32: the locator's first stage; 96 / 192 / 384 / 768: the generator's decoder
 @pytest.mark.parametrize("C,T", [(64, 16000), (64, 244), (64, 245), (64, 1), (64, 7), (64, 500), (128, 8000), (128, 120), (128, 121), (128, 3),
-                                 (256, 2000), (256, 119), (256, 241), (512, 400), (512, 56), (512, 57), (512, 5)])
+                                 (256, 2000), (256, 119), (256, 241), (512, 400), (512, 56), (512, 57), (512, 5),
+                                 (32, 16000), (32, 476), (32, 477), (32, 2), (96, 16000), (96, 120), (96, 121), (96, 6), (192, 8000), (192, 241), (192, 1),
+                                 (384, 2000), (384, 56), (384, 57), (384, 3), (768, 400), (768, 113), (768, 4)])
 def test_resblock(ops, C, T):
     rng = np.random.default_rng(C * 3 + T)
     B = 3
     X = h(rnd(rng, B, C, T))
-    w1, w2 = h(rnd(rng, C, C, 1, scale=C ** -0.5)), h(rnd(rng, C, C, 1, scale=C ** -0.5))
+    w1, w2 = rnd(rng, C, C, 1, scale=C ** -0.5), rnd(rng, C, C, 1, scale=C ** -0.5)
     d1, d2 = rnd(rng, C, 1, 5, scale=0.45), rnd(rng, C, 1, 5, scale=0.45)
     b1, b2 = rnd(rng, C, scale=0.1), rnd(rng, C, scale=0.1)
     pre, s_out, s_act = np.float32(0.8660254), np.float32(0.41), np.float32(0.7071)
-    xa = h(O.elu(X * pre))
-    u = h(O.elu(O.sconv1d(O.sconv1d(xa.astype(np.float64), w1.astype(np.float64), None), d1.astype(np.float64), b1.astype(np.float64), groups=C)))
-    y = X + s_out * O.sconv1d(O.sconv1d(u.astype(np.float64), w2.astype(np.float64), None), d2.astype(np.float64), b2.astype(np.float64), groups=C)
-    y = y.astype(np.float32)
+    y = resblock16_ref(X, w1, d1, b1, w2, d2, b2, pre, s_out)
+    # ... and the restated roundings are the block itself: against the plain composition in float64 (f16 rounding of operands only)
+    plain = X + s_out * O.sconv1d(O.sconv1d(O.elu(O.sconv1d(O.sconv1d(O.elu((X * pre).astype(np.float64)), w1.astype(np.float64), None), d1.astype(np.float64),
+                                                                       b1.astype(np.float64), groups=C)), w2.astype(np.float64), None),
+                                  d2.astype(np.float64), b2.astype(np.float64), groups=C)
+    assert np.abs(plain - y).max() <= 6 * 2.0 ** -11 * max(1.0, np.abs(plain).max())
     X16 = ops.h16_from_f32(cu(X))
     got, gact = ops.h16_resblock(X16, w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out), act_scale=float(s_act))
     close(ops.h16_to_f32(got, C), h(y), "resblock16")
     close(ops.h16_to_f32(gact, C), h(O.elu(y * s_act)), "resblock16 (activated copy)")
     only_raw = ops.h16_resblock(X16, w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out))
     only_act = ops.h16_resblock(X16, w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out), act_scale=float(s_act), want_raw=False)
-    assert torch.equal(only_raw, got) and torch.equal(only_act, gact)
+    # the raw-only form rounds y = f16(v * s + x) in one instruction (v_fma_mixlo/hi_f16), the two-output form rounds the f32 sum: the same
+    # value except where the f32 sum sits within its own rounding of an f16 tie
+    assert float((ops.h16_to_f32(only_raw, C) - ops.h16_to_f32(got, C)).abs().max()) <= 2.0 ** -10 * max(1.0, float(np.abs(y).max()))
+    close(ops.h16_to_f32(only_raw, C), h(y), "resblock16 (raw only)")
+    assert torch.equal(only_act, gact)
 
 
 @pytest.mark.parametrize("K,M,Tin,r", [(64, 128, 16000, 2), (64, 128, 1001, 2), (128, 256, 8000, 4), (128, 256, 501, 4), (256, 512, 2000, 5), (256, 512, 203, 5),
@@ -196,14 +220,25 @@ def test_detector_f16_narrow_margin(golden_dir):
           f"{int(((mp >= 0.5).astype(np.int32) != g['det_bits']).sum())} differ in all")
 
 
-def test_detector_f16_refuses_other_nets():
+def test_f16_mode_refuses_nets_without_a_plan():
+    """Layer shapes outside the f16 kernels' set (here 16-channel first stages): the *_f16 entry points report WV_ESTATE -> RuntimeError; the
+    exact path of the same nets runs."""
     from waveverify_amd.config import default_config
     from waveverify_amd.init import random_state_dict
     from waveverify_amd.nets import HipNet
-    cfg = default_config("locator")
-    L = HipNet(cfg, random_state_dict(cfg, 0, parametrized=True))
+    x = torch.zeros(1, 1, 800, device="cuda")
+    for kind in ("locator", "detector"):
+        cfg = default_config(kind, channels_enc=16)
+        N = HipNet(cfg, random_state_dict(cfg, 0, parametrized=True))
+        N._head(x, True, False)
+        with pytest.raises(RuntimeError):
+            N._head(x, True, False, precision="f16")
+    cfg = default_config("generator", channels_enc=16)
+    G = HipNet(cfg, random_state_dict(cfg, 0))
     with pytest.raises(RuntimeError):
-        L._head(torch.zeros(1, 1, 800, device="cuda"), True, False, precision="f16")
+        G.generator(x, torch.zeros(1, 16, device="cuda"), precision="f16")
+    with pytest.raises(ValueError):
+        G.generator(x, torch.zeros(1, 16, device="cuda"), precision="bf16")
 
 
 @pytest.mark.parametrize("B,T", [(1, 16000), (5, 12345), (3, 333), (1, 1), (2, 5), (2, 321), (1, 48001)])
@@ -337,20 +372,18 @@ def test_conv16_generic_geometries(ops, seed):
         close(out["f32"], ref.astype(np.float32), f"conv16 f32 (K={K} M={M} ks={ks} s={stride} pad={pad} Tin={Tin})", tol=2e-4)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(18))
 def test_resblock16_random_lengths(ops, seed):
     rng = np.random.default_rng(2000 + seed)
-    C = int(rng.choice([64, 128, 256, 512]))
+    C = int(rng.choice([32, 64, 96, 128, 192, 256, 384, 512, 768]))
     T = int(rng.integers(1, 700))
     B = int(rng.integers(1, 5))
     X = h(rnd(rng, B, C, T))
-    w1, w2 = h(rnd(rng, C, C, 1, scale=C ** -0.5)), h(rnd(rng, C, C, 1, scale=C ** -0.5))
+    w1, w2 = rnd(rng, C, C, 1, scale=C ** -0.5), rnd(rng, C, C, 1, scale=C ** -0.5)
     d1, d2 = rnd(rng, C, 1, 5, scale=0.45), rnd(rng, C, 1, 5, scale=0.45)
     b1, b2 = rnd(rng, C, scale=0.1), rnd(rng, C, scale=0.1)
     pre, s_out = np.float32(rng.uniform(0.5, 1.0)), np.float32(rng.uniform(0.2, 0.6))
-    xa = h(O.elu(X * pre))
-    u = h(O.elu(O.sconv1d(O.sconv1d(xa, w1, None), d1, b1, groups=C)))
-    y = (X + s_out * O.sconv1d(O.sconv1d(u, w2, None), d2, b2, groups=C)).astype(np.float32)
+    y = resblock16_ref(X, w1, d1, b1, w2, d2, b2, pre, s_out)
     got = ops.h16_resblock(ops.h16_from_f32(cu(X)), w1, d1, b1, w2, d2, b2, pre_scale=float(pre), out_scale=float(s_out))
     close(ops.h16_to_f32(got, C), h(y), f"resblock16 C={C} T={T} B={B}")
 
@@ -367,3 +400,231 @@ def test_detector_f16_mean_only_tail(detector, B, T):
     ref = torch.sigmoid(lg.double()).mean(dim=-1).float()
     assert float((mp - ref).abs().max()) <= 2e-4, float((mp - ref).abs().max())
     assert torch.equal(mp, detector.detector_mean_prob(x, precision="f16"))            # deterministic
+
+
+# ================= round 4: the f16 mode through the Generator and the Locator =================
+@pytest.mark.parametrize("K,M,Tin,r", [(1536, 768, 50, 8), (768, 384, 400, 5), (384, 192, 2000, 4), (192, 96, 8000, 2), (192, 96, 1, 2), (64, 32, 37, 3), (768, 384, 51, 5),
+                                       (384, 192, 513, 4)])
+def test_upsample_as_one_conv(ops, K, M, Tin, r):
+    """The decoder's upsample unit ELU -> depth-wise ConvTranspose1d(2r, r), trimmed -> 1x1 + bias (seanet.py:1147-1170, conv.py:838-881)
+    as ONE two-tap conv over (phase, channel) rows of the input frames: against the reference's two ops in float64 on the f16-rounded
+    activated input (what the composed weight's f16 rounding costs: a few 1e-4 relative), and against the composition restated."""
+    rng = np.random.default_rng(K + M + Tin + r)
+    B = 2
+    X = rnd(rng, B, K, Tin)
+    w_ct, w_pw, b = rnd(rng, K, 1, 2 * r, scale=0.5), rnd(rng, M, K, 1, scale=K ** -0.5), rnd(rng, M, scale=0.1)
+    pre = np.float32(0.7071)
+    xa = h(O.elu(X * pre))
+    two = O.sconv1d(O.sconvtr1d_depthwise(xa.astype(np.float64), w_ct.astype(np.float64), r).astype(np.float64), w_pw.astype(np.float64), b.astype(np.float64))
+    # the composed weight as the packer rounds it: rows (p, m), tap 0 = frame l - 1 (ct[k][p + r]), tap 1 = frame l (ct[k][p])
+    ref = np.zeros((B, M, Tin * r), np.float64)
+    xprev = np.concatenate([np.zeros((B, K, 1)), xa[:, :, :-1]], axis=2).astype(np.float64)
+    for p in range(r):
+        w0 = h(w_pw[:, :, 0] * w_ct[None, :, 0, p + r]).astype(np.float64)
+        w1 = h(w_pw[:, :, 0] * w_ct[None, :, 0, p]).astype(np.float64)
+        ref[:, :, p::r] = np.einsum("mk,bkt->bmt", w0, xprev) + np.einsum("mk,bkt->bmt", w1, xa.astype(np.float64))
+    ref = (ref + b[None, :, None]).astype(np.float32)
+    assert two.shape == ref.shape and np.abs(two - ref).max() <= 4 * 2.0 ** -11 * max(1.0, np.abs(two).max())
+    X16 = ops.h16_from_f32(cu(X), scale=float(pre), elu=True)
+    got, gact = ops.h16_upsample(X16, w_ct, w_pw, b, r, act_scale=0.5)
+    close(ops.h16_to_f32(got, M), h(ref), "upsample16")
+    close(ops.h16_to_f32(gact, M), h(O.elu(ref * np.float32(0.5))), "upsample16 (activated copy)")
+    assert torch.equal(ops.h16_upsample(X16, w_ct, w_pw, b, r), got)
+    assert torch.equal(ops.h16_upsample(X16, w_ct, w_pw, b, r, act_scale=0.5, want_raw=False), gact)
+
+
+@pytest.mark.parametrize("C,Tin,T,ks", [(96, 16000, 16000, 5), (96, 16320, 16001, 5), (96, 4, 3, 5), (96, 1000, 1000, 7), (48, 333, 330, 3), (8, 1, 1, 5)])
+def test_tail16(ops, C, Tin, T, ks):
+    rng = np.random.default_rng(C + Tin + ks)
+    B = 3
+    A = h(O.elu(rnd(rng, B, C, Tin)))
+    w, b, x = rnd(rng, 1, C, ks, scale=(C * ks) ** -0.5), rnd(rng, 1, scale=0.1), rnd(rng, B, 1, T, scale=0.1)
+    s = np.float32(0.1122080159)
+    ref = np.tanh(O.sconv1d(A.astype(np.float64), w.astype(np.float64), b.astype(np.float64))[..., :T] * s).astype(np.float32)
+    A16 = ops.h16_from_f32(cu(A))
+    close(ops.h16_tail(A16, w, b, T, float(s)), ref, "tail16", tol=2e-6)
+    close(ops.h16_tail(A16, w, b, T, float(s), x=cu(x)), ref + x, "tail16 + x", tol=2e-6)
+
+
+@pytest.mark.parametrize("B,D,Fr", [(3, 128, 50), (2, 64, 500), (1, 128, 1), (2, 40, 7)])
+def test_l2norm16(ops, B, D, Fr):
+    rng = np.random.default_rng(D + Fr)
+    X = rnd(rng, B, D, Fr)
+    X[0, :, 0] = 0.0                                              # the eps branch (seanet.py:288-318)
+    ref = X / np.maximum(np.sqrt((X.astype(np.float64) ** 2).sum(1, keepdims=True)), 1e-12) * np.sqrt(D)
+    close(ops.h16_to_f32(ops.h16_l2norm(cu(X)), D), h(ref.astype(np.float32)), "l2norm16", tol=2.0 ** -11)
+
+
+@pytest.mark.parametrize("K,M,Tin,r", [(64, 128, 16000, 2), (128, 256, 8000, 4), (256, 512, 2000, 5), (512, 1024, 400, 8), (512, 1024, 37, 8), (128, 256, 501, 4), (32, 64, 70, 4)])
+def test_downsample_with_film(ops, K, M, Tin, r):
+    """The generator's downsample unit: the composed conv with FiLM (seanet.py:928-966: per clip and band of M / 4 channels, y = gamma * y +
+    beta) in its epilogue -- both conv kernels (x through LDS for stride >= 4 and M >= 256; straight from global memory else)."""
+    rng = np.random.default_rng(K + M + Tin + 7)
+    B, bands = 3, 4
+    X = rnd(rng, B, K, Tin)
+    w_pw, w_dw, b = rnd(rng, M, K, 1, scale=K ** -0.5), rnd(rng, M, 1, 2 * r, scale=(2 * r) ** -0.5), rnd(rng, M, scale=0.1)
+    film = np.stack([rng.uniform(0.6, 1.4, (B, bands)), rng.normal(0, 0.3, (B, bands))], axis=-1).astype(np.float32)
+    xa = h(O.elu(X * np.float32(0.7559)))
+    wc = h(w_pw[:, :, 0][:, None, :] * w_dw[:, 0, :][:, :, None])
+    Tout = (Tin + r - 1) // r
+    ref = _dense_conv_ref(xa, wc, b, r, r, Tout)
+    gam = np.repeat(film[:, :, 0], M // bands, axis=1)[:, :, None]
+    bet = np.repeat(film[:, :, 1], M // bands, axis=1)[:, :, None]
+    ref = (gam * ref + bet).astype(np.float32)
+    X16 = ops.h16_from_f32(cu(X), scale=0.7559, elu=True)
+    got, gact = ops.h16_conv_film(X16, w_pw, w_dw, b, cu(film), 2 * r, r, r, act_scale=0.8)
+    close(ops.h16_to_f32(got, M), h(ref), "downsample16 + FiLM")
+    close(ops.h16_to_f32(gact, M), h(O.elu(ref * np.float32(0.8))), "downsample16 + FiLM (activated copy)")
+
+
+@pytest.fixture(scope="module")
+def nets3():
+    from waveverify_amd.config import default_config
+    from waveverify_amd.init import random_state_dict
+    from waveverify_amd.nets import HipNet
+    out = {}
+    for k in ("generator", "detector", "locator"):
+        cfg = default_config(k)
+        out[k] = HipNet(cfg, random_state_dict(cfg, 0))
+    return out
+
+
+WM_BAR = 1e-4        # north_star: watermarked-waveform samples within 1e-4 of the reference
+
+
+@pytest.mark.parametrize("fixture", ["full_T16000", "full_T16001", "full_T4800", "speech_T16000"])
+def test_generator_f16_vs_reference_golden(golden_dir, nets3, fixture):
+    """wm of the f16 mode against the REFERENCE's own output: max|d| measured and held to north_star's 1e-4 (plain f16 storage of every
+    stage suffices: tools/sim_f16.py predicted 5e-5, no stage needs the two-term split); the bits the reference's detector recovers from
+    the reference's wm are recovered from this wm as well, by the exact detector and by the f16 one."""
+    import os
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    x, msg = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["msg"]).cuda()
+    G, D = nets3["generator"], nets3["detector"]
+    wm = G.generator(x, msg, add_input=True, precision="f16")
+    err = float(np.abs(wm.cpu().numpy() - g["wm"]).max())
+    print(f"{fixture}: f16-mode wm max|d| vs reference {err:.2e}")
+    assert np.isfinite(wm.cpu().numpy()).all() and err <= WM_BAR, err
+    delta = G.generator(x, msg, precision="f16")
+    assert float((delta + x - wm).abs().max()) <= 1e-7
+    for prec in ("f32", "f16"):
+        mp = D.detector_mean_prob(wm, precision=prec).cpu().numpy()
+        dp = float(np.abs(mp - g["det_mean_prob"]).max())
+        decidable = np.abs(g["det_mean_prob"] - 0.5) > 4 * dp
+        assert decidable.all() and ((mp >= 0.5).astype(np.int32) == g["det_bits"]).all(), (prec, dp)
+
+
+@pytest.mark.parametrize("fixture", ["full_T16000", "full_T16001", "full_T4800", "speech_T16000"])
+def test_locator_f16_vs_reference_golden(golden_dir, nets3, fixture):
+    """Locator logits of the f16 mode against the reference's (sub-sampled in the fixture), and the binarised decisions (logit > 0.5,
+    watermarking.py:717) wherever the reference's logit is further from the threshold than 4 x the measured error."""
+    import os
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    if "loc_logits_sub" not in g.files:
+        pytest.skip("fixture holds no locator output")
+    L = nets3["locator"]
+    wm = torch.from_numpy(g["wm"]).cuda()
+    lg = L.locator(wm, precision="f16").cpu().numpy()
+    T = lg.shape[-1]
+    step = -(-T // g["loc_logits_sub"].shape[-1])
+    sub = lg[..., ::step]
+    if sub.shape != g["loc_logits_sub"].shape:
+        sub = lg[..., ::7]
+    assert sub.shape == g["loc_logits_sub"].shape, (sub.shape, g["loc_logits_sub"].shape)
+    ref = g["loc_logits_sub"]
+    err = float(np.abs(sub - ref).max())
+    print(f"{fixture}: f16-mode locator logits max|d| {err:.2e} (|logit| max {np.abs(ref).max():.2f})")
+    assert err <= 0.03 * max(1.0, float(np.abs(ref).max())), err
+    far = np.abs(ref - 0.5) > 4 * err
+    assert ((sub > 0.5) == (ref > 0.5))[far].all() and far.mean() > 0.9
+    lg32 = L.locator(wm).cpu().numpy()
+    assert float(np.abs(lg - lg32).max()) <= 0.03 * max(1.0, float(np.abs(lg32).max()))
+
+
+@pytest.mark.parametrize("B,T", [(1, 16000), (3, 12345), (2, 333), (1, 1), (2, 321), (1, 48001)])
+def test_generator_locator_f16_shapes(nets3, B, T):
+    """Ragged lengths and batch sizes through the whole f16 embed + locate: finite, within the wm bar of the exact path, independent of
+    the batch a clip sits in, deterministic."""
+    from waveverify_amd.init import synthetic_clips
+    x_np, msg_np = synthetic_clips(B, T, seed=B + T)
+    x, msg = torch.from_numpy(x_np).cuda(), torch.from_numpy(msg_np).cuda()
+    G, L = nets3["generator"], nets3["locator"]
+    wm = G.generator(x, msg, add_input=True, precision="f16")
+    wm32 = G.generator(x, msg, add_input=True)
+    assert torch.isfinite(wm).all() and float((wm - wm32).abs().max()) <= WM_BAR
+    assert torch.equal(G.generator(x, msg, add_input=True, precision="f16"), wm)
+    one = G.generator(x[B - 1:B].contiguous(), msg[B - 1:B].contiguous(), add_input=True, precision="f16")
+    assert torch.equal(one[0], wm[B - 1])
+    assert torch.equal(G.generator(x, msg[:1].contiguous().repeat(B, 1), add_input=True, precision="f16"),
+                       G.generator(x, msg[:1].contiguous(), add_input=True, precision="f16"))          # one message for the batch (watermarking.py:320-329)
+    lg = L.locator(wm, precision="f16")
+    lg32 = L.locator(wm)
+    assert torch.isfinite(lg).all() and float((lg - lg32).abs().max()) <= 0.03 * max(1.0, float(lg32.abs().max()))
+    assert torch.equal(L.locator(wm[B - 1:B].contiguous(), precision="f16")[0], lg[B - 1])
+
+
+def test_generator_f16_against_the_oracle_at_batch_8(nets3):
+    """Eight synthetic clips (SURVEY 8d's inputs): wm of the f16 mode against the numpy oracle, max|d| <= 1e-4, BER 0 through both detectors."""
+    from waveverify_amd.config import default_config
+    from waveverify_amd.init import random_state_dict, synthetic_clips
+    x_np, msg_np = synthetic_clips(8, 16000)
+    cfg_g, cfg_d = default_config("generator"), default_config("detector")
+    wm_ref = O.embed(cfg_g, random_state_dict(cfg_g, 0), x_np, msg_np)
+    mp_ref = O.mean_probabilities(O.detector_forward(cfg_d, random_state_dict(cfg_d, 0), wm_ref))
+    wm = nets3["generator"].generator(torch.from_numpy(x_np).cuda(), torch.from_numpy(msg_np).cuda(), add_input=True, precision="f16")
+    err = float(np.abs(wm.cpu().numpy() - wm_ref).max())
+    print(f"f16-mode wm max|d| vs oracle, 8 clips: {err:.2e}")
+    assert err <= WM_BAR
+    for prec in ("f32", "f16"):
+        mp = nets3["detector"].detector_mean_prob(wm, precision=prec).cpu().numpy()
+        assert ((mp >= 0.5) == (mp_ref >= 0.5)).all()
+
+
+def test_f16_batch_1024_rows_equal_a_small_batch(nets3):
+    """configs[4] at full size in the f16 mode (the c8 tensors cross 2 GiB there): rows {0, 512, 1016 ..} of a 1024-clip run are bit-equal to
+    the same clips in an 8-clip run (mirror of test_detector_batch_1024 for the exact path)."""
+    from waveverify_amd.init import synthetic_clips
+    x_np, _ = synthetic_clips(8, 16000, seed=77)
+    x8 = torch.from_numpy(x_np).cuda()
+    big = x8.repeat(128, 1, 1).contiguous()                       # row i = clip i % 8
+    D = nets3["detector"]
+    mp8 = D.detector_mean_prob(x8, precision="f16")
+    mp = D.detector_mean_prob(big, precision="f16")
+    assert torch.isfinite(mp).all()
+    for row in (0, 1, 511, 512, 1016, 1023):
+        assert torch.equal(mp[row], mp8[row % 8]), row
+    del big, mp
+    torch.cuda.empty_cache()
+
+
+def test_generator_f16_batch_256_rows_equal_a_small_batch(nets3):
+    """The headline batch through the f16 generator: rows of a 256-clip run bit-equal to an 8-clip run (which the golden / oracle tests hold)."""
+    from waveverify_amd.init import synthetic_clips
+    x_np, msg_np = synthetic_clips(8, 16000, seed=78)
+    x8, m8 = torch.from_numpy(x_np).cuda(), torch.from_numpy(msg_np).cuda()
+    G = nets3["generator"]
+    wm8 = G.generator(x8, m8, add_input=True, precision="f16")
+    wm = G.generator(x8.repeat(32, 1, 1).contiguous(), m8.repeat(32, 1).contiguous(), add_input=True, precision="f16")
+    for row in (0, 17, 128, 255):
+        assert torch.equal(wm[row], wm8[row % 8]), row
+    del wm
+    torch.cuda.empty_cache()
+
+
+def test_generator_f16_captures_into_a_hip_graph(nets3):
+    from waveverify_amd.init import synthetic_clips
+    x_np, msg_np = synthetic_clips(2, 8000, seed=5)
+    x, msg = torch.from_numpy(x_np).cuda(), torch.from_numpy(msg_np).cuda()
+    G = nets3["generator"]
+    w0 = G.generator(x, msg, add_input=True, precision="f16")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        G.generator(x, msg, add_input=True, precision="f16")
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        w1 = G.generator(x, msg, add_input=True, precision="f16")
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(w1, w0)

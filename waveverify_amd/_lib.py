@@ -151,6 +151,12 @@ SIGNATURES = {
     "wv_h16_conv": (C.c_int, [_VP] * 8 + [C.c_int] * 7 + [C.c_float, C.c_float, _VP]),
     "wv_h16_spec_block": (C.c_int, [_VP] * 6 + [C.c_int] * 5 + [C.c_float] * 4 + [_VP]),
     "wv_detector_forward_f16": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_locator_forward_f16": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_generator_forward_f16": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "wv_h16_upsample": (C.c_int, [_VP] * 6 + [C.c_int] * 5 + [C.c_float, _VP]),
+    "wv_h16_tail": (C.c_int, [_VP] * 5 + [C.c_int] * 5 + [C.c_float, _VP]),
+    "wv_h16_l2norm": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP]),
+    "wv_h16_conv_film": (C.c_int, [_VP] * 5 + [C.c_int] + [_VP] * 2 + [C.c_int] * 7 + [C.c_float, _VP]),
     "wv_op_resblock": (C.c_int, [_VP, C.c_float] + [_VP] * 8 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _VP]),
     "wv_op_dw_pw": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, _VP, C.c_float, _VP]),

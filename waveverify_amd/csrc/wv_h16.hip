@@ -48,9 +48,6 @@ constexpr int H_OOB = 0x7f000000;                               // byte offset b
 __device__ __forceinline__ float rh_dpp_next(float v) {        // lane i <- lane i+1 (wave_shl:1), lane 63 <- 0
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
-__device__ __forceinline__ void rh_fma_next(float& y, float h, float w) {
-    asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(y) : "v"(h), "v"(w));
-}
 
 // 5-tap stencil from the accumulators (wv_rb.hip's): y[e] = bias + sum_i w[i] * H[NT*q + e + i], the lane's NT consecutive columns in
 // its NT accumulators, the columns past them from the next lane(s) as DPP operands of the multiply-adds.
@@ -60,12 +57,14 @@ __device__ __forceinline__ void rh_stencil(const f32x16 (&acc)[NT], int r, const
     float own[NT];
 #pragma unroll
     for (int e = 0; e < NT; ++e) own[e] = acc[e][r];
-    // The DPP multiply-adds below are inline asm: the compiler does not see that they read `own` / `sh` from ANOTHER lane and keeps no
-    // distance between a write of those registers (a copy out of an accumulator register, a reload) and the DPP read (2 wait states on
-    // gfx9).  Materialise them here and wait once; nothing writes them after this point.  (Seen live: a 128-register build of this
-    // kernel returned wrong values in one lane pair per row group, differently from run to run.)
-    if constexpr (NT == 4) asm volatile("s_nop 1" : "+v"(own[0]), "+v"(own[1]), "+v"(own[2]), "+v"(own[3]));
-    else asm volatile("s_nop 1" : "+v"(own[0]), "+v"(own[1]));
+    // The neighbour lanes' taps are DPP operands of the multiply-adds themselves (v_fmac_f32_dpp ... wave_shl:1: a fused multiply-add,
+    // rounds like fmaf).  They are inline asm: the compiler does not see that they read `own` / `sh` from ANOTHER lane and keeps no
+    // distance between a write of those registers (a copy out of an accumulator register, a reload, the shifted copy's v_mov_dpp) and
+    // the DPP read (2 wait states on gfx9; seen live: a 128-register build returned wrong values in one lane pair per row group,
+    // differently from run to run).  Each DPP sequence is therefore ONE asm statement that opens with the wait: whatever the
+    // compiler writes in front of the statement is two wait states old at the first cross-lane read, and it cannot put anything
+    // in between.  tools/dpp_hazard.py / tests/test_dpp_hazard.py check the shipped code objects for exactly this.
+#define WV_DPP_FMAC(y, hh, ww) "v_fmac_f32_dpp " y ", " hh ", " ww " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
     if constexpr (NT == 4) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -74,31 +73,45 @@ __device__ __forceinline__ void rh_stencil(const f32x16 (&acc)[NT], int r, const
             for (int i = 0; i + e < 4; ++i) v = fmaf(w[i], own[e + i], v);
             y[e] = v;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 4 - e; i < 5; ++i) rh_fma_next(y[e], own[e + i - 4], w[i]);
+        asm volatile("s_nop 1\n"
+                     WV_DPP_FMAC("%0", "%4", "%11")
+                     WV_DPP_FMAC("%1", "%4", "%10") WV_DPP_FMAC("%1", "%5", "%11")
+                     WV_DPP_FMAC("%2", "%4", "%9") WV_DPP_FMAC("%2", "%5", "%10") WV_DPP_FMAC("%2", "%6", "%11")
+                     WV_DPP_FMAC("%3", "%4", "%8") WV_DPP_FMAC("%3", "%5", "%9") WV_DPP_FMAC("%3", "%6", "%10") WV_DPP_FMAC("%3", "%7", "%11")
+                     : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])
+                     : "v"(own[0]), "v"(own[1]), "v"(own[2]), "v"(own[3]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
     } else {
-        float sh[2] = {rh_dpp_next(own[0]), rh_dpp_next(own[1])};        // columns 2q + 2, 2q + 3
+        const float sh0 = rh_dpp_next(own[0]), sh1 = rh_dpp_next(own[1]);      // columns 2q + 2, 2q + 3 (compiler-visible DPP moves)
         float v0 = fmaf(w[0], own[0], w1.y), v1 = fmaf(w[0], own[1], w1.y);
         v0 = fmaf(w[1], own[1], v0);
-        rh_fma_next(v1, own[0], w[1]);
-        rh_fma_next(v0, own[0], w[2]); rh_fma_next(v1, own[1], w[2]);
-        rh_fma_next(v0, own[1], w[3]);
-        asm volatile("s_nop 1" : "+v"(sh[0]), "+v"(sh[1]));              // the shifted copies are complete (and two wait states old) before they are DPP operands
-        rh_fma_next(v1, sh[0], w[3]);
-        rh_fma_next(v0, sh[0], w[4]); rh_fma_next(v1, sh[1], w[4]);
+        asm volatile("s_nop 1\n"
+                     WV_DPP_FMAC("%1", "%2", "%6")
+                     WV_DPP_FMAC("%0", "%2", "%7") WV_DPP_FMAC("%1", "%3", "%7")
+                     WV_DPP_FMAC("%0", "%3", "%8")
+                     WV_DPP_FMAC("%1", "%4", "%8")
+                     WV_DPP_FMAC("%0", "%4", "%9") WV_DPP_FMAC("%1", "%5", "%9")
+                     : "+v"(v0), "+v"(v1)
+                     : "v"(own[0]), "v"(own[1]), "v"(sh0), "v"(sh1), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
         y[0] = v0; y[1] = v1;
     }
+#undef WV_DPP_FMAC
 }
 
-// C channels, NG column groups of 32*NT columns (overlapping by the stencil's 4), WPS waves per SIMD.  One wave = one 32-row strip x
-// one column group.  RESIDENT: both weight strips of a wave stay in registers for the kernel's life (C <= 128: 2 * C/16 fragments);
-// wider layers stream them through a ring, A_AHEAD chunks in front of their MFMAs.
-template <int C_, int NG_, int NT_, int WPS_, int RING_ = 8, int PD_ = 2, bool RES_ = (C_ <= 128)>
+// log2(e)-domain ELU.  The block's two activations feed matrix products, so their common factor can live in the weights: the kernel
+// keeps a' = log2(e) * ELU(t) (computed from t' = log2(e) * t as med3(t', log2(e) * 2^t' - log2(e), 0): one v_exp_f32, one fma, one
+// v_med3 -- the plain form needs a multiply in front of the exponential and a subtraction behind it) and the host packs W / log2(e).
+// exp(t) - 1 >= t on both sides of zero, so the median picks t' for t > 0 and the exponential branch for t < 0, as elu1 does.
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float elu_l2(float tl) { return __builtin_amdgcn_fmed3f(tl, fmaf(__builtin_amdgcn_exp2f(tl), LOG2E, -LOG2E), 0.f); }
+
+// C channels, NG column groups of 32*NT columns (overlapping by the stencil's 4), WPS waves per SIMD.  One wave = SPW 32-row strips x
+// one column group (SPW = 2: the 384 / 768-channel layers of the generator's decoder, whose B fragments then serve two strips).
+// RESIDENT: both weight strips of a wave stay in registers for the kernel's life (C <= 128: 2 * C/16 fragments); wider layers stream
+// them through a ring, A_AHEAD chunks in front of their MFMAs.
+template <int C_, int NG_, int NT_, int WPS_, int RING_ = 8, int PD_ = 2, bool RES_ = (C_ <= 128), int SPW_ = 1>
 struct RH {
-    static constexpr int C = C_, NG = NG_, NT = NT_, WPS = WPS_, PD = PD_;
-    static constexpr int WM = C / 32, NWAVES = WM * NG, NTHREADS = 64 * NWAVES;
+    static constexpr int C = C_, NG = NG_, NT = NT_, WPS = WPS_, PD = PD_, SPW = SPW_;
+    static constexpr int WM = C / (32 * SPW), NWAVES = WM * NG, NTHREADS = 64 * NWAVES;
     static constexpr int GS = 32 * NT - 4, WD = NG * GS + 4, TTO = WD - 8;
     static constexpr int G = C / 8, NCH = C / 16;
     static constexpr int PIECES = G * WD;                                  // 16-byte (group, column) pieces of a window
@@ -107,23 +120,24 @@ struct RH {
     static constexpr int NA = RESIDENT ? 2 * NCH : RING_, AD = NA - 1;
     static constexpr size_t WBYTES = (size_t)PIECES * 16;
     static constexpr size_t SMEM = WBYTES + (size_t)2 * C * 8 * sizeof(float);
-    static_assert(C % 32 == 0 && (NT == 2 || NT == 4) && NTHREADS <= 1024 && NTHREADS >= C && (2 * NCH) % NA == 0 && (RESIDENT || AD <= NCH),
-                  "geometry");
+    static_assert(C % (32 * SPW) == 0 && (NT == 2 || NT == 4) && NTHREADS <= 1024 && NTHREADS >= C && (2 * NCH) % NA == 0 && (RESIDENT || AD <= NCH) &&
+                  SMEM <= 160 * 1024, "geometry");
 };
 
-// OUT: 1 = Y, 2 = Yact, 3 = both
+// OUT: 1 = Y, 2 = Yact, 3 = both.  Weights arrive divided by log2(e), the first stencil's taps and bias multiplied by it (pack_rh).
 template <class R, int OUT>
 __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::WPS, R::WPS))) void rh_kernel(RhArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int NT = R::NT, C = R::C, WD = R::WD, NCH = R::NCH, G = R::G, NA = R::NA, AD = R::AD;
+    constexpr int NT = R::NT, C = R::C, WD = R::WD, NCH = R::NCH, G = R::G, NA = R::NA, AD = R::AD, SPW = R::SPW;
     h16* S = reinterpret_cast<h16*>(smem_raw);                   // [G][WD][8]
     float* tab = reinterpret_cast<float*>(smem_raw + R::WBYTES); // [2][C][8]: taps, bias
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int strip = wave % R::WM, grp = wave / R::WM;
+    const int strip = (wave % R::WM) * SPW, grp = wave / R::WM;  // first of this wave's SPW strips
     const int h = lane >> 5, q = lane & 31;
     const int T = p.T, ntiles = p.ntiles, num_t = p.num_t;
     const int clip_bytes = G * T * 16;
+    const float pl2 = p.pre_scale * LOG2E;
 
     for (int i = tid; i < C * 8; i += R::NTHREADS) { tab[i] = p.tab1[i]; tab[C * 8 + i] = p.tab2[i]; }
 
@@ -131,10 +145,11 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
     const __amdgpu_buffer_rsrc_t rW1 = uniform_rsrc(p.w1.wq, NCH * C * 32);
     const __amdgpu_buffer_rsrc_t rW2 = uniform_rsrc(p.w2.wq, NCH * C * 32);
     const int avoff = ((32 * strip + q) * 2 + h) * 16;
-    h16x8 ar[NA];
-    auto load_a = [&](const __amdgpu_buffer_rsrc_t& rw, int c, h16x8& dst) {
+    h16x8 ar[NA][SPW];
+    auto load_a = [&](const __amdgpu_buffer_rsrc_t& rw, int c, h16x8 (&dst)[SPW]) {
         const int so = c * C * 32;
-        dst = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, avoff, so, 0));
+#pragma unroll
+        for (int sw = 0; sw < SPW; ++sw) dst[sw] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, avoff + sw * 32 * 32, so, 0));
     };
 
     // ---- this lane's place in a window (wv_rb.hip): rows 32*strip + 8j + 4h + rr (j, rr = 0..3) = group 4*strip + j, halves 4h + rr;
@@ -190,42 +205,48 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RH_BARRIER();
 
-    h16x4 X[4][NT];                                              // raw x where this lane's outputs lie: the residual operand
+    h16x4 X[SPW][4][NT];                                         // raw x where this lane's outputs lie: the residual operand
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / num_t, tt = tile - b * num_t;
         const int to0 = tt * R::TTO;
-        // ================= activation pass: X = x (raw), S = ELU(c * x) in place ======================
+        // ================= activation pass: X = x (raw), S = log2(e) * ELU(c * x) in place ============
         if (hthread) {
             h16x8* hp = reinterpret_cast<h16x8*>(S + (size_t)hpiece * 8);
             h16x8 v = *hp;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (h16)elu1((float)v[i] * p.pre_scale);
+            for (int i = 0; i < 8; ++i) v[i] = (h16)elu_l2(fmaf((float)v[i], pl2, 0.f));
             *hp = v;
         }
         if (own) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int sw = 0; sw < SPW; ++sw)
 #pragma unroll
-                for (int e = 0; e < NT; ++e) X[j][e] = *reinterpret_cast<const h16x4*>(Xrow + (size_t)(j * WD + e) * 8);
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                    for (int e = 0; e < NT; ++e) X[sw][j][e] = *reinterpret_cast<const h16x4*>(Xrow + (size_t)((4 * sw + j) * WD + e) * 8);
 #pragma unroll
-                for (int e = 0; e < NT; ++e) {
-                    h16x4 v;
+            for (int sw = 0; sw < SPW; ++sw)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu1((float)X[j][e][rr] * p.pre_scale);
-                    *reinterpret_cast<h16x4*>(Xrow + (size_t)(j * WD + e) * 8) = v;
-                }
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) {
+                        h16x4 v;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu_l2(fmaf((float)X[sw][j][e][rr], pl2, 0.f));   // (fma with a zero addend: one v_fma_mix_f32 straight from the f16 half)
+                        *reinterpret_cast<h16x4*>(Xrow + (size_t)((4 * sw + j) * WD + e) * 8) = v;
+                    }
         }
         RH_BARRIER();                                            // B1: window complete
         // ================= GEMM 1: H1 = W1 @ S =======================================================
-        f32x16 acc[NT];
+        f32x16 acc[SPW][NT];
         auto gemm = [&](auto g0c, const __amdgpu_buffer_rsrc_t& rw, const __amdgpu_buffer_rsrc_t& rw_next) {
             constexpr int g0 = decltype(g0c)::value;
 #pragma unroll
-            for (int e = 0; e < NT; ++e)
+            for (int sw = 0; sw < SPW; ++sw)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+                for (int e = 0; e < NT; ++e)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[sw][e][r] = 0.f;
             constexpr int PD = R::PD, NB = PD + 1;
             h16x8 bq[NB][NT];
 #pragma unroll
@@ -243,48 +264,54 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
                     for (int e = 0; e < NT; ++e)
                         bq[(c + PD) % NB][e] = *reinterpret_cast<const h16x8*>(Bf + (size_t)(2 * (c + PD) * WD + e) * 8);
                 }
-                const h16x8 a = ar[(g0 + c) % NA];
 #pragma unroll
-                for (int e = 0; e < NT; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[c % NB][e], acc[e], 0, 0, 0);
-                // one sequence point per chunk over all NT accumulator chains: left alone the compiler runs the chains one after the
+                for (int sw = 0; sw < SPW; ++sw)
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) acc[sw][e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[(g0 + c) % NA][sw], bq[c % NB][e], acc[sw][e], 0, 0, 0);
+                // one sequence point per chunk over all accumulator chains: left alone the compiler runs the chains one after the
                 // other over the whole GEMM and parks the other chains' operands in scratch
-                if constexpr (NT == 4) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-                else asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+#pragma unroll
+                for (int sw = 0; sw < SPW; ++sw) {
+                    if constexpr (NT == 4) asm volatile("" : "+v"(acc[sw][0]), "+v"(acc[sw][1]), "+v"(acc[sw][2]), "+v"(acc[sw][3]));
+                    else asm volatile("" : "+v"(acc[sw][0]), "+v"(acc[sw][1]));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         gemm(std::integral_constant<int, 0>{}, rW1, rW2);
         RH_BARRIER();                                            // B2: every wave has read the window (u overwrites it)
-        // ================= epilogue 1: u = ELU(DW5(H1) + b1) -> S ======================================
+        // ================= epilogue 1: u' = log2(e) * ELU(DW5(H1) + b1) -> S (taps and bias carry the log2(e)) ============
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float uu[4][NT];
+        for (int sw = 0; sw < SPW; ++sw)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int cr = rr + 8 * j;
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wrow1 + cr * 8), w1 = *reinterpret_cast<const f32x4*>(Wrow1 + cr * 8 + 4);
-                float y[NT];
-                rh_stencil<NT>(acc, 4 * j + rr, w0, w1, y);
+            for (int j = 0; j < 4; ++j) {
+                float uu[4][NT];
 #pragma unroll
-                for (int e = 0; e < NT; ++e) uu[rr][e] = elu1(y[e]);
-            }
-            if (uw) {
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int cr = rr + 8 * j + 32 * sw;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wrow1 + cr * 8), w1 = *reinterpret_cast<const f32x4*>(Wrow1 + cr * 8 + 4);
+                    float y[NT];
+                    rh_stencil<NT>(acc[sw], 4 * j + rr, w0, w1, y);
 #pragma unroll
-                for (int e = 0; e < NT; ++e) {
-                    h16x4 v;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)uu[rr][e];
-                    *reinterpret_cast<h16x4*>(Urow + (size_t)(j * WD + e) * 8) = v;
+                    for (int e = 0; e < NT; ++e) uu[rr][e] = elu_l2(y[e]);
                 }
+                if (uw) {
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) {
+                        h16x4 v;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)uu[rr][e];
+                        *reinterpret_cast<h16x4*>(Urow + (size_t)((4 * sw + j) * WD + e) * 8) = v;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
         if (tt == 0 && grp == 0 && NT * q < 4) {                 // u at times < 0 is the second conv's zero padding
             h16x4 z;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) z[rr] = (h16)0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4 * SPW; ++j)
 #pragma unroll
                 for (int e = 0; e < NT; ++e) *reinterpret_cast<h16x4*>(Urow + (size_t)(j * WD + e) * 8) = z;
         }
@@ -307,38 +334,51 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
             const int jstep = T * 16;
             refill(next);                                        // ahead of the stores below (one in-order queue)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float yy[4][NT];
+            for (int sw = 0; sw < SPW; ++sw)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int cr = rr + 8 * j;
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wrow2 + cr * 8), w1 = *reinterpret_cast<const f32x4*>(Wrow2 + cr * 8 + 4);
-                    float v[NT];
-                    rh_stencil<NT>(acc, 4 * j + rr, w0, w1, v);
+                for (int j = 0; j < 4; ++j) {
+                    h16x4 yh[NT];
+                    float yy[4][NT];
 #pragma unroll
-                    for (int e = 0; e < NT; ++e) yy[rr][e] = fmaf(v[e], p.out_scale, (float)X[j][e][rr]);
-                }
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int cr = rr + 8 * j + 32 * sw;
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wrow2 + cr * 8), w1 = *reinterpret_cast<const f32x4*>(Wrow2 + cr * 8 + 4);
+                        float v[NT];
+                        rh_stencil<NT>(acc[sw], 4 * j + rr, w0, w1, v);
 #pragma unroll
-                for (int e = 0; e < NT; ++e) {
-                    const int off = voff[e] == H_OOB ? H_OOB : voff[e] + j * jstep;
-                    if constexpr ((OUT & 1) != 0) {
-                        h16x4 v;
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)yy[rr][e];
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rY, off, 0, 0);
+                        for (int e = 0; e < NT; ++e) {
+                            if constexpr (OUT == 1) {
+                                // y = f16(v * s + x) in ONE instruction: the f16 residual half is a source operand and the f16 result
+                                // lands in its half of the output register (the compiler's own choice here is two conversions, a
+                                // packed fma and a packed conversion: 2 instructions per element instead of 1)
+                                unsigned* yo = reinterpret_cast<unsigned*>(&yh[e]) + (rr >> 1);
+                                const unsigned xi = reinterpret_cast<const unsigned*>(&X[sw][j][e])[rr >> 1];
+                                if constexpr (true) {
+                                    if ((rr & 1) == 0) asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(*yo) : "v"(v[e]), "v"(p.out_scale), "v"(xi));
+                                    else asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(*yo) : "v"(v[e]), "v"(p.out_scale), "v"(xi));
+                                }
+                            } else {
+                                yy[rr][e] = fmaf(v[e], p.out_scale, (float)X[sw][j][e][rr]);
+                                yh[e][rr] = (h16)yy[rr][e];
+                            }
+                        }
                     }
-                    if constexpr ((OUT & 2) != 0) {
-                        h16x4 v;
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu1(yy[rr][e] * p.act_scale);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rA, off, 0, 0);
+                    for (int e = 0; e < NT; ++e) {
+                        const int off = voff[e] == H_OOB ? H_OOB : voff[e] + (4 * sw + j) * jstep;
+                        if constexpr ((OUT & 1) != 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yh[e]), rY, off, 0, 0);
+                        if constexpr ((OUT & 2) != 0) {
+                            h16x4 v;
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu1(yy[rr][e] * p.act_scale);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rA, off, 0, 0);
+                        }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
         // the refill is older than this epilogue's stores: wait until only those are outstanding, then meet the other waves
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NT * ((OUT & 1) + (OUT >> 1))) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * SPW * NT * ((OUT & 1) + (OUT >> 1))) : "memory");
         RH_BARRIER();                                            // B0: the next window has landed
     }
 }
@@ -482,28 +522,38 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
                 for (int e = 0; e < 2; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bb[e], acc[mt][e], 0, 0, 0);
         }
     }
-    // ---- epilogue: rows m0 + 32 mt + 8 j + 4 h + rr, columns n0 + 32 e + q
-    const int ybytes = FLAT ? (int)(yclip * 2 * p.B) : (int)(yclip * 2);
-    const size_t ybase = FLAT ? 0 : bclip * yclip;
+    // ---- epilogue: rows m0 + 32 mt + 8 j + 4 h + rr, columns n0 + 32 e + q.  up > 0: row = (phase, channel), column l -> time l * up + phase
+    const int upr = p.up > 0 ? p.up : 1, Mo = p.up > 0 ? p.M / p.up : p.M, To = Tout * upr;
+    const size_t yclip_o = (size_t)((Mo + 15) / 16 * 2) * To * 8;
+    const int ybytes = FLAT ? (int)(yclip_o * 2 * p.B) : (int)(yclip_o * 2);
+    const size_t ybase = FLAT ? 0 : bclip * yclip_o;
     const __amdgpu_buffer_rsrc_t rR = uniform_rsrc(p.resid ? reinterpret_cast<const h16*>(p.resid) + ybase : reinterpret_cast<const h16*>(p.X), p.resid ? ybytes : 0);
     const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(p.Y ? reinterpret_cast<h16*>(p.Y) + ybase : reinterpret_cast<const h16*>(p.X), p.Y ? ybytes : 0);
     const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(p.Yact ? reinterpret_cast<h16*>(p.Yact) + ybase : reinterpret_cast<const h16*>(p.X), p.Yact ? ybytes : 0);
+    const int bw = p.film ? Mo / p.bands : 1;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int mrow = m0 + 32 * mt + 8 * j + 4 * h;      // first of this lane's 4 rows
+            const int ph = p.up > 0 ? mrow / Mo : 0, mch = mrow - ph * Mo;
             float bias[4];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) bias[rr] = (p.bias && mrow + rr < p.M) ? p.bias[mrow + rr] : 0.f;
+            for (int rr = 0; rr < 4; ++rr) bias[rr] = (p.bias && mrow + rr < p.M) ? p.bias[mch + rr] : 0.f;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int to = to_[e];
                 const bool ok = colok[e] && mrow < p.M;
-                const int off = ok ? (FLAT ? cb_[e] * (int)(yclip * 2) : 0) + ((mrow >> 3) * Tout + to) * 16 + 8 * h : H_OOB;
+                const int off = ok ? (FLAT ? cb_[e] * (int)(yclip_o * 2) : 0) + ((mch >> 3) * To + to * upr + ph) * 16 + 8 * h : H_OOB;
                 float y[4];
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) y[rr] = (acc[mt][e][4 * j + rr] + bias[rr]) * p.out_scale;
+                if (p.film && ok) {
+                    const float* fl = p.film + (size_t)cb_[e] * p.film_stride + 2 * (mch / bw);
+                    const float gam = fl[0], bet = fl[1];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) y[rr] = fmaf(gam, y[rr], bet);
+                }
                 if (p.resid) {
                     const h16x4 rv = __builtin_bit_cast(h16x4, __builtin_amdgcn_raw_buffer_load_b64(rR, off, 0, 0));
 #pragma unroll
@@ -947,6 +997,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float y[4];
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) y[rr] = (acc[mt][e][4 * j + rr] + bias[rr]) * p.out_scale;
+                if (p.film && ok) {
+                    const float* fl = p.film + (size_t)clip * p.film_stride + 2 * (mrow / (p.M / p.bands));
+                    const float gam = fl[0], bet = fl[1];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) y[rr] = fmaf(gam, y[rr], bet);
+                }
                 if (p.Y) {
                     h16x4 v;
 #pragma unroll
@@ -1147,10 +1203,55 @@ __global__ __launch_bounds__(256) void c8_to_f32_kernel(const h16* __restrict__ 
     }
 }
 
+// L2Norm over the channels of a latent [B][D][Fr] f32 (seanet.py:288-318) written as c8 f16: one thread per (clip, frame).
+__global__ __launch_bounds__(256) void l2norm_c8_kernel(const float* __restrict__ X, h16* __restrict__ Y, int D, int Fr, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / Fr, t = i - b * Fr;
+    const float* xb = X + (size_t)b * D * Fr + t;
+    float ss = 0.f;
+    for (int c = 0; c < D; ++c) { const float v = xb[(size_t)c * Fr]; ss = fmaf(v, v, ss); }
+    const float inv = sqrtf((float)D) / fmaxf(sqrtf(ss), 1e-12f);
+    const int G = (D + 15) / 16 * 2;
+    for (int g = 0; g < G; ++g) {
+        h16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c = 8 * g + j; o[j] = (h16)(c < D ? xb[(size_t)c * Fr] * inv : 0.f); }
+        *reinterpret_cast<h16x8*>(Y + (((size_t)b * G + g) * Fr + t) * 8) = o;
+    }
+}
+
+// Decoder tail on the pre-activated c8 input (the last ResnetBlock writes ELU(s * y)): one thread per output sample walks the channel
+// groups; a wave's 16-byte pieces of one (group, tap) are contiguous, each piece is read by KS neighbouring threads (L1 hits).  Taps
+// come as wide scalar loads (KS at compile time).  Sums are f32: f16 x f32 multiply-adds straight from the halves.
+template <int KS>
+__global__ __launch_bounds__(256) void tail16_kernel(const h16* __restrict__ A, const float* __restrict__ w, const float* __restrict__ bias,
+                                                     const float* __restrict__ x, float* __restrict__ out, int C, int Tin, int T, float out_scale) {
+    const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int G = (C + 15) / 16 * 2;
+    const h16* ab = A + (size_t)b * G * Tin * 8;
+    float y = bias ? bias[0] : 0.f;
+    for (int g = 0; g < C / 8; ++g) {
+        const float* wg = w + (size_t)g * 8 * KS;              // w[c][i], c = 8 g + j
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int ti = t - (KS - 1) + i;
+            if (ti < 0 || ti >= Tin) continue;
+            const h16x8 v = *reinterpret_cast<const h16x8*>(ab + ((size_t)g * Tin + ti) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y = fmaf((float)v[j], wg[j * KS + i], y);
+        }
+    }
+    float r = tanhf(y * out_scale);
+    if (x) r += x[(size_t)b * T + t];
+    out[(size_t)b * T + t] = r;
+}
+
 }  // namespace
 
 bool rh_supported(const RhArgs& a) {
-    if (!(a.C == 64 || a.C == 128 || a.C == 256 || a.C == 512)) return false;
+    if (!(a.C == 32 || a.C == 64 || a.C == 96 || a.C == 128 || a.C == 192 || a.C == 256 || a.C == 384 || a.C == 512 || a.C == 768)) return false;
     if (!a.X || (!a.Y && !a.Yact) || a.T < 1 || a.B < 1 || !a.w1.wq || !a.w2.wq || !a.tab1 || !a.tab2) return false;
     if (a.w1.M != a.C || a.w1.K != a.C || a.w2.M != a.C || a.w2.K != a.C || a.w1.Mp != a.C || a.w2.Mp != a.C || a.w1.Kp != a.C || a.w2.Kp != a.C) return false;
     if ((long long)a.C * a.T * 2 >= H_OOB) return false;
@@ -1159,11 +1260,16 @@ bool rh_supported(const RhArgs& a) {
 
 hipError_t launch_resblock16(const RhArgs& a, hipStream_t s) {
     if (!rh_supported(a)) return hipErrorNotSupported;
-    switch (a.C) {
+    switch (a.C) {                                               // <C, column groups, NT, waves per SIMD, A ring, B ring depth, resident A, strips per wave>
+        case 32: return rh_pick_out<RH<32, 8, 2, 4>>(a, s);      // 1 x 8 waves, 484-column windows (the locator's first stage)
         case 64: return rh_pick_out<RH<64, 4, 2, 4>>(a, s);      // 2 x 4 waves, 244-column windows
+        case 96: return rh_pick_out<RH<96, 2, 2, 4, 6, 2, false>>(a, s);    // 3 x 2 waves, 124-column windows, two workgroups per CU
         case 128: return rh_pick_out<RH<128, 2, 2, 4, 8, 2, false>>(a, s);  // 4 x 2 waves, 124-column windows (32 KB), weights streamed
+        case 192: return rh_pick_out<RH<192, 2, 2, 3, 8, 2, false>>(a, s);  // 6 x 2 waves, 124-column windows
         case 256: return rh_pick_out<RH<256, 1, 2, 4, 4, 1>>(a, s); // 8 x 1 waves, 64-column windows (32 KB)
-        default: return rh_pick_out<RH<512, 1, 2, 4, 4, 1>>(a, s); // 16 x 1 waves, 64-column windows (64 KB)
+        case 384: return rh_pick_out<RH<384, 1, 2, 3, 4, 1>>(a, s); // 12 x 1 waves, 64-column windows (48 KB)
+        case 512: return rh_pick_out<RH<512, 1, 2, 4, 4, 1>>(a, s); // 16 x 1 waves, 64-column windows (64 KB)
+        default: return rh_pick_out<RH<768, 1, 2, 3, 4, 1, false, 2>>(a, s); // 12 x 1 waves of two strips each, 64-column windows (96 KB)
     }
 }
 
@@ -1173,18 +1279,22 @@ hipError_t launch_conv16(const Conv16Args& a, hipStream_t s) {
     if ((long long)a.w.Kp * a.Tin * 2 >= H_OOB || (long long)round_up(a.M, 16) * a.Tout * 2 >= H_OOB || (long long)a.w.nchunks * a.w.Mp * 32 >= H_OOB)
         return hipErrorInvalidValue;
     if (!al16(a.X) || !al16(a.w.wq) || (a.Y && !al16(a.Y)) || (a.Yact && !al16(a.Yact)) || (a.resid && !al16(a.resid))) return hipErrorInvalidValue;
-    if ((a.Y || a.Yact || a.resid) && (a.M % 16)) return hipErrorInvalidValue;  // c8 outputs: whole 16-channel group pairs
+    if (a.up < 0 || (a.up > 0 && (a.M % a.up || a.resid || a.Yf32 || a.stride != 1 || (a.M / a.up) % 16))) return hipErrorInvalidValue;
+    const int Mo = a.up > 0 ? a.M / a.up : a.M, upr = a.up > 0 ? a.up : 1;
+    if ((a.Y || a.Yact || a.resid) && (Mo % 16)) return hipErrorInvalidValue;   // c8 outputs: whole 16-channel group pairs
+    if (a.film && (a.bands < 1 || Mo % a.bands || (Mo / a.bands) % 4 || a.film_stride < 2 * a.bands)) return hipErrorInvalidValue;
+    if ((long long)round_up(Mo, 16) * a.Tout * upr * 2 >= H_OOB) return hipErrorInvalidValue;
     // few outputs per clip: the clips' columns as one run (flat), four waves side by side on the same rows of W (its fragments are L1 hits
     // for three of them); else per-clip column tiles with the waves stacked over the rows
-    const long long xbytes = (long long)a.w.Kp * a.Tin * 2 * a.B, ybytes = (long long)round_up(a.M, 16) * a.Tout * 2 * a.B;
+    const long long xbytes = (long long)a.w.Kp * a.Tin * 2 * a.B, ybytes = (long long)round_up(Mo, 16) * a.Tout * upr * 2 * a.B;
     const bool flat = a.Tout < 512 && xbytes < H_OOB && ybytes < H_OOB;
     // the strided layers' own kernel (x through LDS): 2 * stride taps, stride 4 / 5 / 8, no residual, at least 256 rows
-    const bool staged = a.ks == 2 * a.stride && a.pad == a.stride && (a.ks == 8 || a.ks == 10 || a.ks == 16) && !a.resid && a.M >= 256 && ybytes < H_OOB &&
+    const bool staged = a.ks == 2 * a.stride && a.pad == a.stride && (a.ks == 8 || a.ks == 10 || a.ks == 16) && !a.resid && !a.up && a.M >= 256 && ybytes < H_OOB &&
                         (a.Tout > 64 || xbytes < H_OOB);
     std::string name;
     if (prof::enabled())
         name = "conv16<k" + std::to_string(a.ks) + ",s" + std::to_string(a.stride) + "," + std::to_string(a.M) + "x" + std::to_string(a.w.K) +
-               (staged ? ",lds>" : (flat ? ",flat>" : ">"));
+               (a.up ? ",up" + std::to_string(a.up) : std::string()) + (staged ? ",lds>" : (flat ? ",flat>" : ">"));
     const double Bd = a.B, M = a.M;
     prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * a.ks * (double)a.w.K * a.Tout,
                    Bd * (2.0 * a.w.Kp * a.Tin + (a.resid ? 2.0 : 0.0) * M * a.Tout + (a.Y ? 2.0 : 0.0) * M * a.Tout + (a.Yact ? 2.0 : 0.0) * M * a.Tout +
@@ -1253,6 +1363,27 @@ hipError_t launch_f32_to_c8(const float* X, void* Y, int B, int C, int T, float 
     if (!X || !Y || B < 1 || B > 65535 || C < 1 || Gp > 65535 || T < 1) return hipErrorInvalidValue;
     prof::Scope ps(s, "f32_to_c8", 0.0, (double)B * T * (4.0 * C + 16.0 * Gp));
     hipLaunchKernelGGL(f32_to_c8_kernel, dim3((T + 255) / 256, Gp, B), dim3(256), 0, s, X, reinterpret_cast<h16*>(Y), C, Gp, T, scale, elu);
+    return hipGetLastError();
+}
+
+hipError_t launch_l2norm_c8(const float* X, void* Y, int B, int D, int Fr, hipStream_t s) {
+    if (!X || !Y || B < 1 || D < 1 || Fr < 1 || (long long)B * Fr > 0x7fffffffLL) return hipErrorInvalidValue;
+    prof::Scope ps(s, "l2norm_c8", 3.0 * B * D * (double)Fr, (double)B * Fr * (4.0 * D + 2.0 * round_up(D, 16)));
+    const int total = B * Fr;
+    hipLaunchKernelGGL(l2norm_c8_kernel, dim3((total + 255) / 256), dim3(256), 0, s, X, reinterpret_cast<h16*>(Y), D, Fr, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_tail16(const void* A16, const float* w, const float* bias, const float* x, float* out, int B, int C, int Tin, int T, int ks, float out_scale,
+                         hipStream_t s) {
+    if (!A16 || !w || !out || B < 1 || B > 65535 || C < 8 || (C % 8) || Tin < 1 || T < 1 || T > Tin) return hipErrorInvalidValue;
+    if (ks != 5 && ks != 7 && ks != 3) return hipErrorNotSupported;
+    prof::Scope ps(s, "tail16", 2.0 * B * C * ks * (double)T, (double)B * (2.0 * C * Tin + 8.0 * T));
+    const dim3 grid((T + 255) / 256, B);
+    const h16* A = reinterpret_cast<const h16*>(A16);
+    if (ks == 5) hipLaunchKernelGGL(tail16_kernel<5>, grid, dim3(256), 0, s, A, w, bias, x, out, C, Tin, T, out_scale);
+    else if (ks == 7) hipLaunchKernelGGL(tail16_kernel<7>, grid, dim3(256), 0, s, A, w, bias, x, out, C, Tin, T, out_scale);
+    else hipLaunchKernelGGL(tail16_kernel<3>, grid, dim3(256), 0, s, A, w, bias, x, out, C, Tin, T, out_scale);
     return hipGetLastError();
 }
 

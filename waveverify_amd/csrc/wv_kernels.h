@@ -134,16 +134,58 @@ inline std::vector<uint16_t> pack_h16(const float* pw, const float* dw, int M, i
     *out = w;
     return q;
 }
-struct RhArgs {               // whole ResnetBlock, c8 f16 in / out (C in {64, 128, 256, 512}, k = 5, dilation 1)
-    const void* X; float pre_scale; H16Weight w1, w2; const float* tab1; const float* tab2;   // tabs: pack_rb_table (f32)
+// whole ResnetBlock, c8 f16 in / out (C in {32, 64, 96, 128, 192, 256, 384, 512, 768}, k = 5, dilation 1).  The kernel keeps both
+// activations times log2(e) (one instruction less per ELU, wv_h16.hip elu_l2), so the operands arrive pre-scaled -- pack_rh_pw /
+// pack_rh_table1: w1, w2 = the 1x1 weights DIVIDED by log2(e); tab1 = the first stencil's taps and bias TIMES log2(e); tab2 plain
+// (pack_rb_table).
+struct RhArgs {
+    const void* X; float pre_scale; H16Weight w1, w2; const float* tab1; const float* tab2;
     void* Y; void* Yact; float out_scale, act_scale; int B, C, T; int num_t, ntiles;
 };
+constexpr double RH_LOG2E = 1.4426950408889634;
+inline std::vector<uint16_t> pack_rh_pw(const float* pw, int C, H16Weight* out) {
+    std::vector<float> t((size_t)C * C);
+    for (size_t i = 0; i < t.size(); ++i) t[i] = (float)((double)pw[i] / RH_LOG2E);
+    return pack_h16(t.data(), nullptr, C, C, 1, out);
+}
+inline std::vector<float> pack_rh_table1(const float* dw_w, const float* dw_b, int C) {
+    std::vector<float> t = pack_rb_table(dw_w, dw_b, C);
+    for (int m = 0; m < C; ++m)
+        for (int i = 0; i < 6; ++i) t[(size_t)m * 8 + i] = (float)((double)t[(size_t)m * 8 + i] * RH_LOG2E);
+    return t;
+}
 bool rh_supported(const RhArgs& a);
 hipError_t launch_resblock16(const RhArgs& a, hipStream_t s);
 struct Conv16Args {           // y = out_scale * (bias + conv(x)) + resid; x, resid, Y, Yact c8 f16; Yf32 [B][M][Tout] f32 row-major
     const void* X; H16Weight w; const float* bias; const void* resid; void* Y; void* Yact; float* Yf32;
     float out_scale, act_scale; int B, M, Tin, Tout, ks, stride, pad;
+    // FiLM (seanet.py:518-550, 928-966) behind the conv: y = gamma[b][band] * y + beta[b][band], band = m / (M / bands);
+    // film[b * film_stride + 2 * band + {0, 1}], or null
+    const float* film = nullptr; int bands = 1, film_stride = 0;
+    // up = r > 0: the rows are r phases of Mo = M / r output channels (row p * Mo + m: pack_up16) and row (p, m) at input time l is
+    // output channel m at time l * r + p -- the decoder's upsample unit as ONE conv over the input frames; Y / Yact are
+    // [B][Mo / 8][Tout * r][8], bias has Mo entries.  No resid / Yf32 in this form.
+    int up = 0;
 };
+// host: the decoder's upsample unit ELU -> depth-wise ConvTranspose1d(2r, stride r), right-trimmed by r -> 1x1 (seanet.py:1147-1170,
+// conv.py:838-881) composed into a 2-tap conv over the INPUT frames: out[m][r l + p] = b[m] + sum_k pw[m][k] * (ct[k][p] * a[k][l] +
+// ct[k][p + r] * a[k][l - 1]), i.e. rows (p, m), taps i = 0 (frame l - 1: ct[k][p + r]) and i = 1 (frame l: ct[k][p]), causal pad 1.
+inline std::vector<uint16_t> pack_up16(const float* pw, const float* ct, int Mo, int K, int r, H16Weight* out) {
+    H16Weight w; w.K = K; w.M = Mo * r; w.Kp = round_up(K, 16); w.Mp = round_up(w.M, 32);
+    const int nkc = w.Kp / 16;
+    w.nchunks = round_up(2 * nkc, 8);
+    std::vector<uint16_t> q((size_t)w.nchunks * w.Mp * 16, 0);
+    for (int i = 0; i < 2; ++i)
+        for (int p = 0; p < r; ++p)
+            for (int m = 0; m < Mo; ++m) {
+                const size_t row = (size_t)p * Mo + m;
+                for (int k = 0; k < K; ++k)
+                    q[(((size_t)((k / 16) * 2 + i) * w.Mp + row) * 2 + ((k >> 3) & 1)) * 8 + (k & 7)] =
+                        f32_to_f16_bits(pw[(size_t)m * K + k] * ct[(size_t)k * 2 * r + (i == 0 ? p + r : p)]);
+            }
+    *out = w;
+    return q;
+}
 hipError_t launch_conv16(const Conv16Args& a, hipStream_t s);
 // whole SpecBlock (STFT on the f16 pipe with a two-term split of the waveform -> log-magnitude -> 1x1 -> + x), the spectrogram stays in LDS.
 // cosw / sinw: the basis' cos rows f = 0 .. n_fft/2 - 1 and sin rows (row 0 = the Nyquist bin's cos row) as A fragments (pack_stft16);
@@ -187,6 +229,10 @@ inline void pack_stft16(const float* basis, int n_fft, std::vector<uint16_t> (&q
 hipError_t launch_head16(const float* Y, const H16Weight& w, const float* bc, float* mean_prob, int B, int D, int nb, int hop, int Fr, int T, hipStream_t s);
 hipError_t launch_conv_pre16(const float* x, const float* w, const float* bias, void* Y, int B, int C, int T, int ks, float in_scale, hipStream_t s);
 hipError_t launch_f32_to_c8(const float* X, void* Y, int B, int C, int T, float scale, int elu, hipStream_t s);
+// L2Norm over channels (seanet.py:288-318: y / max(||y||, 1e-12) * sqrt(D)) of a latent [B][D][Fr] f32 -> c8 f16 (the f16 decoder's input)
+hipError_t launch_l2norm_c8(const float* X, void* Y, int B, int D, int Fr, hipStream_t s);
+// decoder tail on a PRE-ACTIVATED c8 f16 input: out = tanh(out_scale * (b + conv_{C -> 1, ks}(a))) (+ x), first T samples (seanet.py:1177-1202)
+hipError_t launch_tail16(const void* A16, const float* w, const float* bias, const float* x, float* out, int B, int C, int Tin, int T, int ks, float out_scale, hipStream_t s);
 hipError_t launch_c8_to_f32(const void* X, float* Y, int B, int C, int T, hipStream_t s);
 
 // ---- K2: (identity | DW conv) producer -> 1x1 GEMM -> epilogue --------------------------------

@@ -84,10 +84,16 @@ struct wv_model {
     // ---- head plan
     const float *head_wc = nullptr, *head_bc = nullptr;
     int head_nb = 0;
-    // ---- f16 mode of the detector (wv_h16.hip): A-fragment weights per encoder stage -- the ResnetBlocks' 1x1 pairs, the SpecBlock's
-    // 1x1 over the zero-padded spectrum rows, the downsample unit's 1x1 and depth-wise conv composed into one [M][2r][K] conv
-    struct H16Stage { std::vector<std::pair<wv::H16Weight, wv::H16Weight>> blocks; wv::H16Weight spec, down, cosw, sinw, cosl, sinl, post, head; };   // post / head: the last entry only (conv_post as one composed conv, the head GEMM)
-    std::vector<H16Stage> h16;                    // n_strides stages; one more when spec_post runs on the f16 pipe too (only its spec / cos / sin members)
+    // ---- f16 mode (wv_h16.hip): A-fragment weights per encoder stage -- the ResnetBlocks' 1x1 pairs (divided by log2(e), their first
+    // stencil table times log2(e): RhArgs), the SpecBlock's 1x1 over the zero-padded spectrum rows, the downsample unit's 1x1 and
+    // depth-wise conv composed into one [M][2r][K] conv -- and per decoder stage: the upsample unit as one 2-tap conv over (phase, channel)
+    // rows (pack_up16) and its ResnetBlocks; the decoder's first conv pair as one composed conv
+    struct H16Block { wv::H16Weight w1, w2; const float* tab1 = nullptr; };
+    struct H16Stage { std::vector<H16Block> blocks; wv::H16Weight spec, down, cosw, sinw, cosl, sinl, post, head; };   // post / head: the last entry only (conv_post as one composed conv, the head GEMM)
+    struct H16Up { wv::H16Weight up; std::vector<H16Block> blocks; };
+    std::vector<H16Stage> h16;                    // n_strides stages; one more when spec_post runs on the f16 pipe too (only its spec / cos / sin / post / head members)
+    wv::H16Weight h16_dec_head;
+    std::vector<H16Up> h16_ups;                   // generator only; empty = no f16 decoder plan
 
     ~wv_model() { for (void* p : dev) (void)hipFree(p); }
 };
@@ -217,6 +223,14 @@ struct Uploader {
         const std::vector<uint16_t> q = wv::pack_h16(pw.data(), dw, M, K, ks, &w);
         return h16_up(q, w);
     }
+    wv_model::H16Block h16_block(const std::string& pre, int C) {
+        wv_model::H16Block b;
+        wv::H16Weight w;
+        { const std::vector<uint16_t> q = wv::pack_rh_pw(host(pre + ".block.1.conv.conv.weight").data(), C, &w); b.w1 = h16_up(q, w); }
+        { const std::vector<uint16_t> q = wv::pack_rh_pw(host(pre + ".block.4.conv.conv.weight").data(), C, &w); b.w2 = h16_up(q, w); }
+        b.tab1 = up(wv::pack_rh_table1(host(pre + ".block.2.conv.conv.weight").data(), host(pre + ".block.2.conv.conv.bias").data(), C));
+        return b;
+    }
     wv::H16Weight h16_up(const std::vector<uint16_t>& q, wv::H16Weight w) {
         if (err != WV_OK) return w;
         void* d = nullptr;
@@ -310,6 +324,7 @@ ResBlock pack_resblock(Uploader& U, const std::string& pre, int idx, float rs, i
 }
 
 int ipow(int b, int e) { int r = 1; while (e-- > 0) r *= b; return r; }
+int round_up_int(int x, int a) { return (x + a - 1) / a * a; }
 
 int pack_model(wv_model* m) {
     const wv_config& c = m->cfg;
@@ -442,18 +457,21 @@ int pack_model(wv_model* m) {
         m->head_wc = U.up(wc); m->head_bc = U.up(bc); m->head_nb = nb;
         head_wc_host = wc;
     }
-    // f16 mode: only for the detector, and only for layer shapes the f16 kernels cover (else wv_detector_forward_f16 reports WV_ESTATE)
-    bool h16_ok = c.kind == WV_KIND_DETECTOR && c.residual_kernel_size == 5 && c.dilation_base == 1 && c.kernel_size <= 16;
-    for (int s = 0, C = C0; s < S && h16_ok; ++s, C *= 2) h16_ok = C == 64 || C == 128 || C == 256 || C == 512;
+    // f16 mode: only for layer shapes the f16 kernels cover (else the *_forward_f16 entry points report WV_ESTATE)
+    auto rh_c = [](int C) { return C == 32 || C == 64 || C == 96 || C == 128 || C == 192 || C == 256 || C == 384 || C == 512 || C == 768; };
+    bool h16_ok = c.residual_kernel_size == 5 && c.dilation_base == 1 && c.kernel_size <= 16 && c.last_kernel_size <= 16;
+    for (int s = 0, C = C0; s < S && h16_ok; ++s, C *= 2) {
+        h16_ok = rh_c(C) || m->enc_blocks[s].empty();
+        // a scale the one-launch SpecBlock does not take stages its f16 spectrogram (roundup(F, 16) rows) in the intermediate buffer of C rows of f32
+        if (C != m->specs[s].n_fft && round_up_int(m->specs[s].F, 16) > 2 * C) h16_ok = false;
+        if (C % 8) h16_ok = false;
+    }
     if (h16_ok) {
         int C = C0;
         for (int s = 0; s < S && U.err == WV_OK; ++s, C *= 2) {
             wv_model::H16Stage st;
-            for (int j = 0; j < c.n_residual_enc; ++j) {
-                const std::string pre = "encoder.blocks." + std::to_string(s) + "." + std::to_string(j);
-                st.blocks.emplace_back(U.h16(U.host(pre + ".block.1.conv.conv.weight"), nullptr, C, C, 1),
-                                       U.h16(U.host(pre + ".block.4.conv.conv.weight"), nullptr, C, C, 1));
-            }
+            for (int j = 0; j < c.n_residual_enc; ++j)
+                st.blocks.push_back(U.h16_block("encoder.blocks." + std::to_string(s) + "." + std::to_string(j), C));
             const int F = m->specs[s].F, r = ratio_enc(c, s);
             st.spec = U.h16(U.host("encoder.spec_blocks." + std::to_string(s) + ".layer.conv.conv.weight"), nullptr, C, F, 1);
             const std::string dp = "encoder.downsample." + std::to_string(s);
@@ -486,13 +504,34 @@ int pack_model(wv_model* m) {
                 const std::vector<uint16_t> q = wv::pack_h16(U.host("encoder.conv_post.2.conv.conv.weight").data(), U.host("encoder.conv_post.1.conv.conv.weight").data(),
                                                              c.dimension, C, c.last_kernel_size, &w, true);
                 st.post = U.h16_up(q, w);
-                const int D = c.dimension, rows = m->head_nb * hop_of(c);
-                std::vector<float> wt((size_t)rows * D);
-                for (int d = 0; d < D; ++d)
-                    for (int r = 0; r < rows; ++r) wt[(size_t)r * D + d] = head_wc_host[(size_t)d * rows + r];
-                st.head = U.h16(wt, nullptr, rows, D, 1);
+                if (c.kind != WV_KIND_GENERATOR) {
+                    const int D = c.dimension, rows = m->head_nb * hop_of(c);
+                    std::vector<float> wt((size_t)rows * D);
+                    for (int d = 0; d < D; ++d)
+                        for (int r = 0; r < rows; ++r) wt[(size_t)r * D + d] = head_wc_host[(size_t)d * rows + r];
+                    st.head = U.h16(wt, nullptr, rows, D, 1);
+                }
             }
             m->h16.push_back(std::move(st));
+        }
+        // the generator's decoder (seanet.py:1067-1226): needs the latent from the f16 conv_post above
+        bool dec_ok = c.kind == WV_KIND_GENERATOR && (int)m->h16.size() > S && c.dimension % 16 == 0 && (c.last_kernel_size == 3 || c.last_kernel_size == 5 || c.last_kernel_size == 7);
+        for (size_t i = 0; i < m->ups.size() && dec_ok; ++i) dec_ok = (m->ups[i].res.empty() || rh_c(m->ups[i].pw.M)) && m->ups[i].pw.M % 16 == 0 && m->ups[i].pw.K % 16 == 0;
+        if (dec_ok && U.err == WV_OK) {
+            // decoder.model.0 (1x1, D -> C) and .1 (depth-wise k) as one composed conv: W[m][i][k] = dw[m][i] * pw[m][k]
+            m->h16_dec_head = U.h16(U.host("decoder.model.0.conv.conv.weight"), U.host("decoder.model.1.conv.conv.weight").data(), m->dec_pw0.M, c.dimension, c.kernel_size);
+            int n = 2;
+            for (size_t i = 0; i < m->ups.size() && U.err == WV_OK; ++i) {
+                wv_model::H16Up hu;
+                const UpLayer& u = m->ups[i];
+                wv::H16Weight w;
+                const std::vector<uint16_t> q = wv::pack_up16(U.host("decoder.model." + std::to_string(n + 3) + ".conv.conv.weight").data(),
+                                                              U.host("decoder.model." + std::to_string(n + 2) + ".convtr.convtr.weight").data(), u.pw.M, u.pw.K, u.ratio, &w);
+                hu.up = U.h16_up(q, w);
+                for (int j = 0; j < c.n_residual_dec; ++j) hu.blocks.push_back(U.h16_block("decoder.model." + std::to_string(n + 4 + j), u.pw.M));
+                m->h16_ups.push_back(std::move(hu));
+                n += 4 + c.n_residual_dec;
+            }
         }
     }
     return U.err;
@@ -974,12 +1013,16 @@ int wv_generator_forward(wv_model* m, const float* x, const float* msg, int msg_
     return WV_OK;
 }
 
-// The encoder stages of the f16 mode (wv_h16.hip): conv_pre, then per stage 2 ResnetBlocks (one launch each), the SpecBlock (STFT
-// log-magnitude in f32 as in the exact path, its 1x1 + add on the f16 pipe) and the downsample unit (one composed conv).  The last
-// downsample writes f32 [B, C, Tl] into the stream buffer r[0], where run_encoder(first_stage = n_strides) picks up.
-// mean_prob != null: the caller wants the mean probabilities only -- conv_post and the head run on the f16 pipe as well and *head_done is set.
-static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, char* ws, const WsLayout& L, hipStream_t st, bool* post_done,
-                                  float* mean_prob, bool* head_done) {
+// The encoder stages of the f16 mode (wv_h16.hip): conv_pre, then per stage the ResnetBlocks (one launch each), the SpecBlock (one launch
+// where the scale is one of spec16's, else the exact path's STFT kernel and the 1x1 + add on the f16 pipe) and the downsample unit (one
+// composed conv; FiLM in its epilogue when `film` is given: the generator).  What happens behind the last stage:
+//   tail = H16_TAIL_F32      the last downsample (or spec_post, when it runs on the f16 pipe: *post_done) writes f32 [B, C, Tl] into the stream
+//                            buffer r[0], where run_encoder(first_stage = n_strides) picks up (logits outputs: conv_post and the head exact)
+//   tail = H16_TAIL_LATENT   spec_post -> ELU -> conv_post as one composed conv on the f16 pipe, the latent BEFORE its L2Norm as f32
+//                            [B, D, Fr] at the workspace's latent slot; *latent_done (falls back to H16_TAIL_F32 when that plan is missing)
+enum { H16_TAIL_F32 = 0, H16_TAIL_LATENT = 1 };
+static int run_encoder_stages_f16(wv_model* m, const float* x, const float* film, int B, int T, char* ws, const WsLayout& L, hipStream_t st, int tail,
+                                  bool* post_done, bool* latent_done, int* Fr_out) {
     const wv_config& c = m->cfg;
     const int S = c.n_strides;
     void* R[2] = {ws + L.off_r0, ws + L.off_r1};
@@ -987,6 +1030,7 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, cha
     float* P = (float*)(ws + L.off_p);
     void* P16 = ws + L.off_u;
     int cur = 0, Tl = T, C = c.channels_enc;
+    const int film_stride = c.n_strides * c.freq_bands * 2;
     wv::prof::set_role("enc16.conv_pre");
     LAUNCH(wv::launch_conv_pre16(x, m->pre_w, m->pre_b, R[0], B, C, T, c.kernel_size, 1.f / c.wav_std, st));
     for (int s = 0; s < S; ++s) {
@@ -995,7 +1039,7 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, cha
         for (size_t j = 0; j < m->enc_blocks[s].size(); ++j) {
             const ResBlock& r = m->enc_blocks[s][j];
             wv::RhArgs a{};
-            a.X = R[cur]; a.pre_scale = r.pre_scale; a.w1 = hs.blocks[j].first; a.w2 = hs.blocks[j].second; a.tab1 = r.tab1; a.tab2 = r.tab2;
+            a.X = R[cur]; a.pre_scale = r.pre_scale; a.w1 = hs.blocks[j].w1; a.w2 = hs.blocks[j].w2; a.tab1 = hs.blocks[j].tab1; a.tab2 = r.tab2;
             a.Y = R[cur ^ 1]; a.Yact = nullptr; a.out_scale = r.out_scale; a.act_scale = 0.f; a.B = B; a.C = C; a.T = Tl;
             const hipError_t e = wv::launch_resblock16(a, st);
             if (e != hipSuccess) return fail(e == hipErrorNotSupported ? WV_ESTATE : WV_EHIP, std::string("launch_resblock16: ") + hipGetErrorString(e));
@@ -1010,7 +1054,7 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, cha
         if (sa.Tf != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");
         const DownLayer& d = m->downs[s];
         // x' = x + scale * (W @ P); only ELU(c * x') is consumed.  One launch where the scale is one of the fused kernel's (the default
-        // detector's four), else the exact path's STFT kernel -> P in HBM -> f16 copy -> the 1x1 + add as a k = 1 conv
+        // detector's / generator's four), else the exact path's STFT kernel -> P in HBM -> f16 copy -> the 1x1 + add as a k = 1 conv
         wv::Spec16Args f{};
         f.wav = x; f.cosw = hs.cosw; f.sinw = hs.sinw; f.cosl = hs.cosl; f.sinl = hs.sinl; f.pw = hs.spec; f.resid = R[cur]; f.Y = nullptr; f.Yact = A0;
         f.out_scale = sp.scale; f.act_scale = d.pre_scale; f.c1 = 0.5f * 0.6931471805599453f * sp.inv_std; f.c0 = -sp.mean * sp.inv_std;
@@ -1018,6 +1062,7 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, cha
         const hipError_t fe = C == sp.n_fft ? wv::launch_spec16(f, st) : hipErrorNotSupported;
         if (fe != hipSuccess && fe != hipErrorNotSupported) return fail(WV_EHIP, std::string("launch_spec16: ") + hipGetErrorString(fe));
         if (fe == hipErrorNotSupported) {
+            if ((size_t)B * round_up_int(sp.F, 16) * Tl * 2 > L.act * 4) return fail(WV_ESTATE, "f16 mode: the spectrogram of this scale does not fit its staging buffer");
             LAUNCH(wv::launch_stft_logmag(sa, st));
             LAUNCH(wv::launch_f32_to_c8(P, P16, B, sp.F, Tl, 1.f, 0, st));
             wv::Conv16Args q{};
@@ -1025,16 +1070,20 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, cha
             q.out_scale = sp.scale; q.act_scale = d.pre_scale; q.B = B; q.M = C; q.Tin = Tl; q.Tout = Tl; q.ks = 1; q.stride = 1; q.pad = 0;
             LAUNCH(wv::launch_conv16(q, st));
         }
-        wv::prof::set_role("enc16.down");
+        wv::prof::set_role(film ? "enc16.down_film" : "enc16.down");
         const bool last = s + 1 == S, post16 = (int)m->h16.size() > S;
         wv::Conv16Args g{};
         g.X = A0; g.w = hs.down; g.bias = d.dw_b; g.resid = nullptr; g.Y = (last && !post16) ? nullptr : R[cur ^ 1]; g.Yact = nullptr;
         g.Yf32 = (last && !post16) ? (float*)R[0] : nullptr; g.out_scale = 1.f; g.act_scale = 0.f;
         g.B = B; g.M = 2 * C; g.Tin = Tl; g.Tout = (Tl + d.ratio - 1) / d.ratio; g.ks = 2 * d.ratio; g.stride = d.ratio; g.pad = d.ratio;
+        if (film) {
+            if ((2 * C) % c.freq_bands) return fail(WV_EINVAL, "channels not divisible by freq_bands");
+            g.film = film + (size_t)s * c.freq_bands * 2; g.bands = c.freq_bands; g.film_stride = film_stride;
+        }
         LAUNCH(wv::launch_conv16(g, st));
         cur ^= 1; Tl = g.Tout; C *= 2;
     }
-    *post_done = false; *head_done = false;
+    *post_done = false; *latent_done = false; *Fr_out = Tl;
     if ((int)m->h16.size() > S) {
         // spec_post (seanet.py:781-795) on the f16 pipe as well: x from the c8 buffer, x' = x + scale * (W @ P) out in f32 for conv_post.
         // (x sits in R[cur]; when that is R[0] the f32 result, twice the bytes, goes through R[1] and is copied over.)
@@ -1047,9 +1096,9 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, cha
         f.out_scale = sp.scale; f.act_scale = 0.f; f.c1 = 0.5f * 0.6931471805599453f * sp.inv_std; f.c0 = -sp.mean * sp.inv_std;
         f.B = B; f.T = T; f.Tf = Tl; f.n_fft = sp.n_fft; f.hop = sp.hop;
         if ((T + sp.hop - 1) / sp.hop != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");
-        const int D = c.dimension, hop = hop_of(c);
-        if (mean_prob && D % 16 == 0 && D <= 128 && m->head_nb % 4 == 0 && hop % 32 == 0 && c.last_kernel_size <= 16) {
-            // mean probabilities only: ELU(x') in c8 -> conv_post as one composed conv (f32 out) -> L2Norm + head GEMM + sigmoid + mean
+        const int D = c.dimension;
+        if (tail == H16_TAIL_LATENT && hs.post.wq && c.last_kernel_size <= 16) {
+            // ELU(x') in c8 -> conv_post as one composed conv (f32 out)
             f.Yf32 = nullptr; f.Yact = A0; f.act_scale = 1.f;
             const hipError_t e1 = wv::launch_spec16(f, st);
             if (e1 == hipSuccess) {
@@ -1059,10 +1108,7 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, int B, int T, cha
                 g.out_scale = 1.f; g.act_scale = 0.f; g.B = B; g.M = D; g.Tin = Tl; g.Tout = Tl; g.ks = c.last_kernel_size; g.stride = 1;
                 g.pad = c.last_kernel_size - 1;
                 LAUNCH(wv::launch_conv16(g, st));
-                wv::prof::set_role("head16");
-                const hipError_t e2 = wv::launch_head16(g.Yf32, hs.head, m->head_bc, mean_prob, B, D, m->head_nb, hop, Tl, T, st);
-                if (e2 != hipSuccess) return fail(WV_EHIP, std::string("launch_head16: ") + hipGetErrorString(e2));
-                *post_done = true; *head_done = true;
+                *post_done = true; *latent_done = true;
                 return WV_OK;
             }
             if (e1 != hipErrorNotSupported) return fail(WV_EHIP, std::string("launch_spec16 (post): ") + hipGetErrorString(e1));
@@ -1093,11 +1139,20 @@ static int run_head_model(wv_model* m, const float* x, float* logits, float* mea
     int Fr = 0;
     bool post_done = false;
     if (f16) {
-        if (m->h16.empty()) return fail(WV_ESTATE, "this model has no f16 plan (detector with 64/128/256/512-channel stages, k = 5, dilation 1)");
-        bool head_done = false;
-        rc = run_encoder_stages_f16(m, x, B, T, w, L, st, &post_done, logits ? nullptr : mean_prob, &head_done);
+        if (m->h16.empty()) return fail(WV_ESTATE, "this model has no f16 plan (ResnetBlock stages of 32 ... 768 channels, k = 5, dilation 1)");
+        // mean probabilities only: conv_post and the head run on the f16 pipe as well (L2Norm + composed head GEMM + sigmoid + time mean)
+        const wv_config& c = m->cfg;
+        const int D = c.dimension, hop = hop_of(c);
+        const bool head16 = !logits && (int)m->h16.size() > c.n_strides && m->h16.back().head.wq && D % 16 == 0 && D <= 128 && m->head_nb % 4 == 0 && hop % 32 == 0;
+        bool latent_done = false;
+        rc = run_encoder_stages_f16(m, x, nullptr, B, T, w, L, st, head16 ? H16_TAIL_LATENT : H16_TAIL_F32, &post_done, &latent_done, &Fr);
         if (rc) return rc;
-        if (head_done) return WV_OK;
+        if (latent_done) {
+            wv::prof::set_role("head16");
+            const hipError_t e2 = wv::launch_head16(latent, m->h16.back().head, m->head_bc, mean_prob, B, D, m->head_nb, hop, Fr, T, st);
+            if (e2 != hipSuccess) return fail(WV_EHIP, std::string("launch_head16: ") + hipGetErrorString(e2));
+            return WV_OK;
+        }
     }
     rc = run_encoder(m, x, nullptr, 0, latent, B, T, w, L, st, &Fr, f16 ? m->cfg.n_strides : 0, post_done);
     if (rc) return rc;
@@ -1125,6 +1180,90 @@ int wv_locator_forward(wv_model* m, const float* x, float* logits, int B, int T,
                        size_t ws_bytes, void* stream) {
     if (m && m->cfg.kind != WV_KIND_LOCATOR) return fail(WV_ESTATE, "not a locator model");
     return run_head_model(m, x, logits, nullptr, B, T, ws, ws_bytes, stream);
+}
+
+int wv_locator_forward_f16(wv_model* m, const float* x, float* logits, int B, int T, void* ws,
+                           size_t ws_bytes, void* stream) {
+    if (m && m->cfg.kind != WV_KIND_LOCATOR) return fail(WV_ESTATE, "not a locator model");
+    return run_head_model(m, x, logits, nullptr, B, T, ws, ws_bytes, stream, true);
+}
+
+// Generator.forward in the f16-operand mode (generator.py:360-423; seanet.py:883-976, 1067-1226): the encoder stages above with FiLM in
+// the downsample convs' epilogues, the latent's L2Norm, then the decoder on the same kernels -- the first conv pair as one composed
+// conv, every upsample unit as one 2-tap conv over (phase, channel) rows, the ResnetBlocks in one launch each, the tail (f32 sums, tanh)
+// on the pre-activated c8 stream.  Message MLP and FiLM scalars are the exact path's (f32).
+int wv_generator_forward_f16(wv_model* m, const float* x, const float* msg, int msg_rows, float* out,
+                             int add_input, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    WsLayout L;
+    int rc = check_common(m, B, T, ws, ws_bytes, &L);
+    if (rc) return rc;
+    if (m->cfg.kind != WV_KIND_GENERATOR) return fail(WV_ESTATE, "not a generator model");
+    if (!x || !msg || !out) return fail(WV_EINVAL, "null tensor");
+    if (m->h16.empty() || m->h16_ups.empty()) return fail(WV_ESTATE, "this model has no f16 plan (stages of 32 ... 768 channels, k = 5, dilation 1, the default spec_post)");
+    hipStream_t st = (hipStream_t)stream;
+    const wv_config& c = m->cfg;
+    char* w = (char*)ws;
+    float* latent = (float*)(w + L.off_lat);
+    float* film = (float*)(w + L.off_film);
+    rc = run_film(m, msg, msg_rows, film, B, st);
+    if (rc) return rc;
+    int Fr = 0;
+    bool post_done = false, latent_done = false;
+    rc = run_encoder_stages_f16(m, x, film, B, T, w, L, st, H16_TAIL_LATENT, &post_done, &latent_done, &Fr);
+    if (rc) return rc;
+    if (!latent_done) return fail(WV_ESTATE, "f16 generator: spec_post / conv_post are not on the f16 pipe for this configuration");
+    void* R[2] = {w + L.off_r0, w + L.off_r1};
+    void* A0 = w + L.off_a0;
+    wv::prof::set_role("dec16.l2norm");
+    LAUNCH(wv::launch_l2norm_c8(latent, A0, B, c.dimension, Fr, st));
+    wv::prof::set_role("dec16.head");
+    {
+        wv::Conv16Args g{};
+        g.X = A0; g.w = m->h16_dec_head; g.bias = m->dec_dw0_b; g.resid = nullptr; g.Y = nullptr; g.Yact = R[0]; g.Yf32 = nullptr;
+        g.out_scale = 1.f; g.act_scale = m->ups[0].pre_scale; g.B = B; g.M = m->dec_pw0.M; g.Tin = Fr; g.Tout = Fr; g.ks = c.kernel_size; g.stride = 1;
+        g.pad = c.kernel_size - 1;
+        LAUNCH(wv::launch_conv16(g, st));
+    }
+    void* act = R[0];                                            // the activated stream the next unit consumes
+    int Tl = Fr;
+    for (size_t i = 0; i < m->ups.size(); ++i) {
+        const UpLayer& u = m->ups[i];
+        const wv_model::H16Up& hu = m->h16_ups[i];
+        const bool last_up = i + 1 == m->ups.size();
+        const float stage_next = last_up ? m->dec_post : m->ups[i + 1].pre_scale;    // the next upsample's / the tail's ELU(dec_post * y)
+        wv::prof::set_role("dec16.upsample");
+        void* free1 = act == R[0] ? R[1] : R[0];
+        wv::Conv16Args g{};
+        g.X = act; g.w = hu.up; g.bias = u.pw_b; g.resid = nullptr; g.Yf32 = nullptr; g.out_scale = 1.f;
+        g.B = B; g.M = u.pw.M * u.ratio; g.Tin = Tl; g.Tout = Tl; g.ks = 2; g.stride = 1; g.pad = 1; g.up = u.ratio;
+        if (u.res.empty()) { g.Y = nullptr; g.Yact = free1; g.act_scale = stage_next; }
+        else { g.Y = free1; g.Yact = nullptr; g.act_scale = 0.f; }
+        LAUNCH(wv::launch_conv16(g, st));
+        Tl *= u.ratio;
+        void* bufs[3] = {R[0], R[1], A0};
+        void* curb = free1;
+        wv::prof::set_role("dec16.resblock");
+        for (size_t j = 0; j < u.res.size(); ++j) {
+            const ResBlock& r = u.res[j];
+            const bool last = j + 1 == u.res.size();
+            void* dst = nullptr;
+            for (void* bb : bufs) if (bb != curb) { dst = bb; break; }
+            wv::RhArgs a{};
+            a.X = curb; a.pre_scale = r.pre_scale; a.w1 = hu.blocks[j].w1; a.w2 = hu.blocks[j].w2; a.tab1 = hu.blocks[j].tab1; a.tab2 = r.tab2;
+            a.Y = last ? nullptr : dst; a.Yact = last ? dst : nullptr; a.out_scale = r.out_scale; a.act_scale = last ? stage_next : 0.f;
+            a.B = B; a.C = u.pw.M; a.T = Tl;
+            const hipError_t e = wv::launch_resblock16(a, st);
+            if (e != hipSuccess) return fail(e == hipErrorNotSupported ? WV_ESTATE : WV_EHIP, std::string("launch_resblock16 (decoder): ") + hipGetErrorString(e));
+            curb = dst;
+        }
+        act = curb;
+    }
+    wv::prof::set_role("dec16.tail");
+    {
+        const hipError_t e = wv::launch_tail16(act, m->last_w, m->last_b, add_input ? x : nullptr, out, B, c.channels_dec, Tl, T, c.last_kernel_size, c.wav_std, st);
+        if (e != hipSuccess) return fail(e == hipErrorNotSupported ? WV_ESTATE : WV_EHIP, std::string("launch_tail16: ") + hipGetErrorString(e));
+    }
+    return WV_OK;
 }
 
 int wv_profile_enable(int on) { wv::prof::enable(on != 0); return WV_OK; }

@@ -123,8 +123,10 @@ int wv_h16_resblock(const void* X16, float pre_scale, const float* w_pw1, const 
     if (!X16 || !w_pw1 || !w_dw1 || !w_pw2 || !w_dw2 || (!Y16 && !Yact16) || B < 1 || C < 1 || T < 1) return WV_EINVAL;
     Tmp t;
     wv::RhArgs a{};
-    a.X = X16; a.pre_scale = pre_scale; a.w1 = t.h16(w_pw1, nullptr, C, C, 1); a.w2 = t.h16(w_pw2, nullptr, C, C, 1);
-    a.tab1 = t.upv(wv::pack_rb_table(w_dw1, b1, C)); a.tab2 = t.upv(wv::pack_rb_table(w_dw2, b2, C));
+    a.X = X16; a.pre_scale = pre_scale;
+    { const std::vector<uint16_t> q = wv::pack_rh_pw(w_pw1, C, &a.w1); a.w1.wq = t.upb(q.data(), q.size() * sizeof(uint16_t)); }
+    { const std::vector<uint16_t> q = wv::pack_rh_pw(w_pw2, C, &a.w2); a.w2.wq = t.upb(q.data(), q.size() * sizeof(uint16_t)); }
+    a.tab1 = t.upv(wv::pack_rh_table1(w_dw1, b1, C)); a.tab2 = t.upv(wv::pack_rb_table(w_dw2, b2, C));
     a.Y = Y16; a.Yact = Yact16; a.out_scale = out_scale; a.act_scale = act_scale; a.B = B; a.C = C; a.T = T;
     const hipError_t e = wv::launch_resblock16(a, (hipStream_t)stream);
     if (e == hipErrorNotSupported) return WV_EINVAL;
@@ -244,6 +246,38 @@ int wv_op_spec_block(const float* wav, const float* basis_or_null, const float* 
     return done(t, e, (hipStream_t)stream);
 }
 
+int wv_h16_upsample(const void* X16, const float* w_ct, const float* w_pw, const float* bias, void* Y16, void* Yact16,
+                    int B, int K, int M, int Tin, int ratio, float act_scale, void* stream) {
+    if (!X16 || !w_ct || !w_pw || (!Y16 && !Yact16) || B < 1 || K < 1 || M < 1 || Tin < 1 || ratio < 1) return WV_EINVAL;
+    Tmp t;
+    wv::Conv16Args a{};
+    { const std::vector<uint16_t> q = wv::pack_up16(w_pw, w_ct, M, K, ratio, &a.w); a.w.wq = t.upb(q.data(), q.size() * sizeof(uint16_t)); }
+    a.X = X16; a.bias = t.up(bias, M); a.Y = Y16; a.Yact = Yact16; a.out_scale = 1.f; a.act_scale = act_scale;
+    a.B = B; a.M = M * ratio; a.Tin = Tin; a.Tout = Tin; a.ks = 2; a.stride = 1; a.pad = 1; a.up = ratio;
+    return done(t, wv::launch_conv16(a, (hipStream_t)stream), (hipStream_t)stream);
+}
+int wv_h16_tail(const void* A16, const float* w, const float* bias, const float* x, float* out, int B, int C, int Tin, int T, int ks,
+                float out_scale, void* stream) {
+    if (!A16 || !w || !out || C < 1 || ks < 1) return WV_EINVAL;
+    Tmp t;
+    const hipError_t e = wv::launch_tail16(A16, t.up(w, (size_t)C * ks), t.up(bias, 1), x, out, B, C, Tin, T, ks, out_scale, (hipStream_t)stream);
+    if (e == hipErrorNotSupported) return WV_EINVAL;
+    return done(t, e, (hipStream_t)stream);
+}
+int wv_h16_l2norm(const float* lat, void* Y16, int B, int D, int Fr, void* stream) {
+    Tmp t;
+    return done(t, wv::launch_l2norm_c8(lat, Y16, B, D, Fr, (hipStream_t)stream), (hipStream_t)stream);
+}
+int wv_h16_conv_film(const void* X16, const float* w_pw, const float* w_dw, const float* bias, const float* film, int bands, void* Y16, void* Yact16,
+                     int B, int K, int M, int Tin, int ks, int stride, int pad, float act_scale, void* stream) {
+    if (!X16 || !w_pw || !film || bands < 1 || B < 1 || K < 1 || M < 1 || Tin < 1 || ks < 1 || stride < 1 || pad < 0) return WV_EINVAL;
+    Tmp t;
+    wv::Conv16Args a{};
+    a.X = X16; a.w = t.h16(w_pw, w_dw, M, K, ks); a.bias = t.up(bias, M); a.Y = Y16; a.Yact = Yact16;
+    a.out_scale = 1.f; a.act_scale = act_scale; a.B = B; a.M = M; a.Tin = Tin; a.Tout = (Tin + stride - 1) / stride; a.ks = ks; a.stride = stride; a.pad = pad;
+    a.film = film; a.bands = bands; a.film_stride = 2 * bands;
+    return done(t, wv::launch_conv16(a, (hipStream_t)stream), (hipStream_t)stream);
+}
 int wv_h16_spec_block(const float* wav, const float* basis_or_null, const float* w_pw, const void* x16, void* Y16, void* Yact16, int B, int T,
                       int n_fft, int hop, int M, float mean, float std_, float out_scale, float act_scale, void* stream) {
     if (!wav || !w_pw || !x16 || (!Y16 && !Yact16) || B < 1 || T < 1 || n_fft < 2 || (n_fft & 1) || hop < 1 || M != n_fft || !(std_ > 0.f)) return WV_EINVAL;

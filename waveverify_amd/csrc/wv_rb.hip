@@ -106,11 +106,6 @@ struct RB {
 __device__ __forceinline__ float rb_dpp_next(float v) {        // lane i <- lane i+1 (wave_shl:1), lane 63 <- 0
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
-// y += w * (the next lane's h): the lane shift is a DPP operand of the multiply-add itself (v_fmac_f32 is a fused
-// multiply-add, so this rounds like fmaf).  h must not have been written by the instruction right before.
-__device__ __forceinline__ void rb_fma_next(float& y, float h, float w) {
-    asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(y) : "v"(h), "v"(w));
-}
 
 // 5-tap stencil from the accumulators: y[e] = bias + sum_i w[i] * H[NT*q + e + i]  (taps ascending, as K1).  Columns past the lane's
 // own NT come from the next lane (NT = 4) or the next two (NT = 2: one shifted copy, then the same DPP multiply-add on it).
@@ -120,11 +115,14 @@ __device__ __forceinline__ void rb_stencil(const f32x16 (&acc)[NT], int r, const
     float own[NT];
 #pragma unroll
     for (int e = 0; e < NT; ++e) own[e] = acc[e][r];
-    // The DPP multiply-adds below are inline asm: the compiler does not see that they read `own` / `sh` from ANOTHER lane and keeps no
-    // distance between a write of those registers (a copy out of an accumulator register, a reload) and the DPP read (2 wait states on
-    // gfx9).  Materialise them here and wait once; nothing writes them after this point.
-    if constexpr (NT == 4) asm volatile("s_nop 1" : "+v"(own[0]), "+v"(own[1]), "+v"(own[2]), "+v"(own[3]));
-    else asm volatile("s_nop 1" : "+v"(own[0]), "+v"(own[1]));
+    // The neighbour lanes' taps are DPP operands of the multiply-adds themselves (v_fmac_f32_dpp ... wave_shl:1: a fused multiply-add,
+    // rounds like fmaf).  They are inline asm: the compiler does not see that they read `own` / `sh` from ANOTHER lane and keeps no
+    // distance between a write of those registers (a copy out of an accumulator register, a reload, the shifted copy's v_mov_dpp) and
+    // the DPP read (2 wait states on gfx9; seen live: a 128-register build returned wrong values in one lane pair per row group,
+    // differently from run to run).  Each DPP sequence is therefore ONE asm statement that opens with the wait: whatever the
+    // compiler writes in front of the statement is two wait states old at the first cross-lane read, and it cannot put anything
+    // in between.  tools/dpp_hazard.py / tests/test_dpp_hazard.py check the shipped code objects for exactly this.
+#define WV_DPP_FMAC(y, hh, ww) "v_fmac_f32_dpp " y ", " hh ", " ww " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
     if constexpr (NT == 4) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -133,22 +131,28 @@ __device__ __forceinline__ void rb_stencil(const f32x16 (&acc)[NT], int r, const
             for (int i = 0; i + e < 4; ++i) v = fmaf(w[i], own[e + i], v);
             y[e] = v;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 4 - e; i < 5; ++i) rb_fma_next(y[e], own[e + i - 4], w[i]);
+        asm volatile("s_nop 1\n"
+                     WV_DPP_FMAC("%0", "%4", "%11")
+                     WV_DPP_FMAC("%1", "%4", "%10") WV_DPP_FMAC("%1", "%5", "%11")
+                     WV_DPP_FMAC("%2", "%4", "%9") WV_DPP_FMAC("%2", "%5", "%10") WV_DPP_FMAC("%2", "%6", "%11")
+                     WV_DPP_FMAC("%3", "%4", "%8") WV_DPP_FMAC("%3", "%5", "%9") WV_DPP_FMAC("%3", "%6", "%10") WV_DPP_FMAC("%3", "%7", "%11")
+                     : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])
+                     : "v"(own[0]), "v"(own[1]), "v"(own[2]), "v"(own[3]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
     } else {
-        float sh[2] = {rb_dpp_next(own[0]), rb_dpp_next(own[1])};        // columns 2q + 2, 2q + 3
+        const float sh0 = rb_dpp_next(own[0]), sh1 = rb_dpp_next(own[1]);      // columns 2q + 2, 2q + 3 (compiler-visible DPP moves)
         float v0 = fmaf(w[0], own[0], w1.y), v1 = fmaf(w[0], own[1], w1.y);
         v0 = fmaf(w[1], own[1], v0);
-        rb_fma_next(v1, own[0], w[1]);
-        rb_fma_next(v0, own[0], w[2]); rb_fma_next(v1, own[1], w[2]);
-        rb_fma_next(v0, own[1], w[3]);
-        asm volatile("s_nop 1" : "+v"(sh[0]), "+v"(sh[1]));              // the shifted copies are complete (and two wait states old) before they are DPP operands
-        rb_fma_next(v1, sh[0], w[3]);
-        rb_fma_next(v0, sh[0], w[4]); rb_fma_next(v1, sh[1], w[4]);
+        asm volatile("s_nop 1\n"
+                     WV_DPP_FMAC("%1", "%2", "%6")
+                     WV_DPP_FMAC("%0", "%2", "%7") WV_DPP_FMAC("%1", "%3", "%7")
+                     WV_DPP_FMAC("%0", "%3", "%8")
+                     WV_DPP_FMAC("%1", "%4", "%8")
+                     WV_DPP_FMAC("%0", "%4", "%9") WV_DPP_FMAC("%1", "%5", "%9")
+                     : "+v"(v0), "+v"(v1)
+                     : "v"(own[0]), "v"(own[1]), "v"(sh0), "v"(sh1), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
         y[0] = v0; y[1] = v1;
     }
+#undef WV_DPP_FMAC
 }
 
 // One GEMM of the block: acc = W @ S over all C rows of the window.  A fragments: global chunk g in ar[g % NA], loaded AD chunks

@@ -151,11 +151,13 @@ class HipNet:
         return self.cfg.hop_length
 
     # ------------------------------------------------------------------ forward passes
-    def generator(self, x: torch.Tensor, msg: torch.Tensor, add_input: bool = False) -> torch.Tensor:
+    def generator(self, x: torch.Tensor, msg: torch.Tensor, add_input: bool = False, precision: str = "f32") -> torch.Tensor:
         """delta = G(x, msg) [B,1,T]; with add_input the watermarked audio delta + x
-        (model/watermarking.py:423-441)."""
+        (model/watermarking.py:423-441).  precision="f16": the f16-operand / f32-accumulate throughput mode (csrc/wv_h16.hip)."""
         if self.cfg.kind != "generator":
             raise RuntimeError("not a generator")
+        if precision not in ("f32", "f16"):
+            raise ValueError("precision must be 'f32' or 'f16'")
         x = self._prep(x)
         B, _, T = x.shape
         msg = msg.to(self.device).float().contiguous()          # seanet.py:909 casts to float
@@ -167,10 +169,11 @@ class HipNet:
         out = torch.empty_like(x)
         with torch.cuda.device(self.device):
             ws = self._workspace(B, T)
-            _lib.check(self._lib.wv_generator_forward(
+            fn = self._lib.wv_generator_forward_f16 if precision == "f16" else self._lib.wv_generator_forward
+            _lib.check(fn(
                 self._h, x.data_ptr(), msg.data_ptr(), msg.shape[0], out.data_ptr(),
                 int(add_input), B, T, ws.data_ptr(), ws.numel(), self._stream()),
-                "wv_generator_forward")
+                "wv_generator_forward" + ("_f16" if precision == "f16" else ""))
         return out
 
     def _head(self, x, want_logits: bool, want_mean: bool, precision: str = "f32"):
@@ -183,8 +186,6 @@ class HipNet:
             ws = self._workspace(B, T)
             if precision not in ("f32", "f16"):
                 raise ValueError("precision must be 'f32' or 'f16'")
-            if precision == "f16" and self.cfg.kind != "detector":
-                raise RuntimeError("the f16 mode exists for the detector only")
             if self.cfg.kind == "detector":
                 fn = self._lib.wv_detector_forward_f16 if precision == "f16" else self._lib.wv_detector_forward
                 _lib.check(fn(
@@ -192,9 +193,10 @@ class HipNet:
                     mean.data_ptr() if want_mean else None, B, T, ws.data_ptr(), ws.numel(),
                     self._stream()), "wv_detector_forward" + ("_f16" if precision == "f16" else ""))
             elif self.cfg.kind == "locator":
-                _lib.check(self._lib.wv_locator_forward(
+                fn = self._lib.wv_locator_forward_f16 if precision == "f16" else self._lib.wv_locator_forward
+                _lib.check(fn(
                     self._h, x.data_ptr(), logits.data_ptr(), B, T, ws.data_ptr(), ws.numel(),
-                    self._stream()), "wv_locator_forward")
+                    self._stream()), "wv_locator_forward" + ("_f16" if precision == "f16" else ""))
             else:
                 raise RuntimeError("generator has no detection head")
         return logits, mean
@@ -209,11 +211,11 @@ class HipNet:
             raise RuntimeError("not a detector")
         return self._head(x, False, True, precision)[1]
 
-    def locator(self, x: torch.Tensor) -> torch.Tensor:
-        """Locator.forward: logits [B, 1, T]."""
+    def locator(self, x: torch.Tensor, precision: str = "f32") -> torch.Tensor:
+        """Locator.forward: logits [B, 1, T].  precision="f16": the f16-operand / f32-accumulate throughput mode."""
         if self.cfg.kind != "locator":
             raise RuntimeError("not a locator")
-        return self._head(x, True, False)[0]
+        return self._head(x, True, False, precision)[0]
 
     def encoder(self, x: torch.Tensor, msg: Optional[torch.Tensor] = None) -> torch.Tensor:
         """SEANetEncoder.forward: latent [B, dimension, ceil(T/hop)]."""

@@ -269,3 +269,66 @@ def h16_spec_block(wav, w_pw, x16, n_fft, hop, mean=0.0, std=1.0, out_scale=1.0,
     if Y is None:
         return Yact
     return Y if act_scale is None else (Y, Yact)
+
+
+def h16_upsample(X16, w_ct, w_pw, bias, ratio: int, act_scale: Optional[float] = None, want_raw: bool = True):
+    """The decoder's upsample unit (ELU -> depth-wise ConvTranspose1d(2r, r), trimmed -> 1x1 + bias; seanet.py:1147-1170) as one conv on
+    the f16 pipe.  X16 = the PRE-ACTIVATED input, c8 f16 [B, K/8, Tin, 8] -> c8 f16 [B, M/8, Tin * r, 8]."""
+    lib = _lib.load()
+    X16 = _c8(X16)
+    B, G, Tin, _ = X16.shape
+    K = 8 * G
+    w_pw, w_ct, bias = _w(w_pw), _w(w_ct), _w(bias)
+    M = w_pw.shape[0]
+    w_pw, w_ct = w_pw.reshape(M, K), w_ct.reshape(K, 2 * ratio)
+    Y = torch.empty((B, M // 8, Tin * ratio, 8), dtype=torch.float16, device=X16.device) if want_raw else None
+    Yact = torch.empty((B, M // 8, Tin * ratio, 8), dtype=torch.float16, device=X16.device) if act_scale is not None else None
+    _lib.check(lib.wv_h16_upsample(X16.data_ptr(), _hp(w_ct), _hp(w_pw), _hp(bias), _dp(Y), _dp(Yact), B, K, M, Tin, int(ratio),
+                                   float(act_scale or 0.0), _stream()), "wv_h16_upsample")
+    if Y is None:
+        return Yact
+    return Y if act_scale is None else (Y, Yact)
+
+
+def h16_tail(A16, w, bias, T: int, out_scale: float, x=None) -> torch.Tensor:
+    """Decoder tail on the pre-activated c8 stream: tanh(out_scale * (b + Conv1d(C -> 1, ks)(a))) (+ x) -> [B, 1, T] f32."""
+    lib = _lib.load()
+    A16 = _c8(A16)
+    B, G, Tin, _ = A16.shape
+    w, bias = _w(w), _w(bias)
+    Cc, ks = w.shape[-2], w.shape[-1]
+    if (Cc + 15) // 16 * 2 != G:
+        raise ValueError("weight channels do not match the tensor's channel groups")
+    xd = _dev(x) if x is not None else None
+    out = torch.empty((B, 1, T), dtype=torch.float32, device=A16.device)
+    _lib.check(lib.wv_h16_tail(A16.data_ptr(), _hp(w.reshape(Cc, ks)), _hp(bias), _dp(xd), out.data_ptr(), B, Cc, Tin, T, ks, float(out_scale), _stream()),
+               "wv_h16_tail")
+    return out
+
+
+def h16_l2norm(lat) -> torch.Tensor:
+    lib = _lib.load()
+    lat = _dev(lat)
+    B, D, Fr = lat.shape
+    Y = torch.empty((B, (D + 15) // 16 * 2, Fr, 8), dtype=torch.float16, device=lat.device)
+    _lib.check(lib.wv_h16_l2norm(lat.data_ptr(), Y.data_ptr(), B, D, Fr, _stream()), "wv_h16_l2norm")
+    return Y
+
+
+def h16_conv_film(X16, w_pw, w_dw, bias, film, ks, stride, pad, act_scale: Optional[float] = None, want_raw: bool = True):
+    """wv_h16_conv with FiLM behind the conv: film [B, bands, 2] (gamma, beta) on the device."""
+    lib = _lib.load()
+    X16, film = _c8(X16), _dev(film)
+    B, G, Tin, _ = X16.shape
+    w_pw, w_dw, bias = _w(w_pw), _w(w_dw), _w(bias)
+    M = w_pw.shape[0]
+    K = w_pw.reshape(M, -1).shape[1]
+    Tout = (Tin + stride - 1) // stride
+    Gm = (M + 15) // 16 * 2
+    Y = torch.empty((B, Gm, Tout, 8), dtype=torch.float16, device=X16.device) if want_raw else None
+    Yact = torch.empty((B, Gm, Tout, 8), dtype=torch.float16, device=X16.device) if act_scale is not None else None
+    _lib.check(lib.wv_h16_conv_film(X16.data_ptr(), _hp(w_pw.reshape(M, K)), _hp(w_dw.reshape(M, ks) if w_dw is not None else None), _hp(bias), film.data_ptr(),
+                                    int(film.shape[1]), _dp(Y), _dp(Yact), B, K, M, Tin, ks, stride, pad, float(act_scale or 0.0), _stream()), "wv_h16_conv_film")
+    if Y is None:
+        return Yact
+    return Y if act_scale is None else (Y, Yact)
