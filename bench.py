@@ -22,9 +22,11 @@ the launch stream, ~190 pairs per step), whose own wall time is reported as `pro
 
 Other workloads (--workload): longform (configs[3]), detector_stress (configs[4]) and grad_allreduce
 (configs[2]: the training step's only exchange, a bucketed RCCL all-reduce of 56.1 + 170.1 MB of fp32
-gradients; reports ms per all-reduce and bus GB/s).  `--workload detector_stress --precision f16` runs the
-detector's f16-operand / f32-accumulate mode (configs[4] as BASELINE words it) and prints ITS OWN line: dtype "f16",
-the exact-f32 mode timed beside it, both modes' mean probabilities against each other and against the oracle.
+gradients; reports ms per all-reduce and bus GB/s).  `--precision f16` (embed_detect, longform, detector_stress) runs the
+f16-operand / f32-accumulate mode of the three nets (csrc/wv_h16.hip; configs[1] "bf16" / configs[4] "fp16" as BASELINE words them) and
+prints ITS OWN line: dtype "f16", the exact-f32 mode timed beside it, both modes' outputs against each other and against the oracle.
+The default (exact f32) line carries a `reduced_precision` block -- that mode's ms per step, wm max|d| and BER on the same batch -- so
+the driver's record holds it; `value` is always the exact path's.
 """
 from __future__ import annotations
 
@@ -43,8 +45,8 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16 / bf16 (v_mfma_f32_32x32x16_f16, 32 cycles per SIMD)
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-PMC_FILE_F16 = os.path.join(ROOT, "profiles", "r03_pmc_traffic_f16.json")   # the same passes over the f16 mode's command (tools/profile_f16.sh)
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+PMC_FILE_F16 = os.path.join(ROOT, "profiles", "r04_pmc_traffic_f16.json")   # the same passes over the f16 mode's command (tools/profile_f16.sh)
 
 
 def parse():
@@ -64,8 +66,8 @@ def parse():
                          "part of configs[2]'s training step that runs on the HIP training units (G+D+L, 64 clips per GPU)")
     ap.add_argument("--bucket-mb", type=float, default=25.0, help="grad_allreduce: bucket size")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
-                    help="detector_stress only: f16 = the detector's f16-operand / f32-accumulate mode (csrc/wv_h16.hip), its own line with "
-                         "its own parity block and roofs; the headline and every other workload are exact f32")
+                    help="f16 = the f16-operand / f32-accumulate mode of the nets (csrc/wv_h16.hip) for embed_detect / longform / detector_stress: "
+                         "its own line (dtype f16) with its own parity block and roofs; the headline `value` is always exact f32")
     return ap.parse_args()
 
 
@@ -281,8 +283,8 @@ def rendezvous(a, dist, world, rank, backend):
 
 def main():
     a = parse()
-    if a.precision != "f32" and a.workload != "detector_stress":   # before any GPU call
-        raise SystemExit("--precision f16 exists for --workload detector_stress only (BASELINE.json configs[4]); the headline is exact f32")
+    if a.precision != "f32" and a.workload not in ("embed_detect", "longform", "detector_stress"):   # before any GPU call
+        raise SystemExit("--precision f16 exists for the inference workloads (embed_detect, longform, detector_stress); training is exact f32")
     env_world = os.environ.get("WORLD_SIZE")
     if a.gpus > 1 and env_world is None:
         raise SystemExit(self_launch(a))                          # before any GPU call
@@ -342,14 +344,14 @@ def main():
     x_np, msg_np = synthetic_clips(B, T, seed=1234 + rank)         # each rank owns its shard
     x, msg = torch.from_numpy(x_np).to(dev), torch.from_numpy(msg_np).to(dev)
 
-    def step():
+    def step(precision=a.precision):
         if a.workload == "detector_stress":
-            mp = D.detector_mean_prob(x, precision=a.precision)
+            mp = D.detector_mean_prob(x, precision=precision)
             return x, mp, mp >= 0.5
-        wm = G.generator(x, msg, add_input=True)
+        wm = G.generator(x, msg, add_input=True, precision=precision)
         if Lnet is not None:
-            Lnet.locator(wm)
-        mp = D.detector_mean_prob(wm)
+            Lnet.locator(wm, precision=precision)
+        mp = D.detector_mean_prob(wm, precision=precision)
         return wm, mp, mp >= 0.5
 
     def timed(profiled: bool):
@@ -412,7 +414,9 @@ def main():
             pmc = None
     except Exception:
         pmc = None
-    headline = (a.workload == "embed_detect" and B == 256 and T == 16000) or (f16 and B == 1024 and T == 16000)   # the shapes the passes ran on
+    headline = (a.workload == "embed_detect" and B == 256 and T == 16000) or (f16 and a.workload == "detector_stress" and B == 1024 and T == 16000)   # the shapes the passes ran on
+    if f16 and a.workload != "detector_stress":
+        pmc = None                                                  # the f16 counter passes were taken over the detector_stress command
 
     def traffic_of(kernel):
         kernel = kernel.replace(",flat", "")       # flat tiling is a launch-time property of the same kernel symbol
@@ -443,7 +447,7 @@ def main():
                     avg_launch_us=round(dom_avg_s * 1e6, 1), launches_per_step=dom["launches"] // a.steps,
                     share_of_kernel_time=round(dom["ms"] / total_ms, 3),
                     algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 2))
-    film = [e for e in prof if e["role"] == "enc.down_film"]
+    film = [e for e in prof if e["role"] == "enc.down_film"]     # (the f16 mode's FiLM convs run under "enc16.down_film": no block for them)
     roofline_film = None
     if film:
         ms = sum(e["ms"] for e in film); by = sum(e["bytes"] for e in film); fl = sum(e["flops"] for e in film)
@@ -463,7 +467,10 @@ def main():
                              per_launch=[dict(kernel=e["kernel"], us=round(e["ms"] / e["launches"] * 1e3, 1),
                                               tflops=round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 1),
                                               launches_per_step=e["launches"] // a.steps) for e in film],
-                             algorithmic_mb_per_clip=round(by / a.steps / B / 1e6, 2))
+                             algorithmic_mb_per_clip=round(by / a.steps / B / 1e6, 2),
+                             note="north_star prices this unit against the HBM roof; with the 1x1 expansion fused in (SURVEY 8d allows it) its "
+                                  "arithmetic intensity lies above the f32-matrix ridge (19.7 FLOP/B), so the MATRIX roof is the binding one: "
+                                  "`frac` is of that roof, `hbm_frac` is what its algorithmic bytes reach of 8 TB/s")
     kernels = sorted(({"kernel": k, "ms_per_step": round(v["ms"] / a.steps, 3),
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] else 0.0,
                        "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] else 0.0}
@@ -473,7 +480,7 @@ def main():
               "longform": "clips/sec embed+locate+detect, 30s@16kHz bs=32",
               "detector_stress": "clips/sec detect, 1s@16kHz bs=1024"}[a.workload]
     if f16:
-        metric = "clips/sec detect (f16-operand / f32-accumulate mode), 1s@16kHz bs=1024"
+        metric = metric.replace(",", " (f16-operand / f32-accumulate mode),", 1)
     step_flops = sum(v["flops"] for v in by_kernel.values()) / a.steps
     out = dict(metric=metric, value=round(world * B * a.steps / elapsed, 2),
                unit="clips/s", n_gpus=world, rccl_ranks=dist.get_world_size() if dist else 0, steps=a.steps, warmup=a.warmup,
@@ -490,7 +497,7 @@ def main():
                                   step_tflops=round(step_flops / (total_ms / a.steps * 1e-3) / 1e12, 2),
                                   note="hipEvent pair around every launch; `value` is from the clean pass before it"),
                scaling_measured=("N>1 not measured in this run" if world == 1 else "this line"))
-    if not a.no_cpu_baseline and a.workload == "embed_detect" and world == 1:      # the CPU leg: rank 0 at N = 1 only
+    if not a.no_cpu_baseline and a.workload == "embed_detect" and world == 1 and not f16:      # the CPU leg: rank 0 at N = 1 only
         cb, wm_ref, mp_ref = cpu_baseline(cfgG, cfgD, sdG, sdD, x_np, msg_np, min(a.cpu_clips, B))
         n = wm_ref.shape[0]
         out["cpu_baseline"] = cb
@@ -499,15 +506,35 @@ def main():
             wm_max_abs_err=float(np.abs(wm[:n].cpu().numpy() - wm_ref).max()),
             mean_prob_max_abs_err=float(np.abs(mp[:n].cpu().numpy() - mp_ref).max()),
             ber_vs_oracle=float(((mp_ref >= 0.5) != bits[:n].cpu().numpy()).mean()))
-    if f16:
-        # The mode's own evidence: the exact-f32 detector of this library on the same K steps (same input, same weights), the two modes'
-        # mean probabilities against each other on the whole batch, and both against the torch-CPU port of the reference on a sample.
-        def step32():
-            return D.detector_mean_prob(x)
-        step32()
+    if not f16 and a.workload == "embed_detect":
+        # The f16-operand / f32-accumulate mode of the same step (BASELINE configs[1] words the step "bf16"), so that the driver's record of
+        # the DEFAULT run holds it: the same K steps, wm and bits against this run's exact outputs on the whole batch, and -- when the CPU
+        # leg ran -- against the oracle on its sample.  A throughput mode beside the exact path: `value` above is exact f32.
+        step("f16")
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(a.steps):
-            mp32 = step32()
+            wm16, mp16, bits16 = step("f16")
+        torch.cuda.synchronize(); e16 = time.perf_counter() - t0
+        rp = dict(dtype="f16 operands / f32 accumulate (csrc/wv_h16.hip): activations and weights cross HBM as f16, sums, stencils, ELU, FiLM, tanh in f32",
+                  metric=metric.replace(",", " (f16-operand mode),", 1), value=round(world * B * a.steps / e16, 2), unit="clips/s",
+                  ms_per_step=round(e16 / a.steps * 1e3, 3), speedup_vs_exact=round(elapsed / e16, 3),
+                  wm_max_abs_diff_vs_exact=float((wm16 - wm).abs().max()), wm_bar=1e-4,
+                  mean_prob_max_abs_diff_vs_exact=float((mp16 - mp).abs().max()),
+                  bits_compared=int(bits.numel()), bits_differ_vs_exact=int((bits16 != bits).sum()),
+                  note="rank 0's shard; same inputs and weights as the exact pass above; `python bench.py --precision f16` prints this mode's own line with its roofline")
+        if "parity" in out:
+            n = out["parity"]["clips_checked"]
+            rp.update(clips_checked_vs_oracle=n, wm_max_abs_err_vs_oracle=float(np.abs(wm16[:n].cpu().numpy() - wm_ref).max()),
+                      mean_prob_max_abs_err_vs_oracle=float(np.abs(mp16[:n].cpu().numpy() - mp_ref).max()),
+                      ber_vs_oracle=float(((mp_ref >= 0.5) != bits16[:n].cpu().numpy()).mean()))
+        out["reduced_precision"] = rp
+    if f16:
+        # The mode's own evidence: the exact-f32 path of this library on the same K steps (same input, same weights), the two modes'
+        # outputs against each other on the whole batch, and against the torch-CPU port of the reference on a sample.
+        step("f32")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(a.steps):
+            wm32, mp32, _ = step("f32")
         torch.cuda.synchronize(); e32 = time.perf_counter() - t0
         d = (mp - mp32).abs()
         margin = (mp32 - 0.5).abs()
@@ -516,7 +543,17 @@ def main():
                                   bits_compared=int(mp.numel()), bits_differ=int(((mp >= 0.5) != (mp32 >= 0.5)).sum()),
                                   min_margin_f32=float(margin.min()),
                                   bits_with_margin_above_4x_diff=int((margin > 4 * float(d.max())).sum()))
-        if not a.no_cpu_baseline and world == 1:
+        if a.workload != "detector_stress":
+            out["vs_f32_mode"].update(wm_max_abs_diff=float((wm - wm32).abs().max()), wm_bar=1e-4)
+            if not a.no_cpu_baseline and world == 1 and a.workload == "embed_detect":
+                cb, wm_ref, mp_ref = cpu_baseline(cfgG, cfgD, sdG, sdD, x_np, msg_np, min(a.cpu_clips, B))
+                n = wm_ref.shape[0]
+                out["cpu_baseline"] = cb
+                out["parity"] = dict(clips_checked=n, wm_max_abs_err=float(np.abs(wm[:n].cpu().numpy() - wm_ref).max()), wm_bar=1e-4,
+                                     mean_prob_max_abs_err=float(np.abs(mp[:n].cpu().numpy() - mp_ref).max()),
+                                     ber_vs_oracle=float(((mp_ref >= 0.5) != bits[:n].cpu().numpy()).mean()),
+                                     note="torch-CPU port of the reference on the first clips of the batch; the reference-golden checks are tests/test_gpu_h16.py")
+        elif not a.no_cpu_baseline and world == 1:
             from oracle import wv_oracle_torch as OT
             n = min(a.cpu_clips, B)
             torch.set_num_threads(min(os.cpu_count() or 1, 16))
