@@ -456,3 +456,44 @@ def test_resume_from_a_checkpoint_continues_the_same_run(tmp_path):
     wm_a = a.__class__.from_checkpoint(tmp_path / "live").G.forward(x, msg)        # the weights of step 2, live layout
     wm_c = c.G.forward(x, msg)
     assert float((wm_a - wm_c).abs().max()) <= 2e-6
+
+
+def test_a_checkpoints_dft_bases_are_used_and_kept(tmp_path):
+    """ADVICE r3: a checkpoint's `...spec.weight` tensors (learned when the reference trains with spec_learnable: true, conf/base.yml;
+    modules/conv.py:1023) must reach the TRAINING forward the way they reach the inference nets, and survive save -> load unchanged.
+    A perturbed basis through from_checkpoint: the trainers' forward equals WaveVerify(<same file>) (and differs from the analytic-basis
+    result), and the saved file holds the perturbed tensors."""
+    from waveverify_amd import WaveVerify
+    from waveverify_amd.checkpoint import save_atomic_checkpoint, stft_basis, argbind_config
+    from waveverify_amd.train import WatermarkTrainer
+    kinds = ("generator", "detector", "locator")
+    cfgs = {k: default_config(k) for k in kinds}
+    sds = {k: {n: torch.from_numpy(v) for n, v in random_state_dict(cfgs[k], 0).items()} for k in kinds}
+    g = torch.Generator().manual_seed(3)
+    for k in kinds:
+        S = len(cfgs[k].strides)
+        for s in range(S + 1):
+            key = ("encoder.spec_post" if s == S else f"encoder.spec_blocks.{s}") + ".spec.weight"
+            b = stft_basis((2 ** s) * cfgs[k].n_fft_base)
+            sds[k][key] = b + 0.02 * float(b.abs().max()) * torch.randn(b.shape, generator=g)
+    save_atomic_checkpoint(tmp_path / "a", "best", sds, 0, argbind_config(cfgs))
+    tr = WatermarkTrainer.from_checkpoint(tmp_path / "a")
+    wv = WaveVerify(str(tmp_path / "a"))
+    rng = np.random.default_rng(11)
+    x = _cu((0.1 * rng.standard_normal((2, 1, 8000))).astype(np.float32))
+    msg = _cu(rng.integers(0, 2, (2, 16)).astype(np.float32))
+    wm_t, wm_i = tr.G.forward(x, msg), wv.embed_batch(x, msg)
+    assert float((wm_t - wm_i).abs().max()) <= 2e-6
+    mp_t = torch.sigmoid(tr.D.forward(wm_t)).mean(-1)
+    assert float((wv.detect_batch(wm_t)[1] - mp_t).abs().max()) <= 2e-6
+    # ... and the perturbation matters: the analytic-basis nets give something else
+    plain = WatermarkTrainer(cfgs["generator"], random_state_dict(cfgs["generator"], 0, parametrized=True), cfgs["detector"],
+                             random_state_dict(cfgs["detector"], 0, parametrized=True), cfgs["locator"], random_state_dict(cfgs["locator"], 0, parametrized=True))
+    assert float((plain.G.forward(x, msg) - wm_t).abs().max()) > 1e-4
+    tr.save_checkpoint(tmp_path / "b", "best")
+    ck = torch.load(str(tmp_path / "b" / "best.pth"), map_location="cpu", weights_only=True)
+    for k in kinds:
+        for key, v in sds[k].items():
+            if key.endswith("spec.weight"):
+                assert torch.equal(ck["models"][k][key], v), (k, key)
+    assert "optimizers" not in ck and "wv_amd_optimizers" in ck

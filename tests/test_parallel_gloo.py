@@ -168,12 +168,15 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr
 
 
-def test_bench_keeps_the_f16_mode_off_the_headline():
-    """`--precision f16` is the detector_stress workload's own line; every other workload (the headline first of all) refuses it, before
+def test_bench_keeps_the_f16_mode_off_the_training_workloads():
+    """`--precision f16` selects the f16-operand mode's OWN line for the inference workloads (embed_detect, longform, detector_stress; the
+    default line's `value` stays exact f32 and carries the mode in a `reduced_precision` block); the training workloads refuse it, before
     any GPU call."""
-    for wl in ("embed_detect", "longform", "train_step", "grad_allreduce"):
+    for wl in ("train_step", "grad_allreduce"):
         r = _bench(["--workload", wl, "--precision", "f16"])
-        assert r.returncode != 0 and "detector_stress only" in r.stderr, (wl, r.stderr[-300:])
+        assert r.returncode != 0 and "training is exact f32" in r.stderr, (wl, r.stderr[-300:])
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    assert 'out["reduced_precision"] = rp' in src and 'dtype="f16" if f16 else "f32"' in src
 
 
 def _overlap_worker(rank, world, port, out_dir):

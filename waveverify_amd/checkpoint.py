@@ -213,10 +213,11 @@ def stft_basis(n_fft: int) -> torch.Tensor:
 def to_parametrized(sd: Mapping[str, object], cfg: NetConfig) -> Dict[str, torch.Tensor]:
     """A stripped state dict (plain `...weight`) in the live weight-norm layout a training step updates: what torch's weight_norm
     parametrization does when it is applied to an existing weight (`_WeightNorm.right_inverse`: original0 = ||w|| over all dimensions
-    but the first, original1 = w), i.e. how the reference resumes from its own checkpoints.  Keys already parametrized pass through;
-    DFT buffers are dropped (the nets recompute them)."""
+    but the first, original1 = w), i.e. how the reference resumes from its own checkpoints.  Keys already parametrized pass through,
+    and so do the DFT bases (`...spec.weight`: a learned parameter when the reference trained with spec_learnable: true -- the
+    trainers run their forward on them and write them back)."""
     from .params import param_specs
-    out: Dict[str, torch.Tensor] = {}
+    out: Dict[str, torch.Tensor] = {k: torch.as_tensor(v).float() for k, v in sd.items() if k.endswith("spec.weight")}
     for key, shape, role in param_specs(cfg):
         base = key[: -len("weight")] + _TAG if role == "wn" else None
         if role == "wn" and base + "0" in sd:
@@ -230,16 +231,38 @@ def to_parametrized(sd: Mapping[str, object], cfg: NetConfig) -> Dict[str, torch
     return out
 
 
+_FIXED = {"activation": "ELU", "activation_kwargs": {"alpha": 1.0}, "norm": "weight_norm", "norm_kwargs": {}, "skip": "identity", "act_all": False,
+          "expansion": 1, "groups": -1, "encoder_l2norm": True, "bias": True, "spec": "stft", "spec_compression": "log", "pad_mode": "constant",
+          "causal": True, "inout_norm": True, "channels_audio": 1}
+
+
 def argbind_config(cfgs: Mapping[str, NetConfig]) -> Dict[str, object]:
-    """The flat 'Class.argument' dict the reference saves next to the weights (scripts/train.py:1652) for the scalars tensor
-    shapes cannot tell; `apply_argbind_config` reads it back."""
+    """The flat 'Class.argument' dict the reference saves next to the weights (scripts/train.py:1652).  The reference's loader uses a
+    present `config` INSTEAD of conf/base.yml and builds Generator / Detector / Locator under argbind.scope(config)
+    (waveverify/core.py:226-236,272-276), so every constructor argument we leave out takes the CLASS default (zero_init=True,
+    channels_enc=64, ...): the whole architecture is written, argument by argument (model/generator.py:63-104, detector.py:82-114,
+    locator.py:84-115) -- the widths, strides, kernel sizes, residual scales, zero_init (which decides whether res_scale_param /
+    scale_param exist at all), the heads' sizes, and the fixed options this library supports (apply_argbind_config's whitelist).
+    tests/golden/state_dict_keys.json pins that the reference's constructors, given this dict, produce exactly our key set and shapes."""
     flat: Dict[str, object] = {}
     for kind, cfg in cfgs.items():
         c = _CLASS[kind]
-        flat[f"{c}.res_scale_enc"] = float(cfg.res_scale_enc)
-        flat[f"{c}.dilation_base"] = int(cfg.dilation_base)
+        args = dict(sample_rate=int(cfg.sample_rate), dimension=int(cfg.dimension), channels_enc=int(cfg.channels_enc), n_fft_base=int(cfg.n_fft_base),
+                    n_residual_enc=int(cfg.n_residual_enc), res_scale_enc=float(cfg.res_scale_enc), strides=[int(v) for v in cfg.strides],
+                    kernel_size=int(cfg.kernel_size), last_kernel_size=int(cfg.last_kernel_size), residual_kernel_size=int(cfg.residual_kernel_size),
+                    dilation_base=int(cfg.dilation_base), zero_init=bool(cfg.zero_init))
+        args.update(_FIXED)
         if kind == "generator":
-            flat[f"{c}.res_scale_dec"] = float(cfg.res_scale_dec)
+            args.update(msg_dimension=int(cfg.msg_dimension), channels_dec=int(cfg.channels_dec), n_residual_dec=int(cfg.n_residual_dec),
+                        res_scale_dec=float(cfg.res_scale_dec), nbits=int(cfg.nbits), embedding_dim=int(cfg.embedding_dim),
+                        embedding_layers=int(cfg.embedding_layers), freq_bands=int(cfg.freq_bands), final_activation="Tanh", spec_layer="1x1_zero",
+                        spec_learnable=False)
+        else:
+            args.update(output_dim=int(cfg.output_dim))
+            if kind == "detector":
+                args.update(nbits=int(cfg.nbits))
+        for k, v in args.items():
+            flat[f"{c}.{k}"] = v
     return flat
 
 

@@ -171,16 +171,27 @@ class _Handle:
             pass
 
 
+OPT_KEY = "wv_amd_optimizers"        # checkpoint key of this library's flat AdamW moments (not the reference's `optimizers` schema)
+
+
 class StftFeatures(_Handle):
     """Normalised log-magnitude CausalSTFT features of one scale (/root/reference/modules/conv.py:1036-1086, seanet.py:479-494)
     with the DFT basis packed and uploaded once."""
     _create, _destroy = "wv_stft_plan_create", "wv_stft_plan_destroy"
 
-    def __init__(self, n_fft: int, hop: int, mean: float, std: float):
+    def __init__(self, n_fft: int, hop: int, mean: float, std: float, basis=None):
+        """basis: the `...spec.weight` tensor of a checkpoint ([2F, 1, n_fft], a learned one when the reference trained with
+        spec_learnable: true, conf/base.yml) or None = the reference's windowed DFT basis (conv.py:1003-1026)."""
         self.n_fft, self.hop, self.mean, self.std = int(n_fft), int(hop), float(mean), float(std)
         self._lib = _lib.load()
         self._h = C.c_void_p()
-        if self._lib.wv_stft_plan_create(self.n_fft, None, C.byref(self._h)) != 0:
+        bp = None
+        if basis is not None:
+            b = np.ascontiguousarray(np.asarray(basis, dtype=np.float32).reshape(-1))
+            if b.size != (self.n_fft + 2) * self.n_fft:
+                raise ValueError(f"spec.weight for n_fft={self.n_fft} must hold {(self.n_fft + 2) * self.n_fft} values, got {b.size}")
+            bp = b.ctypes.data_as(C.c_void_p)
+        if self._lib.wv_stft_plan_create(self.n_fft, bp, C.byref(self._h)) != 0:
             raise RuntimeError("wv_stft_plan_create failed")
 
     def __call__(self, wav: torch.Tensor) -> torch.Tensor:
@@ -706,6 +717,10 @@ class _NetTrainer:
         # the tensors this net never touches (a detector's / locator's message MLP + FiLM: grad None in the reference) are carried along
         # for state_dict(): the reference's own state dicts hold them
         self.frozen = {k: torch.from_numpy(np.array(v, dtype=np.float32)) for k, v in state_dict.items() if skip and k.startswith(skip)}
+        # the DFT bases the state dict came with (`...spec.weight`: a buffer, or a learned parameter of a reference run with
+        # spec_learnable: true, modules/conv.py:1023): the training forward uses THEM (as the inference nets do through
+        # wv_model_set_stft_basis) and state_dict() writes them back unchanged; they are not trained here (no gradient towards the basis)
+        self.spec_basis = {k: torch.from_numpy(np.array(v, dtype=np.float32)) for k, v in state_dict.items() if k.endswith("spec.weight")}
         # the message MLP + FiLM parameters sit together, in the order the FiLM kernels read them: their packed block and its gradient
         # are then plain slices of the arenas (no gather before the forward, no scatter after the backward)
         self.film = FilmMlp(cfg) if with_msg else None
@@ -730,12 +745,13 @@ class _NetTrainer:
         for s, r in enumerate(cfg.ratios_enc):
             n_fft = (2 ** s) * cfg.n_fft_base
             self.scales.append(dict(C=C, r=r, blocks=[TrainBlock(C) for _ in range(cfg.n_residual_enc)], spec=TrainSpecAdd(C, n_fft // 2 + 1),
-                                    down=TrainUnit(C, 2 * C, 2 * r, r), stft=StftFeatures(n_fft, stride, cfg.spec_means[s], cfg.spec_stds[s])))
+                                    down=TrainUnit(C, 2 * C, 2 * r, r),
+                                    stft=StftFeatures(n_fft, stride, cfg.spec_means[s], cfg.spec_stds[s], self.spec_basis.get(f"encoder.spec_blocks.{s}.spec.weight"))))
             C *= 2
             stride *= r
         n_fft = (2 ** len(cfg.ratios_enc)) * cfg.n_fft_base
         self.spec_post = TrainSpecAdd(C, n_fft // 2 + 1)
-        self.stft_post = StftFeatures(n_fft, stride, cfg.spec_means[-1], cfg.spec_stds[-1])
+        self.stft_post = StftFeatures(n_fft, stride, cfg.spec_means[-1], cfg.spec_stds[-1], self.spec_basis.get("encoder.spec_post.spec.weight"))
         self.conv_post = TrainConvPost(C, cfg.dimension, cfg.last_kernel_size)
         self._film_p = self._film_g = None
         if with_msg:
@@ -788,6 +804,17 @@ class _NetTrainer:
         """Backward has finished every gradient whose key starts with one of `prefixes`."""
         if self._reducer is not None and self._reducer.active:
             self._reducer.mark([k for k in self.ranges if k.startswith(prefixes)])
+
+    def abort_reduce(self) -> None:
+        """After an error inside a step: keep this rank's collectives matched with its peers' -- arm the reducer if the step had not
+        got that far, launch every bucket not yet launched, wait -- then forget it."""
+        try:
+            if self._reducer is None:
+                self.begin_reduce()
+            self._reducer.wait()
+        except Exception:
+            pass
+        self._reducer = None
 
     def finish_reduce(self) -> int:
         """Wait for the exchange (launching what backward did not mark) and take the mean.  Returns the number of collectives."""
@@ -855,7 +882,9 @@ class _NetTrainer:
                 raise KeyError(f"{key}: not in the state dict this trainer was built from")
         for s in range(len(self.cfg.ratios_enc) + 1):
             pre = "encoder.spec_post" if s == len(self.cfg.ratios_enc) else f"encoder.spec_blocks.{s}"
-            out[pre + ".spec.weight"] = stft_basis((2 ** s) * self.cfg.n_fft_base)
+            n_fft = (2 ** s) * self.cfg.n_fft_base
+            kept = self.spec_basis.get(pre + ".spec.weight")
+            out[pre + ".spec.weight"] = kept.reshape(n_fft + 2, 1, n_fft).clone() if kept is not None else stft_basis(n_fft)
         return out
 
     def _block_fwd(self, blk, pre, h, pre_scale, rs):
@@ -1150,12 +1179,18 @@ class WatermarkTrainer:
     def save_checkpoint(self, save_path, tag: str = "latest", step: Optional[int] = None, parametrized: bool = False):
         """Write the three nets as the reference's atomic checkpoint <save_path>/<tag>.pth (scripts/train.py:1589-1676: weight-norm
         parametrizations removed, temporary file renamed into place) -- the file `WaveVerify(checkpoint=<save_path>)` reads
-        (waveverify/core.py:324-426), here and in the reference.  The optimizer moments go along as plain tensors."""
+        (waveverify/core.py:324-426), here and in the reference.  INFERENCE-compatible with the reference, not resume-compatible: its
+        training resume (scripts/train.py:654-657,674,773-774) also wants `models.discriminator`, `schedulers`, `tracker` and torch
+        AdamW state dicts under `optimizers`, none of which this path has.  Our flat AdamW moments therefore go under the private key
+        `wv_amd_optimizers` ({net: {step, exp_avg, exp_avg_sq}} keyed by parameter name), so the reference sees NO optimizer state
+        rather than a malformed one.  `parametrized=True` (the live g / v layout) is the only layout `from_checkpoint` restores the
+        moments for, and the reference's INFERENCE loader does not read it (strict=False: every weight would stay at its initial
+        value) -- write the default stripped layout for files the reference should load."""
         from .checkpoint import argbind_config, save_atomic_checkpoint
         opts = {k: n.optimizer_state() for k, n in (("generator", self.G), ("detector", self.D), ("locator", self.L))}
         cfgs = {"generator": self.G.cfg, "detector": self.D.cfg, "locator": self.L.cfg}
         return save_atomic_checkpoint(save_path, tag, self.state_dicts(parametrized), self.G.opt.t if step is None else step,
-                                      argbind_config(cfgs), {"optimizers": opts})
+                                      argbind_config(cfgs), {OPT_KEY: opts})
 
     @classmethod
     def from_checkpoint(cls, path, **kwargs) -> "WatermarkTrainer":
@@ -1172,7 +1207,7 @@ class WatermarkTrainer:
         tr = cls(cfgs["generator"], live["generator"], cfgs["detector"], live["detector"], cfgs["locator"], live["locator"], **kwargs)
         if is_atomic_checkpoint(path):
             ck = _load(find_atomic_checkpoint_file(path))
-            step, opts = int(ck.get("step", 0) or 0), ck.get("optimizers") or {}
+            step, opts = int(ck.get("step", 0) or 0), ck.get(OPT_KEY) or {}
             for k, net in (("generator", tr.G), ("detector", tr.D), ("locator", tr.L)):
                 was_live = any("parametrizations.weight.original" in n for n in sds[k])     # moments of (g, v) fit these (g, v) only
                 if not (was_live and isinstance(opts, dict) and net.load_optimizer_state(opts.get(k))):
@@ -1223,29 +1258,39 @@ class WatermarkTrainer:
         logits_d = self.D.forward(wm_aug)
         dec, dzD = bce_logits(logits_d, mask, msg, grad_scale=lam["dec/loss"])
         # each net's gradient exchange starts inside its own backward (bucket by bucket) and runs under everything that follows:
-        # the detector's under the locator's passes and the generator's backward, the locator's under the generator's backward
-        self.D.begin_reduce()
-        d_aug = self.D.backward(dzD, need_dx=True)
-        self.D._reducer.flush()
-        logits_l = self.L.forward(wm_aug)
-        loc, dzL = bce_logits(logits_l, mask, None, grad_scale=lam["loc/loss"])
-        self.L.begin_reduce()
-        d_aug = d_aug + self.L.backward(dzL, need_dx=True)
-        self.L._reducer.flush()
-        if applied:
-            self._update_effect_metrics(logits_d, logits_l, msg, mask, applied)
-            stats = dict(stats, selected_effects=applied)
-            if self.effect_backward is not None:                          # back through each clip's effect (identity when there is no hook)
-                for i, (name, params) in enumerate(applied):
-                    if str(name) != "identity":
-                        d_aug[i:i + 1] = self.effect_backward(str(name), params, d_aug[i:i + 1].clone())
-        d_wm = self.aug.backward(d_aug) if augment else d_aug
-        wav, d_wav = l1_loss(wm, x, grad_scale=lam["waveform/loss"])
-        d_wm = d_wm + d_wav
-        if extra_d_wm is not None:
-            d_wm = d_wm + _f(extra_d_wm)
-        self.G.begin_reduce()
-        self.G.backward(d_wm)
+        # the detector's under the locator's passes and the generator's backward, the locator's under the generator's backward.
+        # (Measured under gloo only so far: the RCCL overlap has not run on hardware)
+        try:
+            self.D.begin_reduce()
+            d_aug = self.D.backward(dzD, need_dx=True)
+            self.D._reducer.flush()
+            logits_l = self.L.forward(wm_aug)
+            loc, dzL = bce_logits(logits_l, mask, None, grad_scale=lam["loc/loss"])
+            self.L.begin_reduce()
+            d_aug = d_aug + self.L.backward(dzL, need_dx=True)
+            self.L._reducer.flush()
+            if applied:
+                self._update_effect_metrics(logits_d, logits_l, msg, mask, applied)
+                stats = dict(stats, selected_effects=applied)
+                if self.effect_backward is not None:                      # back through each clip's effect (identity when there is no hook)
+                    for i, (name, params) in enumerate(applied):
+                        if str(name) != "identity":
+                            d_aug[i:i + 1] = self.effect_backward(str(name), params, d_aug[i:i + 1].clone())
+            d_wm = self.aug.backward(d_aug) if augment else d_aug
+            wav, d_wav = l1_loss(wm, x, grad_scale=lam["waveform/loss"])
+            d_wm = d_wm + d_wav
+            if extra_d_wm is not None:
+                d_wm = d_wm + _f(extra_d_wm)
+            self.G.begin_reduce()
+            self.G.backward(d_wm)
+        except BaseException:
+            # a rank that raises between the first begin_reduce and the last finish_reduce (a user hook, an augmentation) must not leave its
+            # peers blocked in finish_reduce on collectives it never issues: it still issues EVERY bucket of the step, in the step's order
+            # (D, L, G), waits for them, drops the reducers, and only then re-raises -- the peers' step completes (with this rank's
+            # unfinished gradients in the mean: the step is lost either way) and the next step starts clean on every rank
+            for net in (self.D, self.L, self.G):
+                net.abort_reduce()
+            raise
         for net in (self.G, self.D, self.L):
             net.finish_reduce()
         norm = self.G.opt.step(self.G.arena, self.G.grads, self.G.max_norm)          # clipping: the generator only
