@@ -70,13 +70,15 @@ def short(name: str) -> str:
     return f"{base}<{bm},{bn},{wm},{wn}>"
 
 
-def library_version() -> str:
-    """wv_version() of the library the passes ran on (it carries a hash of the kernel sources): bench.py drops the traffic figures
-    when the library it runs on answers differently."""
+def stamp(d: str) -> str:
+    """The library build a counter pass ran on: tools/profile_bench.sh / profile_f16.sh write wv_version() into <pass dir>/library.txt
+    right after the pass.  Passes without a stamp, or stamps that differ between the passes merged into one file, are refused: a
+    figure built from two builds is tied to neither."""
     import os
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from waveverify_amd import _lib
-    return _lib.load().wv_version().decode()
+    p = os.path.join(d, "library.txt")
+    if not os.path.exists(p):
+        raise SystemExit(f"{d}: no library.txt stamp (run the pass through tools/profile_bench.sh or tools/profile_f16.sh)")
+    return open(p).read().strip()
 
 
 def rows(d: str, suffix: str):
@@ -110,12 +112,15 @@ def durations(d: str):
 
 
 def traffic(fetch_dir, write_dir, command="bench.py --steps 5 --warmup 2 --no-cpu-baseline` (tools/profile_bench.sh)"):
+    lib_f, lib_w = stamp(fetch_dir), stamp(write_dir)
+    if lib_f != lib_w:
+        raise SystemExit(f"refusing to merge counter passes from different builds: {fetch_dir}: {lib_f} / {write_dir}: {lib_w}")
     f, nf = reduce_pass(fetch_dir, ["FETCH_SIZE"])
     w, nw = reduce_pass(write_dir, ["WRITE_SIZE"])
     f, nf, w, nw = f["FETCH_SIZE"], nf["FETCH_SIZE"], w["WRITE_SIZE"], nw["WRITE_SIZE"]
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `" + command + "; counters are KiB; gfx950 correction per "
                    "MI355X_MICROARCH.md section HBM: traffic = 2*FETCH_SIZE + WRITE_SIZE",
-           "library": library_version(), "kernels": {}}
+           "library": lib_f, "kernels": {}}
     for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0.0))):
         if not nw.get(k):
             continue
@@ -136,7 +141,7 @@ def busy(sq_dir):
                    "clock ~3 % lower than un-profiled ones); wait_any / wait_inst = SQ_WAIT_ANY / SQ_WAIT_INST_ANY "
                    "over SQ_WAVE_CYCLES (waves parked at s_waitcnt or a barrier / stalled at issue, e.g. behind the "
                    "matrix pipe); valu_per_mfma = other VALU instructions per MFMA",
-           "kernels": {}}
+           "library": stamp(sq_dir), "kernels": {}}
     tt = sum(dur.values())
     for k in sorted(dur, key=lambda k: -dur[k]):
         L = n["GRBM_GUI_ACTIVE"].get(k, 0)

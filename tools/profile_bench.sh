@@ -13,4 +13,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $B > $out/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
   --output-format csv -d $out/pmc_sq -- python3 $B > $out/pmc_sq.log 2>&1
+# stamp every pass with the library build it ran on (tools/pmc_traffic.py refuses passes without a stamp or with different ones)
+for d in stats pmc_fetch pmc_write pmc_sq; do (cd $GRAFT_REPO_ROOT && python3 -c "from waveverify_amd import _lib; print(_lib.load().wv_version().decode())") > $out/$d/library.txt; done
 find $out -name "*.csv" | head -20

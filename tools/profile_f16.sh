@@ -19,6 +19,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_C
   --output-format csv -d $out/f16_pmc_sq -- python3 $B16 > $out/f16_pmc_sq.log 2>&1
 echo "counter passes done"
 cd $R
+for d in f16_stats f16_pmc_fetch f16_pmc_write f16_pmc_sq; do python3 -c "from waveverify_amd import _lib; print(_lib.load().wv_version().decode())" > $out/$d/library.txt; done
 python3 tools/pmc_traffic.py traffic $out/f16_pmc_fetch $out/f16_pmc_write "bench.py --workload detector_stress --precision f16 --steps 5 --warmup 2 --no-cpu-baseline\` (tools/profile_f16.sh)" > $out/pmc_traffic_f16.json
 python3 tools/pmc_traffic.py busy $out/f16_pmc_sq > $out/mfma_busy_f16.json
 python3 tools/h16time.py > $out/h16time.txt 2>/dev/null
