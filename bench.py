@@ -414,9 +414,7 @@ def main():
             pmc = None
     except Exception:
         pmc = None
-    headline = (a.workload == "embed_detect" and B == 256 and T == 16000) or (f16 and a.workload == "detector_stress" and B == 1024 and T == 16000)   # the shapes the passes ran on
-    if f16 and a.workload != "detector_stress":
-        pmc = None                                                  # the f16 counter passes were taken over the detector_stress command
+    headline = a.workload == "embed_detect" and B == 256 and T == 16000   # the shape the counter passes ran on (both modes: tools/profile_bench.sh, profile_f16.sh)
 
     def traffic_of(kernel):
         kernel = kernel.replace(",flat", "")       # flat tiling is a launch-time property of the same kernel symbol

@@ -37,6 +37,26 @@ def test_three_second_clip_vs_oracle(nets):
     assert np.abs(mp - mp_ref).max() <= 1e-5 and ((mp >= 0.5) == (mp_ref >= 0.5)).all()
 
 
+def test_thirty_second_clip_locator_vs_oracle(nets):
+    """configs[3] as worded ("long-form 30 s clips ... locator MIoU vs reference"): ONE 30 s clip (T = 480000), locator logits and the
+    MIoU of the binarised decisions against the numpy oracle at the full length (the 3 s test above holds the generator; the oracle's
+    locator takes ~20 s of CPU on this clip), in the exact mode and in the f16-operand mode."""
+    T = 480000
+    x, _ = synthetic_clips(1, T, seed=34)
+    x[0, 0, 100000:140000] *= 0.02                                # a quiet stretch: the spectrogram clamps are exercised
+    cfg = nets["locator"].cfg
+    ref = O.locator_forward(cfg, random_state_dict(cfg, 0), x)
+    lo = nets["locator"].locator(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert lo.shape == ref.shape == (1, 1, T)
+    err = float(np.abs(lo - ref).max())
+    assert err <= 2e-4 * max(1.0, float(np.abs(ref).max())), err
+    assert O.miou((lo > 0.5).astype(int), (ref > 0.5).astype(int)) >= 0.9999
+    lo16 = nets["locator"].locator(torch.from_numpy(x).cuda(), precision="f16").cpu().numpy()
+    e16 = float(np.abs(lo16 - ref).max())
+    assert e16 <= 0.03 * max(1.0, float(np.abs(ref).max())), e16
+    assert O.miou((lo16 > 0.5).astype(int), (ref > 0.5).astype(int)) >= 0.995
+
+
 def test_thirty_second_clip_prefix_property(nets):
     """30 s at 16 kHz (T = 480000).  Everything is causal up to the end of a hop frame, so the
     first L samples (L a multiple of 320) of every output equal the outputs on the L-sample prefix."""

@@ -45,6 +45,9 @@ def short(name: str) -> str:
     m = re.search(r"conv16s_kernel<(\d+), (true|false|[01])>", name)
     if m:
         return f"conv16<k{m.group(1)},lds>"                     # one symbol per tap count (the profiler's name also carries M x K)
+    m = re.search(r"conv16u_kernel<(true|false|[01])>", name)
+    if m:
+        return f"conv16<k2,up{',short' if m.group(1) in ('true', '1') else ''},lds>"   # the decoder's upsample units (one symbol for all four)
     m = re.search(r"conv16_kernel<(\d+), (\d+), (true|false|[01])>", name)
     if m:
         return f"conv16<{m.group(1)}x{m.group(2)}{',flat' if m.group(3) in ('true', '1') else ''}>"   # several layers share a symbol

@@ -49,52 +49,24 @@ __device__ __forceinline__ float rh_dpp_next(float v) {        // lane i <- lane
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
-// 5-tap stencil from the accumulators (wv_rb.hip's): y[e] = bias + sum_i w[i] * H[NT*q + e + i], the lane's NT consecutive columns in
-// its NT accumulators, the columns past them from the next lane(s) as DPP operands of the multiply-adds.
-template <int NT>
-__device__ __forceinline__ void rh_stencil(const f32x16 (&acc)[NT], int r, const f32x4& w0, const f32x4& w1, float (&y)[NT]) {
-    const float w[5] = {w0.x, w0.y, w0.z, w0.w, w1.x};
-    float own[NT];
-#pragma unroll
-    for (int e = 0; e < NT; ++e) own[e] = acc[e][r];
-    // The neighbour lanes' taps are DPP operands of the multiply-adds themselves (v_fmac_f32_dpp ... wave_shl:1: a fused multiply-add,
-    // rounds like fmaf).  They are inline asm: the compiler does not see that they read `own` / `sh` from ANOTHER lane and keeps no
-    // distance between a write of those registers (a copy out of an accumulator register, a reload, the shifted copy's v_mov_dpp) and
-    // the DPP read (2 wait states on gfx9; seen live: a 128-register build returned wrong values in one lane pair per row group,
-    // differently from run to run).  Each DPP sequence is therefore ONE asm statement that opens with the wait: whatever the
-    // compiler writes in front of the statement is two wait states old at the first cross-lane read, and it cannot put anything
-    // in between.  tools/dpp_hazard.py / tests/test_dpp_hazard.py check the shipped code objects for exactly this.
-#define WV_DPP_FMAC(y, hh, ww) "v_fmac_f32_dpp " y ", " hh ", " ww " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    if constexpr (NT == 4) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = w1.y;
-#pragma unroll
-            for (int i = 0; i + e < 4; ++i) v = fmaf(w[i], own[e + i], v);
-            y[e] = v;
-        }
-        asm volatile("s_nop 1\n"
-                     WV_DPP_FMAC("%0", "%4", "%11")
-                     WV_DPP_FMAC("%1", "%4", "%10") WV_DPP_FMAC("%1", "%5", "%11")
-                     WV_DPP_FMAC("%2", "%4", "%9") WV_DPP_FMAC("%2", "%5", "%10") WV_DPP_FMAC("%2", "%6", "%11")
-                     WV_DPP_FMAC("%3", "%4", "%8") WV_DPP_FMAC("%3", "%5", "%9") WV_DPP_FMAC("%3", "%6", "%10") WV_DPP_FMAC("%3", "%7", "%11")
-                     : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])
-                     : "v"(own[0]), "v"(own[1]), "v"(own[2]), "v"(own[3]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
-    } else {
-        const float sh0 = rh_dpp_next(own[0]), sh1 = rh_dpp_next(own[1]);      // columns 2q + 2, 2q + 3 (compiler-visible DPP moves)
-        float v0 = fmaf(w[0], own[0], w1.y), v1 = fmaf(w[0], own[1], w1.y);
-        v0 = fmaf(w[1], own[1], v0);
-        asm volatile("s_nop 1\n"
-                     WV_DPP_FMAC("%1", "%2", "%6")
-                     WV_DPP_FMAC("%0", "%2", "%7") WV_DPP_FMAC("%1", "%3", "%7")
-                     WV_DPP_FMAC("%0", "%3", "%8")
-                     WV_DPP_FMAC("%1", "%4", "%8")
-                     WV_DPP_FMAC("%0", "%4", "%9") WV_DPP_FMAC("%1", "%5", "%9")
-                     : "+v"(v0), "+v"(v1)
-                     : "v"(own[0]), "v"(own[1]), "v"(sh0), "v"(sh1), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
-        y[0] = v0; y[1] = v1;
-    }
-#undef WV_DPP_FMAC
+// 5-tap stencil from the accumulators for a PAIR of rows (accumulator registers r, r + 1: two adjacent channels; a lane's NT = 2
+// consecutive columns in its two accumulators): y[e] = bias + sum_i w[i] * H[2q + e + i] as packed-f32 multiply-adds (v_pk_fma_f32: one
+// instruction for both rows), taps in ascending order like wv_rb.hip's stencil.  The columns past the lane's own come from the next
+// lane and the one after it as shifted copies (wave_shl:1, compiler-visible DPP moves: it keeps the read-after-write distance itself).
+// Table row of a channel pair (pack_rh_table): {w0a, w0b, w1a, w1b | w2a, w2b, w3a, w3b | w4a, w4b, ba, bb}.
+__device__ __forceinline__ f32x2 rh_pair_next(f32x2 v) { return f32x2{rh_dpp_next(v.x), rh_dpp_next(v.y)}; }
+__device__ __forceinline__ void rh_stencil2(const f32x16 (&acc)[2], int r, const float* tp, f32x2 (&y)[2]) {
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(tp), q1 = *reinterpret_cast<const f32x4*>(tp + 4), q2 = *reinterpret_cast<const f32x4*>(tp + 8);
+    const f32x2 w0{q0.x, q0.y}, w1{q0.z, q0.w}, w2{q1.x, q1.y}, w3{q1.z, q1.w}, w4{q2.x, q2.y}, bb{q2.z, q2.w};
+    const f32x2 a0{acc[0][r], acc[0][r + 1]}, a1{acc[1][r], acc[1][r + 1]};
+    const f32x2 n0 = rh_pair_next(a0), n1 = rh_pair_next(a1);    // columns 2q + 2, 2q + 3
+    const f32x2 m0 = rh_pair_next(n0), m1 = rh_pair_next(n1);    // columns 2q + 4, 2q + 5
+    f32x2 v0 = __builtin_elementwise_fma(w0, a0, bb), v1 = __builtin_elementwise_fma(w0, a1, bb);
+    v0 = __builtin_elementwise_fma(w1, a1, v0); v1 = __builtin_elementwise_fma(w1, n0, v1);
+    v0 = __builtin_elementwise_fma(w2, n0, v0); v1 = __builtin_elementwise_fma(w2, n1, v1);
+    v0 = __builtin_elementwise_fma(w3, n1, v0); v1 = __builtin_elementwise_fma(w3, m0, v1);
+    v0 = __builtin_elementwise_fma(w4, m0, v0); v1 = __builtin_elementwise_fma(w4, m1, v1);
+    y[0] = v0; y[1] = v1;
 }
 
 // log2(e)-domain ELU.  The block's two activations feed matrix products, so their common factor can live in the weights: the kernel
@@ -103,6 +75,11 @@ __device__ __forceinline__ void rh_stencil(const f32x16 (&acc)[NT], int r, const
 // exp(t) - 1 >= t on both sides of zero, so the median picks t' for t > 0 and the exponential branch for t < 0, as elu1 does.
 constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float elu_l2(float tl) { return __builtin_amdgcn_fmed3f(tl, fmaf(__builtin_amdgcn_exp2f(tl), LOG2E, -LOG2E), 0.f); }
+__device__ __forceinline__ f32x2 elu_l2(f32x2 tl) {            // two at once: the multiply-add behind the exponentials is one packed instruction
+    const f32x2 e{__builtin_amdgcn_exp2f(tl.x), __builtin_amdgcn_exp2f(tl.y)};
+    const f32x2 m = __builtin_elementwise_fma(e, f32x2{LOG2E, LOG2E}, f32x2{-LOG2E, -LOG2E});
+    return f32x2{__builtin_amdgcn_fmed3f(tl.x, m.x, 0.f), __builtin_amdgcn_fmed3f(tl.y, m.y, 0.f)};
+}
 
 // C channels, NG column groups of 32*NT columns (overlapping by the stencil's 4), WPS waves per SIMD.  One wave = SPW 32-row strips x
 // one column group (SPW = 2: the 384 / 768-channel layers of the generator's decoder, whose B fragments then serve two strips).
@@ -119,8 +96,9 @@ struct RH {
     static constexpr bool RESIDENT = RES_;
     static constexpr int NA = RESIDENT ? 2 * NCH : RING_, AD = NA - 1;
     static constexpr size_t WBYTES = (size_t)PIECES * 16;
-    static constexpr size_t SMEM = WBYTES + (size_t)2 * C * 8 * sizeof(float);
-    static_assert(C % (32 * SPW) == 0 && (NT == 2 || NT == 4) && NTHREADS <= 1024 && NTHREADS >= C && (2 * NCH) % NA == 0 && (RESIDENT || AD <= NCH) &&
+    static constexpr int TABF = C / 2 * 12;                                 // floats of one stencil table: 12 per channel pair
+    static constexpr size_t SMEM = WBYTES + (size_t)2 * TABF * sizeof(float);
+    static_assert(C % (32 * SPW) == 0 && NT == 2 && NTHREADS <= 1024 && NTHREADS >= C && (2 * NCH) % NA == 0 && (RESIDENT || AD <= NCH) &&
                   SMEM <= 160 * 1024, "geometry");
 };
 
@@ -130,7 +108,7 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = R::NT, C = R::C, WD = R::WD, NCH = R::NCH, G = R::G, NA = R::NA, AD = R::AD, SPW = R::SPW;
     h16* S = reinterpret_cast<h16*>(smem_raw);                   // [G][WD][8]
-    float* tab = reinterpret_cast<float*>(smem_raw + R::WBYTES); // [2][C][8]: taps, bias
+    float* tab = reinterpret_cast<float*>(smem_raw + R::WBYTES); // [2][C / 2][12]: taps and bias per channel pair (pack_rh_table)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int strip = (wave % R::WM) * SPW, grp = wave / R::WM;  // first of this wave's SPW strips
@@ -139,7 +117,7 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
     const int clip_bytes = G * T * 16;
     const float pl2 = p.pre_scale * LOG2E;
 
-    for (int i = tid; i < C * 8; i += R::NTHREADS) { tab[i] = p.tab1[i]; tab[C * 8 + i] = p.tab2[i]; }
+    for (int i = tid; i < R::TABF; i += R::NTHREADS) { tab[i] = p.tab1[i]; tab[R::TABF + i] = p.tab2[i]; }
 
     // ---- A fragments: wq16[chunk][C][2][8]; lane (q, h) of strip: 16 bytes at ((32*strip + q) * 2 + h) * 16, chunk as scalar offset
     const __amdgpu_buffer_rsrc_t rW1 = uniform_rsrc(p.w1.wq, NCH * C * 32);
@@ -161,8 +139,8 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
     const h16* Bf = S + (size_t)(h * WD + co) * 8;               // B fragments of this lane's k-half, its columns (chunk c: + 2c*WD*8)
     h16* Urow = S + (size_t)(4 * strip * WD + co) * 8 + 4 * h;    // (group 4*strip, column co), this lane's 4 halves (group j: + j*WD*8)
     h16* Xrow = Urow + 8 * 8;
-    const float* Wrow1 = tab + row0 * 8;
-    const float* Wrow2 = Wrow1 + C * 8;
+    const float* Wrow1 = tab + (row0 / 2) * 12;                 // channel pair row0 / 2 (row0 is a multiple of 4)
+    const float* Wrow2 = Wrow1 + R::TABF;
     const bool hthread = tid < G * 8;                            // the 8 halo columns in front: one 16-byte piece per thread
     const int hpiece = (tid >> 3) * WD + (tid & 7);
 
@@ -232,7 +210,11 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
                     for (int e = 0; e < NT; ++e) {
                         h16x4 v;
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)elu_l2(fmaf((float)X[sw][j][e][rr], pl2, 0.f));   // (fma with a zero addend: one v_fma_mix_f32 straight from the f16 half)
+                        for (int rr = 0; rr < 4; rr += 2) {
+                            // (fma with a zero addend: one v_fma_mix_f32 straight from the f16 half)
+                            const f32x2 a = elu_l2(f32x2{fmaf((float)X[sw][j][e][rr], pl2, 0.f), fmaf((float)X[sw][j][e][rr + 1], pl2, 0.f)});
+                            v[rr] = (h16)a.x; v[rr + 1] = (h16)a.y;
+                        }
                         *reinterpret_cast<h16x4*>(Xrow + (size_t)((4 * sw + j) * WD + e) * 8) = v;
                     }
         }
@@ -285,24 +267,20 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
         for (int sw = 0; sw < SPW; ++sw)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float uu[4][NT];
+                h16x4 uh[NT];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int cr = rr + 8 * j + 32 * sw;
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wrow1 + cr * 8), w1 = *reinterpret_cast<const f32x4*>(Wrow1 + cr * 8 + 4);
-                    float y[NT];
-                    rh_stencil<NT>(acc[sw], 4 * j + rr, w0, w1, y);
+                for (int rr = 0; rr < 4; rr += 2) {
+                    f32x2 y[2];
+                    rh_stencil2(acc[sw], 4 * j + rr, Wrow1 + ((rr + 8 * j + 32 * sw) / 2) * 12, y);
 #pragma unroll
-                    for (int e = 0; e < NT; ++e) uu[rr][e] = elu_l2(y[e]);
+                    for (int e = 0; e < NT; ++e) {
+                        const f32x2 u = elu_l2(y[e]);
+                        uh[e][rr] = (h16)u.x; uh[e][rr + 1] = (h16)u.y;
+                    }
                 }
                 if (uw) {
 #pragma unroll
-                    for (int e = 0; e < NT; ++e) {
-                        h16x4 v;
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) v[rr] = (h16)uu[rr][e];
-                        *reinterpret_cast<h16x4*>(Urow + (size_t)((4 * sw + j) * WD + e) * 8) = v;
-                    }
+                    for (int e = 0; e < NT; ++e) *reinterpret_cast<h16x4*>(Urow + (size_t)((4 * sw + j) * WD + e) * 8) = uh[e];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -340,26 +318,23 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
                     h16x4 yh[NT];
                     float yy[4][NT];
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int cr = rr + 8 * j + 32 * sw;
-                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wrow2 + cr * 8), w1 = *reinterpret_cast<const f32x4*>(Wrow2 + cr * 8 + 4);
-                        float v[NT];
-                        rh_stencil<NT>(acc[sw], 4 * j + rr, w0, w1, v);
+                    for (int rr = 0; rr < 4; rr += 2) {
+                        f32x2 v[2];
+                        rh_stencil2(acc[sw], 4 * j + rr, Wrow2 + ((rr + 8 * j + 32 * sw) / 2) * 12, v);
 #pragma unroll
                         for (int e = 0; e < NT; ++e) {
                             if constexpr (OUT == 1) {
-                                // y = f16(v * s + x) in ONE instruction: the f16 residual half is a source operand and the f16 result
+                                // y = f16(v * s + x) in ONE instruction per element: the f16 residual half is a source operand and the f16 result
                                 // lands in its half of the output register (the compiler's own choice here is two conversions, a
-                                // packed fma and a packed conversion: 2 instructions per element instead of 1)
+                                // packed fma and a packed conversion)
                                 unsigned* yo = reinterpret_cast<unsigned*>(&yh[e]) + (rr >> 1);
                                 const unsigned xi = reinterpret_cast<const unsigned*>(&X[sw][j][e])[rr >> 1];
-                                if constexpr (true) {
-                                    if ((rr & 1) == 0) asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(*yo) : "v"(v[e]), "v"(p.out_scale), "v"(xi));
-                                    else asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(*yo) : "v"(v[e]), "v"(p.out_scale), "v"(xi));
-                                }
+                                asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(*yo) : "v"(v[e].x), "v"(p.out_scale), "v"(xi));
+                                asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(*yo) : "v"(v[e].y), "v"(p.out_scale), "v"(xi));
                             } else {
-                                yy[rr][e] = fmaf(v[e], p.out_scale, (float)X[sw][j][e][rr]);
-                                yh[e][rr] = (h16)yy[rr][e];
+                                yy[rr][e] = fmaf(v[e].x, p.out_scale, (float)X[sw][j][e][rr]);
+                                yy[rr + 1][e] = fmaf(v[e].y, p.out_scale, (float)X[sw][j][e][rr + 1]);
+                                yh[e][rr] = (h16)yy[rr][e]; yh[e][rr + 1] = (h16)yy[rr + 1][e];
                             }
                         }
                     }
@@ -536,7 +511,8 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int mrow = m0 + 32 * mt + 8 * j + 4 * h;      // first of this lane's 4 rows
-            const int ph = p.up > 0 ? mrow / Mo : 0, mch = mrow - ph * Mo;
+            int ph = 0, mch = mrow;                              // up: row = (block, phase, channel in block)
+            if (p.up > 0) { const int blk = mrow / (upr * p.up_mb), rem = mrow - blk * upr * p.up_mb; ph = rem / p.up_mb; mch = blk * p.up_mb + rem - ph * p.up_mb; }
             float bias[4];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) bias[rr] = (p.bias && mrow + rr < p.M) ? p.bias[mch + rr] : 0.f;
@@ -1045,6 +1021,194 @@ hipError_t conv16s_launch(const Conv16Args& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// The decoder's upsample unit (Conv16Args::up: a two-tap, stride-1 conv over the input frames whose rows are (phase, channel) pairs) with
+// the x window staged through LDS.  Straight from global memory (conv16_kernel) every wave streams its own B fragments through the L1,
+// whose 64 B per clock hold a 64 x 64 wave tile to about half the matrix pipe's rate (measured 320-680 TFLOP/s on the four units); here
+// a workgroup owns 256 rows x 128 input frames, copies the window of 32 channels (4 groups x 129 frames) by LDS-DMA into a double buffer
+// -- each piece fetched once per workgroup -- and every wave reads its fragments from there (consecutive frames are consecutive 16-byte
+// pieces: conflict-free as they lie).  One barrier per 32 channels (4 chunks x 8 matrix instructions per wave); the A fragments of a
+// step are requested two steps ahead into a three-step register ring.  SHORT: at most 64 frames per clip (the first unit: 50) -> two
+// clips per tile.  Needs K % 32 == 0.
+// The output: lane (frame l) of row (phase p, channel m) belongs at time l * up + p -- stored straight from the accumulators that is one
+// 8-byte write per lane at a stride of up * 16 bytes, and those scattered writes took HALF the kernel's time (measured: 510-740 TFLOP/s
+// with them, 870-1120 without).  So a workgroup owns a row BLOCK = all phases of up_mb channels (Conv16Args::up_mb, pack_up16), stages
+// its tile in LDS in the output's own layout [group][time][8] (one pad piece per 16, which makes the strided writes conflict-free) --
+// the window buffers are free by then -- and copies it out in whole contiguous runs, 16 bytes per lane.
+template <bool SHORT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv16u_kernel(Conv16Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int KCB = 2, GR = 2 * KCB, NCHS = 2 * KCB;         // 16-channel steps, channel groups and (channel step, tap) chunks per barrier
+    constexpr int NSUB = SHORT ? 2 : 1, CPS = 128 / NSUB, W = CPS + 1;   // a sub-window's outputs l0 .. l0 + CPS - 1 read frames l0 - 1 .. l0 + CPS - 1
+    constexpr int PIECES = GR * NSUB * W, ND = (PIECES + 255) / 256;
+    h16* S0 = reinterpret_cast<h16*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r = lane & 31;
+    const int Tin = p.Tin, Gk = p.w.Kp / 8, Mp = p.w.Mp, NKC = p.w.Kp / 16;
+    const int upr = p.up, Mo = p.M / upr, To = Tin * upr;
+    const size_t xclip = (size_t)Gk * Tin * 8, yclip = (size_t)((Mo + 15) / 16 * 2) * To * 8;      // halves per clip
+    int b0, to0;
+    if constexpr (SHORT) { b0 = 2 * blockIdx.x; to0 = 0; }
+    else { const int ncol = (Tin + 127) / 128; b0 = blockIdx.x / ncol; to0 = (blockIdx.x - b0 * ncol) * 128; }
+    const int MB = p.up_mb, RB = upr * MB;                       // rows of this workgroup's block (<= 256): (phase, channel in block)
+    const int m0 = blockIdx.y * RB + wave * 64;                  // this wave's first row
+    const bool rows = wave * 64 < RB;                            // (all waves copy and meet at the barriers; a wave past the block computes nothing)
+    const __amdgpu_buffer_rsrc_t rX = SHORT ? uniform_rsrc(p.X, (int)(xclip * 2 * p.B)) : uniform_rsrc(reinterpret_cast<const h16*>(p.X) + b0 * xclip, (int)(xclip * 2));
+    const __amdgpu_buffer_rsrc_t rW = uniform_rsrc(p.w.wq, p.w.nchunks * Mp * 32);
+
+    // ---- this thread's ND pieces of a window copy: place q = tid + 256 j of [GR groups][NSUB][W]; group gl of step st is channel group GR * st + gl
+    int dvo[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const int q = tid + 256 * j;
+        const int gl = q / (NSUB * W), rem = q - gl * (NSUB * W), sub = rem / W, pos = rem - sub * W;
+        const int t = to0 - 1 + pos;
+        const bool ok = q < PIECES && t >= 0 && t < Tin && (!SHORT || b0 + sub < p.B);
+        dvo[j] = ok ? (SHORT ? (b0 + sub) * (int)(xclip * 2) : 0) + (gl * Tin + t) * 16 : H_OOB;
+    }
+    auto copy = [&](int st, int buf) {
+        const int so = GR * st * Tin * 16;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int q0 = 256 * j + 64 * wave;                  // wave-uniform first place of this instruction
+            h16* dst = S0 + (size_t)(buf * PIECES + q0) * 8;
+            const int vo = dvo[j];
+            if (q0 < PIECES) {
+                if (q0 + lane < PIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)dst, 16, vo, so, 0, 0);
+            }
+        }
+    };
+    // ---- B fragment places: column 32 e + r -> (sub-window, local frame tl); chunk (channel step kl, tap i), k-half h: group 2 kl + h, frame tl + i
+    int bpl[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int col = 32 * e + r, sub = SHORT ? col / 64 : 0, tl = SHORT ? col % 64 : col;
+        bpl[e] = (h * NSUB + sub) * W + tl;
+    }
+    int avoff[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) avoff[mt] = (rows && m0 + 32 * mt + r < Mp) ? ((m0 + 32 * mt + r) * 2 + h) * 16 : H_OOB;
+    h16x8 ar[3][NCHS][2];                                        // [step mod 3][chunk of the step][row tile]: requested TWO steps ahead
+    auto lda = [&](int st, h16x8 (&d)[NCHS][2]) {                 // chunk index of (channel step kc, tap i) = 2 kc + i (pack_up16)
+#pragma unroll
+        for (int c = 0; c < NCHS; ++c) {
+            const int so = (NCHS * st + c) * Mp * 32;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) d[c][mt] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, avoff[mt], so, 0));
+        }
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][e][i] = 0.f;
+
+    const int nst = NKC / KCB;                                   // K % 32 == 0 (launcher)
+    lda(0, ar[0]);
+    copy(0, 0);
+    if (nst > 1) lda(1, ar[1]);
+    // Order in the queue when step st begins: ... fragments(st) | window(st) | fragments(st + 1).  One L2 round trip under this load is
+    // longer than a step (32 matrix instructions per wave), so the fragments run two steps ahead and the wait at the head of a step
+    // leaves the youngest set in flight: everything older than those 2 * NCHS loads has landed.
+    auto step = [&](int st, auto par) {
+        constexpr int P = decltype(par)::value;
+        if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NCHS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RH_BARRIER();                                            // this step's window is there in every wave; and every wave has read the other buffer
+        if (st + 1 < nst) copy(st + 1, (st + 1) & 1);
+        if (st + 2 < nst) lda(st + 2, ar[(P + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        const h16* Sb = S0 + (size_t)((st & 1) * PIECES) * 8;
+#pragma unroll
+        for (int c = 0; c < NCHS; ++c) {
+            const int kl = c >> 1, i = c & 1;
+            h16x8 bb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bb[e] = *reinterpret_cast<const h16x8*>(Sb + (size_t)(bpl[e] + 2 * kl * NSUB * W + i) * 8);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[P][c][mt], bb[e], acc[mt][e], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int st = 0; st < nst; st += 3) {
+        step(st, std::integral_constant<int, 0>{});
+        if (st + 1 < nst) step(st + 1, std::integral_constant<int, 1>{});
+        if (st + 2 < nst) step(st + 2, std::integral_constant<int, 2>{});
+    }
+    // ---- epilogue: the tile through LDS in the output's layout.  Piece (group gl of the block, sub-window, local time ts = tl * up + phase) sits at
+    // ((gl * NSUB + sub) * TP + ts + ts / 16) * 16 bytes; a lane writes its 4 channels (8 bytes) of one piece.
+    const int TS = CPS * upr, TP = TS + TS / 16 + 1, NG = MB / 8;
+    const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(p.Y ? reinterpret_cast<h16*>(p.Y) : reinterpret_cast<const h16*>(p.X), p.Y ? (int)(yclip * 2 * p.B) : 0);
+    const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(p.Yact ? reinterpret_cast<h16*>(p.Yact) : reinterpret_cast<const h16*>(p.X), p.Yact ? (int)(yclip * 2 * p.B) : 0);
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 0 ? !p.Y : !p.Yact) continue;                // (uniform)
+        RH_BARRIER();                                            // the window buffers (pass 0) / the staged tile (pass 1) have been read by every wave
+        if (rows) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int lr = wave * 64 + 32 * mt + 8 * j + 4 * h;                 // row in the block
+                    if (lr >= RB) continue;
+                    const int ph = lr / MB, ml = lr - ph * MB;
+                    float bias[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) bias[rr] = p.bias ? p.bias[blockIdx.y * MB + ml + rr] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = 32 * e + r, sub = SHORT ? col / 64 : 0, tl = SHORT ? col % 64 : col;
+                        const int ts = tl * upr + ph;
+                        h16x4 v;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const float y = (acc[mt][e][4 * j + rr] + bias[rr]) * p.out_scale;
+                            v[rr] = (h16)(pass == 0 ? y : elu1(y * p.act_scale));
+                        }
+                        *reinterpret_cast<h16x4*>(S0 + (size_t)(((ml >> 3) * NSUB + sub) * TP + ts + (ts >> 4)) * 8 + (ml & 4)) = v;
+                    }
+                }
+        }
+        RH_BARRIER();                                            // the tile is staged
+        const __amdgpu_buffer_rsrc_t& rO = pass == 0 ? rY : rA;
+        const int npieces = NG * NSUB * TS;
+        for (int i = tid; i < npieces; i += 256) {
+            const int gl = i / (NSUB * TS), rem = i - gl * (NSUB * TS), sub = rem / TS, ts = rem - sub * TS;
+            const int clip = SHORT ? b0 + sub : b0, t = (SHORT ? 0 : to0 * upr) + ts;
+            const bool ok = t < To && clip < p.B;
+            const int off = ok ? clip * (int)(yclip * 2) + ((blockIdx.y * NG + gl) * To + t) * 16 : H_OOB;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(S0 + (size_t)((gl * NSUB + sub) * TP + ts + (ts >> 4)) * 8);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rO, off, 0, 0);
+        }
+    }
+}
+
+template <bool SHORT>
+hipError_t conv16u_launch(const Conv16Args& a, hipStream_t s) {
+    constexpr int NSUB = SHORT ? 2 : 1, CPS = 128 / NSUB, W = CPS + 1;
+    const int TS = CPS * a.up, TP = TS + TS / 16 + 1;
+    const int smem = std::max(2 * 4 * NSUB * W * 16, (a.up_mb / 8) * NSUB * TP * 16);     // the window double buffer, then the staged output tile
+    static std::atomic<unsigned> attr{0};
+    {
+        int d = 0; (void)hipGetDevice(&d);
+        const unsigned bit = 1u << (d & 31);
+        if (!(attr.load(std::memory_order_relaxed) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv16u_kernel<SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) return e;
+            attr.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    if (smem > 80 * 1024) return hipErrorInvalidValue;
+    const long long gx = SHORT ? (a.B + 1) / 2 : (long long)((a.Tin + 127) / 128) * a.B;
+    if (gx > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv16u_kernel<SHORT>), dim3((unsigned)gx, (unsigned)(a.M / (a.up * a.up_mb))), dim3(256), smem, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Detector head for the mean-probability output (detector.py:300-310 + core.py:577-580): L2Norm over the latent's channels
 // (seanet.py:288-318: y / max(||y||, 1e-12) * sqrt(D)), the composed ConvTranspose1d(k = s = hop) -> Conv1d(O -> nb, 1) as one GEMM per
 // frame tile against wc[D][nb * hop], sigmoid, mean over time -- the [B, nb, T] logits never exist.  One workgroup per clip (fixed
@@ -1262,12 +1426,39 @@ hipError_t launch_resblock16(const RhArgs& a, hipStream_t s) {
     if (!rh_supported(a)) return hipErrorNotSupported;
     switch (a.C) {                                               // <C, column groups, NT, waves per SIMD, A ring, B ring depth, resident A, strips per wave>
         case 32: return rh_pick_out<RH<32, 8, 2, 4>>(a, s);      // 1 x 8 waves, 484-column windows (the locator's first stage)
-        case 64: return rh_pick_out<RH<64, 4, 2, 4>>(a, s);      // 2 x 4 waves, 244-column windows
+        case 64: return rh_pick_out<RH<64, 4, 2, 4, 4, 2, false>>(a, s);   // 2 x 4 waves, 244-column windows, weights streamed (a ring of 4: the packed stencil needs the registers)
+#ifndef RH_CFG96
+#define RH_CFG96 2
+#endif
+#ifndef RH_CFG192
+#define RH_CFG192 0
+#endif
+#ifndef RH_CFG384
+#define RH_CFG384 0
+#endif
+#if RH_CFG96 == 1
+        case 96: return rh_pick_out<RH<96, 5, 2, 4, 6, 2, false>>(a, s);    // 3 x 5 waves, 304-column windows, one workgroup per CU
+#elif RH_CFG96 == 2
+        case 96: return rh_pick_out<RH<96, 1, 2, 4, 4, 2, false>>(a, s);    // 3 x 1 waves, 64-column windows, five workgroups per CU
+#elif RH_CFG96 == 3
+        case 96: return rh_pick_out<RH<96, 4, 2, 4, 6, 2, false>>(a, s);    // 3 x 4 waves, 244-column windows, one workgroup per CU
+#else
         case 96: return rh_pick_out<RH<96, 2, 2, 4, 6, 2, false>>(a, s);    // 3 x 2 waves, 124-column windows, two workgroups per CU
-        case 128: return rh_pick_out<RH<128, 2, 2, 4, 8, 2, false>>(a, s);  // 4 x 2 waves, 124-column windows (32 KB), weights streamed
+#endif
+        case 128: return rh_pick_out<RH<128, 2, 2, 4, 4, 2, false>>(a, s);  // 4 x 2 waves, 124-column windows (32 KB), weights streamed
+#if RH_CFG192 == 1
+        case 192: return rh_pick_out<RH<192, 1, 2, 3, 8, 2, false>>(a, s);  // 6 x 1 waves, 64-column windows, two workgroups per CU
+#elif RH_CFG192 == 2
+        case 192: return rh_pick_out<RH<192, 2, 2, 3, 4, 1, false, 2>>(a, s);  // 3 x 2 waves of two strips each, 124-column windows, two workgroups per CU
+#else
         case 192: return rh_pick_out<RH<192, 2, 2, 3, 8, 2, false>>(a, s);  // 6 x 2 waves, 124-column windows
+#endif
         case 256: return rh_pick_out<RH<256, 1, 2, 4, 4, 1>>(a, s); // 8 x 1 waves, 64-column windows (32 KB)
+#if RH_CFG384 == 1
+        case 384: return rh_pick_out<RH<384, 1, 2, 3, 4, 1, false, 2>>(a, s); // 6 x 1 waves of two strips each, 64-column windows, two workgroups per CU
+#else
         case 384: return rh_pick_out<RH<384, 1, 2, 3, 4, 1>>(a, s); // 12 x 1 waves, 64-column windows (48 KB)
+#endif
         case 512: return rh_pick_out<RH<512, 1, 2, 4, 4, 1>>(a, s); // 16 x 1 waves, 64-column windows (64 KB)
         default: return rh_pick_out<RH<768, 1, 2, 3, 4, 1, false, 2>>(a, s); // 12 x 1 waves of two strips each, 64-column windows (96 KB)
     }
@@ -1279,7 +1470,8 @@ hipError_t launch_conv16(const Conv16Args& a, hipStream_t s) {
     if ((long long)a.w.Kp * a.Tin * 2 >= H_OOB || (long long)round_up(a.M, 16) * a.Tout * 2 >= H_OOB || (long long)a.w.nchunks * a.w.Mp * 32 >= H_OOB)
         return hipErrorInvalidValue;
     if (!al16(a.X) || !al16(a.w.wq) || (a.Y && !al16(a.Y)) || (a.Yact && !al16(a.Yact)) || (a.resid && !al16(a.resid))) return hipErrorInvalidValue;
-    if (a.up < 0 || (a.up > 0 && (a.M % a.up || a.resid || a.Yf32 || a.stride != 1 || (a.M / a.up) % 16))) return hipErrorInvalidValue;
+    if (a.up < 0 || (a.up > 0 && (a.M % a.up || a.resid || a.Yf32 || a.stride != 1 || (a.M / a.up) % 16 || a.up_mb < 4 || (a.up_mb & 3) || (a.M / a.up) % a.up_mb)))
+        return hipErrorInvalidValue;
     const int Mo = a.up > 0 ? a.M / a.up : a.M, upr = a.up > 0 ? a.up : 1;
     if ((a.Y || a.Yact || a.resid) && (Mo % 16)) return hipErrorInvalidValue;   // c8 outputs: whole 16-channel group pairs
     if (a.film && (a.bands < 1 || Mo % a.bands || (Mo / a.bands) % 4 || a.film_stride < 2 * a.bands)) return hipErrorInvalidValue;
@@ -1291,14 +1483,18 @@ hipError_t launch_conv16(const Conv16Args& a, hipStream_t s) {
     // the strided layers' own kernel (x through LDS): 2 * stride taps, stride 4 / 5 / 8, no residual, at least 256 rows
     const bool staged = a.ks == 2 * a.stride && a.pad == a.stride && (a.ks == 8 || a.ks == 10 || a.ks == 16) && !a.resid && !a.up && a.M >= 256 && ybytes < H_OOB &&
                         (a.Tout > 64 || xbytes < H_OOB);
+    // the upsample form through LDS: two taps, whole 32-channel steps, no FiLM; the clip-spanning offsets of the two-clip tiles must fit the sentinel
+    const bool ups = a.up > 0 && a.ks == 2 && a.pad == 1 && a.w.Kp % 32 == 0 && !a.film && a.up_mb % 8 == 0 && a.up * a.up_mb <= 256 && a.up * a.up_mb >= 128 &&
+                     ybytes < H_OOB && (a.Tin > 64 || xbytes < H_OOB);
     std::string name;
     if (prof::enabled())
         name = "conv16<k" + std::to_string(a.ks) + ",s" + std::to_string(a.stride) + "," + std::to_string(a.M) + "x" + std::to_string(a.w.K) +
-               (a.up ? ",up" + std::to_string(a.up) : std::string()) + (staged ? ",lds>" : (flat ? ",flat>" : ">"));
+               (a.up ? ",up" + std::to_string(a.up) : std::string()) + ((staged || ups) ? ",lds>" : (flat ? ",flat>" : ">"));
     const double Bd = a.B, M = a.M;
     prof::Scope ps(s, name.c_str(), 2.0 * Bd * M * a.ks * (double)a.w.K * a.Tout,
                    Bd * (2.0 * a.w.Kp * a.Tin + (a.resid ? 2.0 : 0.0) * M * a.Tout + (a.Y ? 2.0 : 0.0) * M * a.Tout + (a.Yact ? 2.0 : 0.0) * M * a.Tout +
                          (a.Yf32 ? 4.0 : 0.0) * M * a.Tout));
+    if (ups) return a.Tin <= 64 ? conv16u_launch<true>(a, s) : conv16u_launch<false>(a, s);
     if (staged) {
         const bool sh = a.Tout <= 64;
         if (a.ks == 8) return sh ? conv16s_launch<8, true>(a, s) : conv16s_launch<8, false>(a, s);

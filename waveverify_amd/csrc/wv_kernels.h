@@ -136,8 +136,8 @@ inline std::vector<uint16_t> pack_h16(const float* pw, const float* dw, int M, i
 }
 // whole ResnetBlock, c8 f16 in / out (C in {32, 64, 96, 128, 192, 256, 384, 512, 768}, k = 5, dilation 1).  The kernel keeps both
 // activations times log2(e) (one instruction less per ELU, wv_h16.hip elu_l2), so the operands arrive pre-scaled -- pack_rh_pw /
-// pack_rh_table1: w1, w2 = the 1x1 weights DIVIDED by log2(e); tab1 = the first stencil's taps and bias TIMES log2(e); tab2 plain
-// (pack_rb_table).
+// pack_rh_table: w1, w2 = the 1x1 weights DIVIDED by log2(e); tab1 = the first stencil's taps and bias TIMES log2(e)
+// (pack_rh_table(.., RH_LOG2E)); tab2 plain (pack_rh_table(.., 1.0)); both tables in the kernel's channel-pair layout.
 struct RhArgs {
     const void* X; float pre_scale; H16Weight w1, w2; const float* tab1; const float* tab2;
     void* Y; void* Yact; float out_scale, act_scale; int B, C, T; int num_t, ntiles;
@@ -148,10 +148,15 @@ inline std::vector<uint16_t> pack_rh_pw(const float* pw, int C, H16Weight* out) 
     for (size_t i = 0; i < t.size(); ++i) t[i] = (float)((double)pw[i] / RH_LOG2E);
     return pack_h16(t.data(), nullptr, C, C, 1, out);
 }
-inline std::vector<float> pack_rh_table1(const float* dw_w, const float* dw_b, int C) {
-    std::vector<float> t = pack_rb_table(dw_w, dw_b, C);
-    for (int m = 0; m < C; ++m)
-        for (int i = 0; i < 6; ++i) t[(size_t)m * 8 + i] = (float)((double)t[(size_t)m * 8 + i] * RH_LOG2E);
+// stencil table of the f16 ResnetBlock kernel: per channel PAIR (2p, 2p + 1) twelve floats {w0a, w0b, w1a, w1b, w2a, w2b, w3a, w3b, w4a, w4b,
+// bias_a, bias_b} (the kernel multiplies both rows of a pair in one packed instruction), times `scale` (log2(e) for the first stencil)
+inline std::vector<float> pack_rh_table(const float* dw_w, const float* dw_b, int C, double scale) {
+    std::vector<float> t((size_t)(C / 2) * 12, 0.f);
+    for (int m = 0; m < C; ++m) {
+        float* row = t.data() + (size_t)(m / 2) * 12 + (m & 1);
+        for (int i = 0; i < 5; ++i) row[2 * i] = (float)((double)dw_w[(size_t)m * 5 + i] * scale);
+        row[10] = dw_b ? (float)((double)dw_b[m] * scale) : 0.f;
+    }
     return t;
 }
 bool rh_supported(const RhArgs& a);
@@ -165,12 +170,20 @@ struct Conv16Args {           // y = out_scale * (bias + conv(x)) + resid; x, re
     // up = r > 0: the rows are r phases of Mo = M / r output channels (row p * Mo + m: pack_up16) and row (p, m) at input time l is
     // output channel m at time l * r + p -- the decoder's upsample unit as ONE conv over the input frames; Y / Yact are
     // [B][Mo / 8][Tout * r][8], bias has Mo entries.  No resid / Yf32 in this form.
-    int up = 0;
+    // The rows come in blocks of up * up_mb: row = (block, phase, channel in block), channel = block * up_mb + c -- a row block holds ALL phases
+    // of its up_mb channels, so that a workgroup owning one produces whole runs of the output (wv_h16.hip conv16u_kernel).
+    int up = 0, up_mb = 0;
 };
+inline int up16_block(int Mo, int r) {                          // channels per row block: the largest multiple of 8 with r * MB <= 256 that divides Mo
+    for (int mb = (256 / r) / 8 * 8; mb >= 8; mb -= 8)
+        if (Mo % mb == 0) return mb;
+    return 0;
+}
 // host: the decoder's upsample unit ELU -> depth-wise ConvTranspose1d(2r, stride r), right-trimmed by r -> 1x1 (seanet.py:1147-1170,
 // conv.py:838-881) composed into a 2-tap conv over the INPUT frames: out[m][r l + p] = b[m] + sum_k pw[m][k] * (ct[k][p] * a[k][l] +
-// ct[k][p + r] * a[k][l - 1]), i.e. rows (p, m), taps i = 0 (frame l - 1: ct[k][p + r]) and i = 1 (frame l: ct[k][p]), causal pad 1.
-inline std::vector<uint16_t> pack_up16(const float* pw, const float* ct, int Mo, int K, int r, H16Weight* out) {
+// ct[k][p + r] * a[k][l - 1]), i.e. rows (block, p, m in block) (Conv16Args::up_mb = mb channels per block; mb = Mo: plain (p, m) order),
+// taps i = 0 (frame l - 1: ct[k][p + r]) and i = 1 (frame l: ct[k][p]), causal pad 1.
+inline std::vector<uint16_t> pack_up16(const float* pw, const float* ct, int Mo, int K, int r, int mb, H16Weight* out) {
     H16Weight w; w.K = K; w.M = Mo * r; w.Kp = round_up(K, 16); w.Mp = round_up(w.M, 32);
     const int nkc = w.Kp / 16;
     w.nchunks = round_up(2 * nkc, 8);
@@ -178,7 +191,7 @@ inline std::vector<uint16_t> pack_up16(const float* pw, const float* ct, int Mo,
     for (int i = 0; i < 2; ++i)
         for (int p = 0; p < r; ++p)
             for (int m = 0; m < Mo; ++m) {
-                const size_t row = (size_t)p * Mo + m;
+                const size_t row = (size_t)(m / mb) * r * mb + (size_t)p * mb + m % mb;
                 for (int k = 0; k < K; ++k)
                     q[(((size_t)((k / 16) * 2 + i) * w.Mp + row) * 2 + ((k >> 3) & 1)) * 8 + (k & 7)] =
                         f32_to_f16_bits(pw[(size_t)m * K + k] * ct[(size_t)k * 2 * r + (i == 0 ? p + r : p)]);

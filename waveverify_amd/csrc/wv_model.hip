@@ -88,9 +88,9 @@ struct wv_model {
     // stencil table times log2(e): RhArgs), the SpecBlock's 1x1 over the zero-padded spectrum rows, the downsample unit's 1x1 and
     // depth-wise conv composed into one [M][2r][K] conv -- and per decoder stage: the upsample unit as one 2-tap conv over (phase, channel)
     // rows (pack_up16) and its ResnetBlocks; the decoder's first conv pair as one composed conv
-    struct H16Block { wv::H16Weight w1, w2; const float* tab1 = nullptr; };
+    struct H16Block { wv::H16Weight w1, w2; const float *tab1 = nullptr, *tab2 = nullptr; };
     struct H16Stage { std::vector<H16Block> blocks; wv::H16Weight spec, down, cosw, sinw, cosl, sinl, post, head; };   // post / head: the last entry only (conv_post as one composed conv, the head GEMM)
-    struct H16Up { wv::H16Weight up; std::vector<H16Block> blocks; };
+    struct H16Up { wv::H16Weight up; int mb = 0; std::vector<H16Block> blocks; };
     std::vector<H16Stage> h16;                    // n_strides stages; one more when spec_post runs on the f16 pipe too (only its spec / cos / sin / post / head members)
     wv::H16Weight h16_dec_head;
     std::vector<H16Up> h16_ups;                   // generator only; empty = no f16 decoder plan
@@ -228,7 +228,8 @@ struct Uploader {
         wv::H16Weight w;
         { const std::vector<uint16_t> q = wv::pack_rh_pw(host(pre + ".block.1.conv.conv.weight").data(), C, &w); b.w1 = h16_up(q, w); }
         { const std::vector<uint16_t> q = wv::pack_rh_pw(host(pre + ".block.4.conv.conv.weight").data(), C, &w); b.w2 = h16_up(q, w); }
-        b.tab1 = up(wv::pack_rh_table1(host(pre + ".block.2.conv.conv.weight").data(), host(pre + ".block.2.conv.conv.bias").data(), C));
+        b.tab1 = up(wv::pack_rh_table(host(pre + ".block.2.conv.conv.weight").data(), host(pre + ".block.2.conv.conv.bias").data(), C, wv::RH_LOG2E));
+        b.tab2 = up(wv::pack_rh_table(host(pre + ".block.5.conv.conv.weight").data(), host(pre + ".block.5.conv.conv.bias").data(), C, 1.0));
         return b;
     }
     wv::H16Weight h16_up(const std::vector<uint16_t>& q, wv::H16Weight w) {
@@ -525,8 +526,9 @@ int pack_model(wv_model* m) {
                 wv_model::H16Up hu;
                 const UpLayer& u = m->ups[i];
                 wv::H16Weight w;
+                hu.mb = wv::up16_block(u.pw.M, u.ratio) ? wv::up16_block(u.pw.M, u.ratio) : u.pw.M;
                 const std::vector<uint16_t> q = wv::pack_up16(U.host("decoder.model." + std::to_string(n + 3) + ".conv.conv.weight").data(),
-                                                              U.host("decoder.model." + std::to_string(n + 2) + ".convtr.convtr.weight").data(), u.pw.M, u.pw.K, u.ratio, &w);
+                                                              U.host("decoder.model." + std::to_string(n + 2) + ".convtr.convtr.weight").data(), u.pw.M, u.pw.K, u.ratio, hu.mb, &w);
                 hu.up = U.h16_up(q, w);
                 for (int j = 0; j < c.n_residual_dec; ++j) hu.blocks.push_back(U.h16_block("decoder.model." + std::to_string(n + 4 + j), u.pw.M));
                 m->h16_ups.push_back(std::move(hu));
@@ -1039,7 +1041,7 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, const float* film
         for (size_t j = 0; j < m->enc_blocks[s].size(); ++j) {
             const ResBlock& r = m->enc_blocks[s][j];
             wv::RhArgs a{};
-            a.X = R[cur]; a.pre_scale = r.pre_scale; a.w1 = hs.blocks[j].w1; a.w2 = hs.blocks[j].w2; a.tab1 = hs.blocks[j].tab1; a.tab2 = r.tab2;
+            a.X = R[cur]; a.pre_scale = r.pre_scale; a.w1 = hs.blocks[j].w1; a.w2 = hs.blocks[j].w2; a.tab1 = hs.blocks[j].tab1; a.tab2 = hs.blocks[j].tab2;
             a.Y = R[cur ^ 1]; a.Yact = nullptr; a.out_scale = r.out_scale; a.act_scale = 0.f; a.B = B; a.C = C; a.T = Tl;
             const hipError_t e = wv::launch_resblock16(a, st);
             if (e != hipSuccess) return fail(e == hipErrorNotSupported ? WV_ESTATE : WV_EHIP, std::string("launch_resblock16: ") + hipGetErrorString(e));
@@ -1235,7 +1237,7 @@ int wv_generator_forward_f16(wv_model* m, const float* x, const float* msg, int 
         void* free1 = act == R[0] ? R[1] : R[0];
         wv::Conv16Args g{};
         g.X = act; g.w = hu.up; g.bias = u.pw_b; g.resid = nullptr; g.Yf32 = nullptr; g.out_scale = 1.f;
-        g.B = B; g.M = u.pw.M * u.ratio; g.Tin = Tl; g.Tout = Tl; g.ks = 2; g.stride = 1; g.pad = 1; g.up = u.ratio;
+        g.B = B; g.M = u.pw.M * u.ratio; g.Tin = Tl; g.Tout = Tl; g.ks = 2; g.stride = 1; g.pad = 1; g.up = u.ratio; g.up_mb = hu.mb;
         if (u.res.empty()) { g.Y = nullptr; g.Yact = free1; g.act_scale = stage_next; }
         else { g.Y = free1; g.Yact = nullptr; g.act_scale = 0.f; }
         LAUNCH(wv::launch_conv16(g, st));
@@ -1249,7 +1251,7 @@ int wv_generator_forward_f16(wv_model* m, const float* x, const float* msg, int 
             void* dst = nullptr;
             for (void* bb : bufs) if (bb != curb) { dst = bb; break; }
             wv::RhArgs a{};
-            a.X = curb; a.pre_scale = r.pre_scale; a.w1 = hu.blocks[j].w1; a.w2 = hu.blocks[j].w2; a.tab1 = hu.blocks[j].tab1; a.tab2 = r.tab2;
+            a.X = curb; a.pre_scale = r.pre_scale; a.w1 = hu.blocks[j].w1; a.w2 = hu.blocks[j].w2; a.tab1 = hu.blocks[j].tab1; a.tab2 = hu.blocks[j].tab2;
             a.Y = last ? nullptr : dst; a.Yact = last ? dst : nullptr; a.out_scale = r.out_scale; a.act_scale = last ? stage_next : 0.f;
             a.B = B; a.C = u.pw.M; a.T = Tl;
             const hipError_t e = wv::launch_resblock16(a, st);

@@ -126,7 +126,7 @@ int wv_h16_resblock(const void* X16, float pre_scale, const float* w_pw1, const 
     a.X = X16; a.pre_scale = pre_scale;
     { const std::vector<uint16_t> q = wv::pack_rh_pw(w_pw1, C, &a.w1); a.w1.wq = t.upb(q.data(), q.size() * sizeof(uint16_t)); }
     { const std::vector<uint16_t> q = wv::pack_rh_pw(w_pw2, C, &a.w2); a.w2.wq = t.upb(q.data(), q.size() * sizeof(uint16_t)); }
-    a.tab1 = t.upv(wv::pack_rh_table1(w_dw1, b1, C)); a.tab2 = t.upv(wv::pack_rb_table(w_dw2, b2, C));
+    a.tab1 = t.upv(wv::pack_rh_table(w_dw1, b1, C, wv::RH_LOG2E)); a.tab2 = t.upv(wv::pack_rh_table(w_dw2, b2, C, 1.0));
     a.Y = Y16; a.Yact = Yact16; a.out_scale = out_scale; a.act_scale = act_scale; a.B = B; a.C = C; a.T = T;
     const hipError_t e = wv::launch_resblock16(a, (hipStream_t)stream);
     if (e == hipErrorNotSupported) return WV_EINVAL;
@@ -251,7 +251,9 @@ int wv_h16_upsample(const void* X16, const float* w_ct, const float* w_pw, const
     if (!X16 || !w_ct || !w_pw || (!Y16 && !Yact16) || B < 1 || K < 1 || M < 1 || Tin < 1 || ratio < 1) return WV_EINVAL;
     Tmp t;
     wv::Conv16Args a{};
-    { const std::vector<uint16_t> q = wv::pack_up16(w_pw, w_ct, M, K, ratio, &a.w); a.w.wq = t.upb(q.data(), q.size() * sizeof(uint16_t)); }
+    const int mb = wv::up16_block(M, ratio) ? wv::up16_block(M, ratio) : M;
+    { const std::vector<uint16_t> q = wv::pack_up16(w_pw, w_ct, M, K, ratio, mb, &a.w); a.w.wq = t.upb(q.data(), q.size() * sizeof(uint16_t)); }
+    a.up_mb = mb;
     a.X = X16; a.bias = t.up(bias, M); a.Y = Y16; a.Yact = Yact16; a.out_scale = 1.f; a.act_scale = act_scale;
     a.B = B; a.M = M * ratio; a.Tin = Tin; a.Tout = Tin; a.ks = 2; a.stride = 1; a.pad = 1; a.up = ratio;
     return done(t, wv::launch_conv16(a, (hipStream_t)stream), (hipStream_t)stream);
