@@ -721,6 +721,12 @@ class _NetTrainer:
         # spec_learnable: true, modules/conv.py:1023): the training forward uses THEM (as the inference nets do through
         # wv_model_set_stft_basis) and state_dict() writes them back unchanged; they are not trained here (no gradient towards the basis)
         self.spec_basis = {k: torch.from_numpy(np.array(v, dtype=np.float32)) for k, v in state_dict.items() if k.endswith("spec.weight")}
+        # a state dict without them (fresh nets): the reference's own buffers (checkpoint.stft_basis, bit-equal to its CausalSTFT.weight:
+        # tests/golden/dft_basis.npz), so that what the forward used is exactly what state_dict() writes and a resumed run repeats it
+        from .checkpoint import stft_basis as _basis
+        for s_ in range(len(cfg.ratios_enc) + 1):
+            key = ("encoder.spec_post" if s_ == len(cfg.ratios_enc) else f"encoder.spec_blocks.{s_}") + ".spec.weight"
+            self.spec_basis.setdefault(key, _basis((2 ** s_) * cfg.n_fft_base))
         # the message MLP + FiLM parameters sit together, in the order the FiLM kernels read them: their packed block and its gradient
         # are then plain slices of the arenas (no gather before the forward, no scatter after the backward)
         self.film = FilmMlp(cfg) if with_msg else None
