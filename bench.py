@@ -195,10 +195,10 @@ def train_step(a, dev, dist, world, rank):
     torch.cuda.synchronize()
     elapsed_prof = time.perf_counter() - t0
     profile.enable(False)
-    by = {}
+    by, stencil = {}, {}
     for e in profile.collect():
-        k = by.setdefault(e["kernel"], dict(ms=0.0, launches=0, flops=0.0))
-        for f in ("ms", "launches", "flops"):
+        k = (stencil if e["kernel"].startswith("dw_bwd") else by).setdefault(e["kernel"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+        for f in ("ms", "launches", "flops", "bytes"):
             k[f] += e[f]
     if rank == 0:
         ms = elapsed / a.steps * 1e3
@@ -227,6 +227,16 @@ def train_step(a, dev, dist, world, rank):
                           step_frac=round(inst_fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                           note="matrix kernels only (K1 forward / backward GEMMs, dW GEMM): their flops over their own event time; step_frac = the "
                                "same flops over the whole step, i.e. with the bandwidth-bound stencil / reduction / optimizer kernels in the denominator"),
+            roofline_stencil_backward=dict(
+                bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s",
+                ms_per_step=round(sum(v["ms"] for v in stencil.values()) / a.steps, 3),
+                achieved=round(sum(v["bytes"] for v in stencil.values()) / max(sum(v["ms"] for v in stencil.values()), 1e-9) / 1e6, 1),
+                frac=round(sum(v["bytes"] for v in stencil.values()) / max(sum(v["ms"] for v in stencil.values()), 1e-9) / 1e6 / PEAK_HBM_GBS, 4),
+                kernels=sorted(({"kernel": k, "ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["launches"] // a.steps,
+                                 "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] else 0.0} for k, v in stencil.items()),
+                               key=lambda d: -d["ms_per_step"]),
+                note="the depth-wise stencils' transposes (dh and the tap / bias sums; the second half's also the res_scale dot): algorithmic bytes "
+                     "= read dy, read h (and v), write dh, over their own event time") if stencil else None,
             kernels=kernels[:12], profiled_ms_per_step=round(elapsed_prof / a.steps * 1e3, 3),
             note="backward on saved activations (the blocks' 1x1 outputs kept from forward), activation derivative / residual / scale "
                  "epilogues fused into the K1 GEMMs, parameter gradients written in place into one flat arena per net")), flush=True)

@@ -285,6 +285,11 @@ static void launch_dw_bwd(hipStream_t s, const float* dy, const float* h, const 
                           const float* dot_v = nullptr, float* dot_partial = nullptr) {
 #define WV_DWB(K, S) hipLaunchKernelGGL((dw_bwd_kernel<K, S>), dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tin, Tout, ks, stride, pad, h_shared)
     const bool al16 = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(dh)) & 15) == 0;
+    // the stencil's transpose is bandwidth work: read dy [B, M, Tout] and h [B, M, Tin] (and v for the fused res_scale dot), write dh [B, M, Tin];
+    // ks multiply-adds per sample for dh and ks for the tap sums.  Named and priced so that the training bench can put it against the HBM roof.
+    std::string pname;
+    if (prof::enabled()) pname = "dw_bwd<k" + std::to_string(ks) + ",s" + std::to_string(stride) + (dot_partial ? ",dot>" : ">");
+    prof::Scope ps(s, pname.c_str(), 4.0 * ks * (double)B * M * Tout, 4.0 * (double)B * M * ((double)Tout * (dot_partial ? 2.0 : 1.0) + (double)Tin * (dh ? 2.0 : 1.0)));
     if (dot_partial)                                         // caller checked dw_bwd_can_fuse_scale
         hipLaunchKernelGGL((dw_bwd51_vec_kernel<true>), dim3(M, B), dim3(256), 0, s, dy, h, w, dh, partial, M, Tin, dy_scale_ptr, dy_scale, dot_v, dot_partial);
     else if (ks == 5 && stride == 1 && pad == 4 && dh && !h_shared && Tin == Tout && (Tin & 3) == 0 && al16)
