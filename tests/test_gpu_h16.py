@@ -256,11 +256,21 @@ def test_detector_f16_shapes(detector, B, T):
 @pytest.mark.parametrize("n_fft,hop,T", [(64, 1, 16000), (64, 1, 300), (64, 1, 257), (64, 1, 5), (128, 2, 16000), (128, 2, 255), (128, 2, 3), (256, 8, 16000), (256, 8, 520),
                                          (256, 8, 7), (512, 40, 16000), (512, 40, 2600), (512, 40, 39), (1024, 320, 16000), (1024, 320, 20481), (1024, 320, 100)])
 def test_spec_block_in_one_launch(ops, n_fft, hop, T):
+    _spec_block_case(ops, n_fft, hop, T, n_fft)
+
+
+# the locator's scales: half as many channels as DFT points (32 / 64 / 128 at n_fft 64 / 128 / 256, hops 1 / 4 / 32)
+@pytest.mark.parametrize("n_fft,hop,T", [(64, 1, 16000), (64, 1, 257), (64, 1, 3), (128, 4, 16000), (128, 4, 1021), (128, 4, 5), (256, 32, 16000), (256, 32, 2081), (256, 32, 31)])
+def test_spec_block_in_one_launch_half_channels(ops, n_fft, hop, T):
+    _spec_block_case(ops, n_fft, hop, T, n_fft // 2)
+
+
+def _spec_block_case(ops, n_fft, hop, T, C):
     """STFT (waveform split in two f16 terms, f16 basis) -> log-magnitude -> 1x1 -> add in one launch, against the oracle's exact
     composition; silence in one clip (both clamps), a loud clip, tile-edge frame counts.  What separates the two: the basis rounded to
     f16 (leakage around the 1e-5 clamp level, visible only on near-silent bins), P and x' rounded to f16."""
-    rng = np.random.default_rng(n_fft + hop + T)
-    C, F, Tf = n_fft, n_fft // 2 + 1, -(-T // hop)
+    rng = np.random.default_rng(n_fft + hop + T + C)
+    F, Tf = n_fft // 2 + 1, -(-T // hop)
     wav = np.clip(rnd(rng, 3, 1, T, scale=0.1), -1, 1)
     wav[1, 0, : T // 3] = 0.0
     wav[2] *= 8.0

@@ -571,9 +571,12 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv16Args p) {
 // ELU(act_scale * y).  (The exact path's two side rows, sin_0 and sin_{F-1} of a reference-built basis, are rounding-level and dropped.)
 // N = n_fft = rows of the 1x1 (the detector's scales: 64, 128, 256, 512; 1024 = spec_post, whose output goes on in f32), HOP in {1, 2, 4, 8 k}.  A wave's unit is 64 rows x 64 frames
 // (one cos/sin tile pair in GEMM 1, two row tiles in GEMM 2).
-template <int N_, int HOP_>
+// M = rows of the 1x1 = channels of the stream: n_fft (generator / detector: every scale has as many channels as DFT points) or n_fft / 2
+// (the locator: 32 / 64 / 128 channels at n_fft 64 / 128 / 256).  GEMM 2 then has half the row units (some waves sit it out).
+template <int N_, int HOP_, int M_ = N_>
 struct SP {
-    static constexpr int N = N_, HOP = HOP_;
+    static constexpr int N = N_, HOP = HOP_, M = M_;
+    static constexpr int MT2 = M >= 64 ? 2 : 1, NP2 = M / (32 * MT2);   // GEMM 2: row tiles per unit, row units
     static constexpr int NP = N / 64;                            // 64-row units
     static constexpr int NQ = NP >= 4 ? 1 : 4 / NP;              // 64-frame units per tile
     static constexpr int BN = 64 * NQ, PASSES = NP * NQ / 4;
@@ -584,7 +587,8 @@ struct SP {
     static constexpr int Fp = N / 2 + 16, G2 = Fp / 8, NC1 = N / 16, NC2 = Fp / 16;
     static constexpr size_t WIN = (size_t)NPL * PSP * 16;        // bytes of one (hi or lo) window
     static constexpr size_t SMEM = 2 * WIN + (size_t)G2 * BN * 16;
-    static_assert(N % 64 == 0 && (HOP == 1 || HOP == 2 || HOP == 4 || HOP % 8 == 0) && NP * NQ % 4 == 0, "geometry");
+    static constexpr int PASSES2 = (NP2 * NQ + 3) / 4;
+    static_assert(N % 64 == 0 && (HOP == 1 || HOP == 2 || HOP == 4 || HOP % 8 == 0) && NP * NQ % 4 == 0 && (M == N || 2 * M == N) && M % 32 == 0, "geometry");
 };
 
 template <class R>
@@ -733,45 +737,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     RH_BARRIER();
     // ================= GEMM 2: W @ P, + x =================
-    const __amdgpu_buffer_rsrc_t rW = uniform_rsrc(p.pw.wq, p.pw.nchunks * N * 32);
-    constexpr int Gm = N / 8;
+    constexpr int M = R::M, MT2 = R::MT2;
+    const __amdgpu_buffer_rsrc_t rW = uniform_rsrc(p.pw.wq, p.pw.nchunks * M * 32);
+    constexpr int Gm = M / 8;
     const size_t yclip = (size_t)Gm * Tf * 8;
     const __amdgpu_buffer_rsrc_t rR = uniform_rsrc(reinterpret_cast<const h16*>(p.resid) + b * yclip, (int)(yclip * 2));
     const __amdgpu_buffer_rsrc_t rY = uniform_rsrc(p.Y ? reinterpret_cast<h16*>(p.Y) + b * yclip : reinterpret_cast<const h16*>(p.resid), p.Y ? (int)(yclip * 2) : 0);
     const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(p.Yact ? reinterpret_cast<h16*>(p.Yact) + b * yclip : reinterpret_cast<const h16*>(p.resid), p.Yact ? (int)(yclip * 2) : 0);
-    for (int pass = 0; pass < R::PASSES; ++pass) {
-        const int u = wave + 4 * pass, mp = u % NP, nq = u / NP;
-        int avw[2];
+    for (int pass = 0; pass < R::PASSES2; ++pass) {
+        const int u = wave + 4 * pass, mp = u % R::NP2, nq = u / R::NP2;
+        if (u >= R::NP2 * R::NQ) break;                          // (wave-uniform; no barrier follows)
+        int avw[MT2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) avw[mt] = ((64 * mp + 32 * mt + r) * 2 + h) * 16;
+        for (int mt = 0; mt < MT2; ++mt) avw[mt] = ((32 * MT2 * mp + 32 * mt + r) * 2 + h) * 16;
         const h16* Bp = P16 + (size_t)(h * BN + 64 * nq + r) * 8;
-        f32x16 acc[2][2];
+        f32x16 acc[MT2][2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][e][i] = 0.f;
         // the residual operand, requested ahead of the matrix loop (nothing it depends on): its latency passes under GEMM 2
-        h16x4 xr[2][4][2];
-        int xoff[2][4][2];
+        h16x4 xr[MT2][4][2];
+        int xoff[MT2][4][2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int mrow = 64 * mp + 32 * mt + 8 * j + 4 * h, t = t0 + 64 * nq + 32 * e + r;
+                    const int mrow = 32 * MT2 * mp + 32 * mt + 8 * j + 4 * h, t = t0 + 64 * nq + 32 * e + r;
                     const int off = t < Tf ? ((mrow >> 3) * Tf + t) * 16 + 8 * h : H_OOB;
                     xoff[mt][j][e] = off;
                     xr[mt][j][e] = __builtin_bit_cast(h16x4, __builtin_amdgcn_raw_buffer_load_b64(rR, off, 0, 0));
                 }
         constexpr int NA2 = 4, AD2 = NA2 - 1;
-        h16x8 aw[NA2][2];
-        auto ldw = [&](int c, h16x8 (&d)[2]) {
-            const int so = c * N * 32;
+        h16x8 aw[NA2][MT2];
+        auto ldw = [&](int c, h16x8 (&d)[MT2]) {
+            const int so = c * M * 32;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) d[mt] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, avw[mt], so, 0));
+            for (int mt = 0; mt < MT2; ++mt) d[mt] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, avw[mt], so, 0));
         };
 #pragma unroll
         for (int c = 0; c < AD2 && c < R::NC2; ++c) ldw(c, aw[c % NA2]);
@@ -782,17 +788,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int e = 0; e < 2; ++e) bb[e] = *reinterpret_cast<const h16x8*>(Bp + (size_t)(2 * c * BN + 32 * e) * 8);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw[c % NA2][mt], bb[e], acc[mt][e], 0, 0, 0);
-            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+            if constexpr (MT2 == 2) asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+            else asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]));
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int mrow = 64 * mp + 32 * mt + 8 * j + 4 * h;
+                const int mrow = 32 * MT2 * mp + 32 * mt + 8 * j + 4 * h;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int t = t0 + 64 * nq + 32 * e + r;
@@ -815,7 +822,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     if (p.Yf32 && t < Tf) {
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) p.Yf32[((size_t)b * N + mrow + rr) * Tf + t] = y[rr];
+                        for (int rr = 0; rr < 4; ++rr) p.Yf32[((size_t)b * M + mrow + rr) * Tf + t] = y[rr];
                     }
                 }
             }
@@ -837,10 +844,10 @@ hipError_t spec16_launch(const Spec16Args& a, hipStream_t s) {
     const long long grid = (long long)((a.Tf + R::BN - 1) / R::BN) * a.B;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
     std::string name;
-    if (prof::enabled()) name = "spec16<" + std::to_string(R::N) + ",hop" + std::to_string(R::HOP) + ">";
-    const double Bd = a.B, Tf = a.Tf, Nn = R::N;
-    prof::Scope ps(s, name.c_str(), Bd * Tf * (2.0 * 2.0 * (Nn + 2.0) * Nn + 2.0 * Nn * (Nn / 2 + 1)),
-                   Bd * (4.0 * a.T + 2.0 * Nn * Tf * (1.0 + (a.Y ? 1.0 : 0.0) + (a.Yact ? 1.0 : 0.0) + (a.Yf32 ? 2.0 : 0.0))));
+    if (prof::enabled()) name = "spec16<" + std::to_string(R::N) + ",hop" + std::to_string(R::HOP) + (R::M != R::N ? "," + std::to_string(R::M) + "ch" : std::string()) + ">";
+    const double Bd = a.B, Tf = a.Tf, Nn = R::N, Mm = R::M;
+    prof::Scope ps(s, name.c_str(), Bd * Tf * (2.0 * 2.0 * (Nn + 2.0) * Nn + 2.0 * Mm * (Nn / 2 + 1)),
+                   Bd * (4.0 * a.T + 2.0 * Mm * Tf * (1.0 + (a.Y ? 1.0 : 0.0) + (a.Yact ? 1.0 : 0.0) + (a.Yf32 ? 2.0 : 0.0))));
     hipLaunchKernelGGL((spec16_kernel<R>), dim3((unsigned)grid), dim3(256), R::SMEM, s, a);
     return hipGetLastError();
 }
@@ -1523,16 +1530,22 @@ hipError_t launch_conv16(const Conv16Args& a, hipStream_t s) {
 
 hipError_t launch_spec16(const Spec16Args& a, hipStream_t s) {
     if (!a.wav || !a.resid || (!a.Y && !a.Yact && !a.Yf32) || !a.cosw.wq || !a.sinw.wq || !a.cosl.wq || !a.sinl.wq || !a.pw.wq || a.B < 1 || a.T < 1) return hipErrorInvalidValue;
-    const int N = a.n_fft;
-    if (a.Tf != (a.T + a.hop - 1) / a.hop || a.pw.M != N || a.pw.K != N / 2 + 1 || a.pw.Mp != N || a.pw.Kp != N / 2 + 16 || a.cosw.M != N / 2 || a.cosw.K != N ||
+    const int N = a.n_fft, M = a.pw.M;
+    if (a.Tf != (a.T + a.hop - 1) / a.hop || (M != N && 2 * M != N) || a.pw.K != N / 2 + 1 || a.pw.Mp != M || a.pw.Kp != N / 2 + 16 || a.cosw.M != N / 2 || a.cosw.K != N ||
         a.sinw.M != N / 2 || a.sinw.K != N || a.cosw.Mp != N / 2 || a.sinw.Mp != N / 2 || a.cosw.nchunks < N / 16 || a.sinw.nchunks < N / 16 || a.cosl.nchunks < N / 16 || a.sinl.nchunks < N / 16)
         return hipErrorNotSupported;
-    if ((long long)N * a.Tf * 2 >= H_OOB || !al16(a.resid) || (a.Y && !al16(a.Y)) || (a.Yact && !al16(a.Yact))) return hipErrorNotSupported;
-    if (N == 64 && a.hop == 1) return spec16_launch<SP<64, 1>>(a, s);
-    if (N == 128 && a.hop == 2) return spec16_launch<SP<128, 2>>(a, s);
-    if (N == 256 && a.hop == 8) return spec16_launch<SP<256, 8>>(a, s);
-    if (N == 512 && a.hop == 40) return spec16_launch<SP<512, 40>>(a, s);
-    if (N == 1024 && a.hop == 320) return spec16_launch<SP<1024, 320>>(a, s);
+    if ((long long)M * a.Tf * 2 >= H_OOB || !al16(a.resid) || (a.Y && !al16(a.Y)) || (a.Yact && !al16(a.Yact))) return hipErrorNotSupported;
+    if (M == N) {                                               // generator / detector scales
+        if (N == 64 && a.hop == 1) return spec16_launch<SP<64, 1>>(a, s);
+        if (N == 128 && a.hop == 2) return spec16_launch<SP<128, 2>>(a, s);
+        if (N == 256 && a.hop == 8) return spec16_launch<SP<256, 8>>(a, s);
+        if (N == 512 && a.hop == 40) return spec16_launch<SP<512, 40>>(a, s);
+        if (N == 1024 && a.hop == 320) return spec16_launch<SP<1024, 320>>(a, s);
+    } else {                                                    // the locator's: half as many channels as DFT points
+        if (N == 64 && a.hop == 1) return spec16_launch<SP<64, 1, 32>>(a, s);
+        if (N == 128 && a.hop == 4) return spec16_launch<SP<128, 4, 64>>(a, s);
+        if (N == 256 && a.hop == 32) return spec16_launch<SP<256, 32, 128>>(a, s);
+    }
     return hipErrorNotSupported;
 }
 

@@ -488,7 +488,8 @@ int pack_model(wv_model* m) {
             }
             m->h16.push_back(std::move(st));
         }
-        if (U.err == WV_OK && C == m->specs[S].n_fft && C == 1024 && m->specs[S].hop == 320) {      // spec_post as one launch as well
+        if (U.err == WV_OK && ((C == m->specs[S].n_fft && C == 1024 && m->specs[S].hop == 320) ||      // spec_post as one launch as well (the default
+                               (2 * C == m->specs[S].n_fft && C == 128 && m->specs[S].hop == 32))) {    // generator / detector; the default locator)
             wv_model::H16Stage st;
             const int n_fft = m->specs[S].n_fft;
             st.spec = U.h16(U.host("encoder.spec_post.layer.conv.conv.weight"), nullptr, C, m->specs[S].F, 1);
@@ -1061,7 +1062,7 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, const float* film
         f.wav = x; f.cosw = hs.cosw; f.sinw = hs.sinw; f.cosl = hs.cosl; f.sinl = hs.sinl; f.pw = hs.spec; f.resid = R[cur]; f.Y = nullptr; f.Yact = A0;
         f.out_scale = sp.scale; f.act_scale = d.pre_scale; f.c1 = 0.5f * 0.6931471805599453f * sp.inv_std; f.c0 = -sp.mean * sp.inv_std;
         f.B = B; f.T = T; f.Tf = Tl; f.n_fft = sp.n_fft; f.hop = sp.hop;
-        const hipError_t fe = C == sp.n_fft ? wv::launch_spec16(f, st) : hipErrorNotSupported;
+        const hipError_t fe = (C == sp.n_fft || 2 * C == sp.n_fft) ? wv::launch_spec16(f, st) : hipErrorNotSupported;
         if (fe != hipSuccess && fe != hipErrorNotSupported) return fail(WV_EHIP, std::string("launch_spec16: ") + hipGetErrorString(fe));
         if (fe == hipErrorNotSupported) {
             if ((size_t)B * round_up_int(sp.F, 16) * Tl * 2 > L.act * 4) return fail(WV_ESTATE, "f16 mode: the spectrogram of this scale does not fit its staging buffer");

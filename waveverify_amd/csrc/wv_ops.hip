@@ -282,7 +282,7 @@ int wv_h16_conv_film(const void* X16, const float* w_pw, const float* w_dw, cons
 }
 int wv_h16_spec_block(const float* wav, const float* basis_or_null, const float* w_pw, const void* x16, void* Y16, void* Yact16, int B, int T,
                       int n_fft, int hop, int M, float mean, float std_, float out_scale, float act_scale, void* stream) {
-    if (!wav || !w_pw || !x16 || (!Y16 && !Yact16) || B < 1 || T < 1 || n_fft < 2 || (n_fft & 1) || hop < 1 || M != n_fft || !(std_ > 0.f)) return WV_EINVAL;
+    if (!wav || !w_pw || !x16 || (!Y16 && !Yact16) || B < 1 || T < 1 || n_fft < 2 || (n_fft & 1) || hop < 1 || (M != n_fft && 2 * M != n_fft) || !(std_ > 0.f)) return WV_EINVAL;
     Tmp t;
     const std::vector<float> basis = stft_basis_host(basis_or_null, n_fft);
     std::vector<uint16_t> q4[4];
