@@ -8,6 +8,9 @@ measured in tools/mfma_peak.hip instead.
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from waveverify_amd import _lib
+if "--lib" in sys.argv:                      # an A/B variant built by tools/variant.sh
+    i = sys.argv.index("--lib"); _lib.LIB_PATH = os.path.abspath(sys.argv[i + 1]); del sys.argv[i:i + 2]
 from waveverify_amd import ops, profile
 
 
