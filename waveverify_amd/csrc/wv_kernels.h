@@ -72,6 +72,11 @@ struct RbArgs {
     float out_scale, act_scale;
     int B, C, T;
     int num_t, ntiles;    // filled by the launcher: tiles per clip, tiles in all
+    // training forward (wv_train_block_forward): out_scale is multiplied by out_scale_ptr[0] (a device scalar: res_scale_param) when
+    // given; sv_* (all four or none, with Y): the tensors the block's backward wants, [B, C, T] each -- h0 = W1 @ ELU(c x), u = DW5(h0) + b1
+    // (BEFORE the second half's ELU), h1 = W2 @ ELU(u), v = DW5(h1) + b2 (y = x + s v) -- written from the same registers the kernel computes them in
+    const float* out_scale_ptr = nullptr;
+    float *sv_h0 = nullptr, *sv_u = nullptr, *sv_h1 = nullptr, *sv_v = nullptr;
 };
 bool rb_supported(const RbArgs& a);
 hipError_t launch_resblock(const RbArgs& a, hipStream_t s);   // hipErrorNotSupported: run it as two K1 launches

@@ -189,7 +189,7 @@ __device__ __forceinline__ void rb_gemm(f32x16 (&acc)[R::NT], f32x4 (&ar)[RB_AD 
     }
 }
 
-// OUT: 1 = Y, 2 = Yact, 3 = both
+// OUT: 1 = Y, 2 = Yact, 3 = both; 5 = Y and the four tensors a training step keeps for the backward (RbArgs::sv_*)
 template <class R, int OUT>
 __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::WPS, R::WPS))) void rb_kernel(RbArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -262,6 +262,13 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
         }
     };
     auto x_off = [&](int to0) { const int t = to0 + co; return (own && t < T) ? (row0 * T + t) * 4 : RB_OOB; };
+    // training forward: which of this lane's columns of the GEMM outputs / of u belong to this tile.  Accumulator column c of GEMM 1 is
+    // time to0 - 8 + c: this tile's share is c in [8, WD), each column owned by one group (the last group also keeps its 4 overlap
+    // columns); u and GEMM 2's output at column c are time to0 - 4 + c: c in [4, WD - 4), the lanes that write u.
+    const bool h0own = (OUT & 4) && co >= 8 && co < R::WD && (NT * q < R::GS || (grp == R::NG - 1 && NT * q < R::GS + 4));
+    const bool u_own = (OUT & 4) && uw && co >= 4 && co < R::WD - 4;
+    auto sv_off = [&](bool mine, int t) { return (mine && t < T) ? (row0 * T + t) * 4 : RB_OOB; };
+    const float oscale = p.out_scale_ptr ? p.out_scale * p.out_scale_ptr[0] : p.out_scale;
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
@@ -310,6 +317,10 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
         RB_T(3);
         // ================= epilogue 1: u = ELU(DW5(H1) + b1) -> S ======================================
         {
+            const size_t bo1 = (size_t)b * C * T;
+            const __amdgpu_buffer_rsrc_t rH0 = uniform_rsrc((OUT & 4) ? p.sv_h0 + bo1 : p.X, (OUT & 4) ? clip_bytes : 0);
+            const __amdgpu_buffer_rsrc_t rU = uniform_rsrc((OUT & 4) ? p.sv_u + bo1 : p.X, (OUT & 4) ? clip_bytes : 0);
+            const int vh0 = sv_off(h0own, to0 - 8 + co), vu = sv_off(u_own, to0 - 4 + co);
             f32x4 w0n = *reinterpret_cast<const f32x4*>(Wrow1), w1n = *reinterpret_cast<const f32x4*>(Wrow1 + 4);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -326,6 +337,19 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
 #pragma unroll
                 for (int e = 0; e < NT; ++e) uv[e] = elu1(y[e] * 1.f);
                 if (uw) *reinterpret_cast<ovec*>(Urow + cr * LD) = uv;
+                if constexpr ((OUT & 4) != 0) {
+                    ovec hv, ur;                                 // the first half's output BEFORE the second half's ELU: what its backward differentiates
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) { hv[e] = acc[e][r]; ur[e] = y[e]; }
+                    const int o0 = vh0 == RB_OOB ? RB_OOB : vh0 + cr * row_bytes, o1 = vu == RB_OOB ? RB_OOB : vu + cr * row_bytes;
+                    if constexpr (NT == 4) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, hv), rH0, o0, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, ur), rU, o1, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, hv), rH0, o0, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, ur), rU, o1, 0, 0);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (tt == 0 && grp == 0 && NT * q < 4) {             // u at times < 0 is the second conv's zero padding
@@ -365,6 +389,9 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
             const __amdgpu_buffer_rsrc_t rY = uniform_rsrc((OUT & 1) ? p.Y + bo : p.X, (OUT & 1) ? clip_bytes : 0);
             const __amdgpu_buffer_rsrc_t rA = uniform_rsrc((OUT & 2) ? p.Yact + bo : p.X, (OUT & 2) ? clip_bytes : 0);
             const int voff0 = x_off(to0);
+            const __amdgpu_buffer_rsrc_t rH1 = uniform_rsrc((OUT & 4) ? p.sv_h1 + bo : p.X, (OUT & 4) ? clip_bytes : 0);
+            const __amdgpu_buffer_rsrc_t rV = uniform_rsrc((OUT & 4) ? p.sv_v + bo : p.X, (OUT & 4) ? clip_bytes : 0);
+            const int vh1 = sv_off(u_own, to0 - 4 + co);
             // what is left of the next window (the rows the last quarter of GEMM 2 still read), ahead of the stores below
             refill(next, R::PARTS > 1 ? 16 * (NCH - NCH / R::PARTS) : 0, C);
             f32x4 w0n = *reinterpret_cast<const f32x4*>(Wrow2), w1n = *reinterpret_cast<const f32x4*>(Wrow2 + 4);
@@ -381,8 +408,21 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
                 rb_stencil<NT>(acc, r, w0, w1, v);
                 ovec y;
 #pragma unroll
-                for (int e = 0; e < NT; ++e) y[e] = fmaf(v[e], p.out_scale, X[r][e]);
+                for (int e = 0; e < NT; ++e) y[e] = fmaf(v[e], oscale, X[r][e]);
                 const int off = voff0 + cr * row_bytes;
+                if constexpr ((OUT & 4) != 0) {
+                    ovec hv, vv;
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) { hv[e] = acc[e][r]; vv[e] = v[e]; }
+                    const int o1 = vh1 == RB_OOB ? RB_OOB : vh1 + cr * row_bytes;
+                    if constexpr (NT == 4) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, hv), rH1, o1, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, vv), rV, off, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, hv), rH1, o1, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, vv), rV, off, 0, 0);
+                    }
+                }
                 if constexpr ((OUT & 1) != 0) {
                     if constexpr (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
@@ -399,7 +439,7 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
         }
         RB_T(8);
         // the refill is older than this epilogue's stores: wait until only those are outstanding, then meet the other waves
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(16 * ((OUT & 1) + (OUT >> 1))) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(16 * ((OUT & 1) + ((OUT >> 1) & 1) + ((OUT & 4) ? 2 : 0))) : "memory");
         RB_BARRIER();                                            // B0: the next window has landed
     }
 #ifdef RB_STAMP
@@ -447,16 +487,17 @@ hipError_t rb_launch(RbArgs a, hipStream_t s) {
     const int per_cu = std::max(1, std::min((int)(160 * 1024 / R::SMEM), 4 * R::WPS / R::NWAVES));
     const int grid = (int)std::min<long long>(nt, (long long)cu_count() * per_cu);
     std::string name;
-    if (prof::enabled()) name = "resblock<" + std::to_string(R::C) + "," + std::to_string(R::WD) + ">";
+    if (prof::enabled()) name = std::string((OUT & 4) ? "resblock_train<" : "resblock<") + std::to_string(R::C) + "," + std::to_string(R::WD) + ">";
     const double C = a.C, Bd = a.B, T = a.T;
     prof::Scope ps(s, name.c_str(), 2.0 * 2.0 * Bd * C * (C * T + 5.0 * T),
-                   4.0 * Bd * C * T * (1.0 + ((OUT & 1) ? 1.0 : 0.0) + ((OUT & 2) ? 1.0 : 0.0)));
+                   4.0 * Bd * C * T * (1.0 + ((OUT & 1) ? 1.0 : 0.0) + ((OUT & 2) ? 1.0 : 0.0) + ((OUT & 4) ? 4.0 : 0.0)));
     hipLaunchKernelGGL((rb_kernel<R, OUT>), dim3((unsigned)grid), dim3(R::NTHREADS), R::SMEM, s, a);
     return hipGetLastError();
 }
 
 template <class R>
 hipError_t rb_pick_out(const RbArgs& a, hipStream_t s) {
+    if (a.sv_h0) return rb_launch<R, 5>(a, s);
     if (a.Y && a.Yact) return rb_launch<R, 3>(a, s);
     if (a.Y) return rb_launch<R, 1>(a, s);
     return rb_launch<R, 2>(a, s);
@@ -470,6 +511,10 @@ bool rb_supported(const RbArgs& a) {
     if (a.pw1.M != a.C || a.pw1.K != a.C || a.pw2.M != a.C || a.pw2.K != a.C) return false;
     if (a.pw1.Mp != round_up(a.C, M_ALIGN) || a.pw2.Mp != a.pw1.Mp) return false;
     if ((long long)a.C * a.T * 4 >= RB_OOB) return false;       // 32-bit buffer offsets inside one clip
+    if (a.sv_h0 || a.sv_u || a.sv_h1 || a.sv_v) {               // the training form: all four, with Y alone
+        if (!a.sv_h0 || !a.sv_u || !a.sv_h1 || !a.sv_v || !a.Y || a.Yact) return false;
+        if (!aligned16(a.sv_h0) || !aligned16(a.sv_u) || !aligned16(a.sv_h1) || !aligned16(a.sv_v)) return false;
+    }
     return aligned16(a.X) && (!a.Y || aligned16(a.Y)) && (!a.Yact || aligned16(a.Yact));
 }
 

@@ -82,6 +82,16 @@ __global__ __launch_bounds__(256) void wn_fold_pair_kernel(WnFoldArgs a, WnFoldA
     else wn_fold_row(b, m - a.M, red);
 }
 
+// the one-launch ResnetBlock kernel's stencil table (wv_kernels.h pack_rb_table: per channel 5 taps, bias, 1, 0) from the folded taps
+__global__ __launch_bounds__(256) void rb_table_pair_kernel(const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ t1,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ t2, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C * 8) return;
+    const int half = i / (C * 8), r = i - half * C * 8, m = r >> 3, j = r & 7;
+    const float* w = half ? w2 : w1; const float* b = half ? b2 : b1; float* t = half ? t2 : t1;
+    t[r] = j < 5 ? w[m * 5 + j] : (j == 5 ? (b ? b[m] : 0.f) : (j == 6 ? 1.f : 0.f));
+}
+
 // (dg, dv) of w = g * v / ||v||:  dot = <dw, v>;  dg = dot / ||v||;  dv = g / ||v|| * (dw - dot / ||v||^2 * v)
 __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ v,
                                                      const float* __restrict__ inv_norm, const float* __restrict__ dw,
@@ -1329,7 +1339,8 @@ int wv_train_half_backward(wv_train_unit* h, const float* x, const float* g_pw, 
 struct wv_train_block {
     wv_train_unit* h[2] = {nullptr, nullptr};
     float* partial = nullptr;
-    ~wv_train_block() { delete h[0]; delete h[1]; if (partial) (void)hipFree(partial); }
+    float* tab = nullptr;                                        // [2][C][8]: the one-launch forward kernel's stencil tables (rebuilt every step)
+    ~wv_train_block() { delete h[0]; delete h[1]; if (partial) (void)hipFree(partial); if (tab) (void)hipFree(tab); }
 };
 
 int wv_train_block_create(int C, wv_train_block** out) {
@@ -1338,6 +1349,7 @@ int wv_train_block_create(int C, wv_train_block** out) {
     int rc = wv_train_half_create(C, &b->h[0]);
     if (!rc) rc = wv_train_half_create(C, &b->h[1]);
     if (!rc && hipMalloc((void**)&b->partial, wv::RED_BLOCKS * sizeof(float)) != hipSuccess) rc = tfail(WV_EHIP, "device allocation failed");
+    if (!rc && hipMalloc((void**)&b->tab, (size_t)2 * C * 8 * sizeof(float)) != hipSuccess) rc = tfail(WV_EHIP, "device allocation failed");
     if (rc) { delete b; return rc; }
     *out = b;
     return WV_OK;
@@ -1362,6 +1374,27 @@ int wv_train_block_forward(wv_train_block* b, const float* x, const wv_half_para
     const size_t act = al256((size_t)B * b->h[0]->M * T * 4);
     float* u = (float*)saved; float* v = (float*)((char*)saved + act);
     float* H0 = (float*)((char*)saved + 2 * act); float* H1 = (float*)((char*)saved + 3 * act);
+    // The narrow layers (C = 64, 96, 128, 192, k = 5): the whole block in ONE launch of the inference kernel (wv_rb.hip) in its training
+    // form -- x read once, u kept in LDS for the second GEMM, and the four saved tensors written from the registers they are computed
+    // in (6 HBM passes instead of the two launches' 8); same accumulation order, stencil and ELU as the two K1 launches below.
+    if (b->h[0]->ks == 5 && b->h[1]->ks == 5) {
+        const int C = b->h[0]->M;
+        wv::RbArgs f{};
+        f.X = x; f.pre_scale = pre_scale; f.pw1 = pack_of(b->h[0], false); f.pw2 = pack_of(b->h[1], false);
+        f.tab1 = b->tab; f.tab2 = b->tab + (size_t)C * 8;
+        f.Y = y; f.Yact = nullptr; f.out_scale = res_scale; f.out_scale_ptr = res_scale_param; f.act_scale = 0.f; f.B = B; f.C = C; f.T = T;
+        f.sv_h0 = H0; f.sv_u = u; f.sv_h1 = H1; f.sv_v = v;
+        if (wv::rb_supported(f)) {
+            int rc = fold_step(b->h[0], p[0].g_pw, p[0].v_pw, p[0].g_dw, p[0].v_dw, s);
+            if (!rc) rc = fold_step(b->h[1], p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, s);
+            if (rc) return rc;
+            hipLaunchKernelGGL(wv::rb_table_pair_kernel, dim3((2 * C * 8 + 255) / 256), dim3(256), 0, s, b->h[0]->w_dw, p[0].bias, b->tab,
+                               b->h[1]->w_dw, p[1].bias, b->tab + (size_t)C * 8, C);
+            T_LAUNCH(hipGetLastError());
+            T_LAUNCH(wv::launch_resblock(f, s));
+            return WV_OK;
+        }
+    }
     int rc = unit_forward_impl(b->h[0], x, p[0].g_pw, p[0].v_pw, p[0].g_dw, p[0].v_dw, p[0].bias, pre_scale, 1, u, H0, B, T, stream);
     bool summed = false;                                       // y = x + s v from the second half's own epilogue where the LDS-DMA core runs it
     if (!rc) rc = unit_forward_impl(b->h[1], u, p[1].g_pw, p[1].v_pw, p[1].g_dw, p[1].v_dw, p[1].bias, 1.f, 1, v, H1, B, T, stream,
