@@ -333,6 +333,18 @@ def test_waveverify_api_opt_in():
     wv.detector_precision = "bf16"
     with pytest.raises(ValueError):
         wv.detect_batch(wm)
+    # all three nets at once: embed / locate through the mode as well; the exact outputs are the default again after set_precision("f32")
+    x, msg = torch.from_numpy(x_np).cuda(), torch.from_numpy(msg_np).cuda()
+    loc32 = wv.locate_batch(wm)
+    wv.set_precision("f16")
+    wm16 = wv.embed_batch(x, msg)
+    assert not torch.equal(wm16, wm) and float((wm16 - wm).abs().max()) <= 1e-4
+    assert torch.equal(wv.detect_batch(wm16)[0], bits32)
+    assert float((wv.locate_batch(wm) - loc32).abs().max()) <= 0.02
+    with pytest.raises(ValueError):
+        wv.set_precision("bf16")
+    wv.set_precision("f32")
+    assert torch.equal(wv.embed_batch(x, msg), wm)
 
 
 # ---- seeded sweep of geometries the detector does not use: the generic conv (any taps / stride / pad, ragged channel counts on the f32
@@ -638,3 +650,40 @@ def test_generator_f16_captures_into_a_hip_graph(nets3):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(w1, w0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_f16_mode_on_other_configurations(seed):
+    """The mode on configurations OTHER than the defaults, inside the f16 kernels' coverage (stage widths 32 ... 768, k = 5, dilation 1):
+    other base widths (so that the SpecBlocks take the fallback path or the half-channel kernel), other block counts, strides and FiLM
+    band counts.  Against the exact path of this library on the same weights (which tests/test_gpu_fuzz.py holds to the oracle): wm within
+    the 1e-4 bar, bits equal, locator logits within 3 % of their range."""
+    from waveverify_amd.config import default_config
+    from waveverify_amd.init import random_state_dict, synthetic_clips
+    from waveverify_amd.nets import HipNet
+    rng = np.random.default_rng(4000 + seed)
+    strides = [[8, 5, 4, 2], [8, 4, 2], [5, 4, 2], [8, 5, 4, 2], [4, 4, 2], [8, 5, 2]][seed]
+    ce = [64, 32, 64, 32, 96, 64][seed]
+    cd = 96                                                      # decoder stages 768 / 384 / 192 / 96 (four strides) or 384 / 192 / 96
+    kw = dict(channels_enc=ce, strides=strides, n_residual_enc=int(rng.integers(1, 3)))
+    cg = default_config("generator", channels_dec=cd, n_residual_dec=int(rng.integers(1, 4)), freq_bands=int(rng.choice([2, 4])), **kw)
+    cdt = default_config("detector", **kw)
+    cl = default_config("locator", **kw)
+    G, D, L = (HipNet(c, random_state_dict(c, 10 + seed)) for c in (cg, cdt, cl))
+    T = int(rng.choice([16000, 8000, 12345]))
+    x_np, msg_np = synthetic_clips(3, T, seed=seed)
+    x, msg = torch.from_numpy(x_np).cuda(), torch.from_numpy(msg_np).cuda()
+    try:
+        wm16 = G.generator(x, msg, add_input=True, precision="f16")
+    except RuntimeError as e:                                    # a stage outside the kernels' set: the mode says so, the exact path runs
+        assert "f16" in str(e)
+        G.generator(x, msg, add_input=True)
+        pytest.skip(f"configuration outside the f16 plan: {e}")
+    wm = G.generator(x, msg, add_input=True)
+    assert torch.isfinite(wm16).all() and float((wm16 - wm).abs().max()) <= 1e-4, float((wm16 - wm).abs().max())
+    mp, mp16 = D.detector_mean_prob(wm), D.detector_mean_prob(wm16, precision="f16")
+    dp = float((mp - mp16).abs().max())
+    far = (mp - 0.5).abs() > 4 * dp
+    assert dp <= 2e-2 and torch.equal((mp16 >= 0.5)[far], (mp >= 0.5)[far])
+    lg, lg16 = L.locator(wm), L.locator(wm, precision="f16")
+    assert float((lg - lg16).abs().max()) <= 0.03 * max(1.0, float(lg.abs().max()))

@@ -70,6 +70,10 @@ class WaveVerify:
         # NOT in the reference: "f16" routes detect / detect_batch / verify through the detector's f16-operand / f32-accumulate mode
         # (csrc/wv_h16.hip; the same bits on every fixture, ~3x the clips per second).  Opt-in only; the default is the exact path.
         self.detector_precision = "f32"
+        # ... and the same switch for embed / embed_batch (`wm` stays within 1e-4 of the exact path's and the reference's) and locate /
+        # locate_batch.  `set_precision("f16")` flips all three; `value` of the headline benchmark is always the exact path.
+        self.generator_precision = "f32"
+        self.locator_precision = "f32"
         # .model.generator / .detector / .locator like the reference's AudioWatermarking
         self.model = SimpleNamespace(generator=nets.get("generator"), detector=nets.get("detector"),
                                      locator=nets.get("locator"))
@@ -81,6 +85,12 @@ class WaveVerify:
             return torch.device("cuda", torch.cuda.current_device())
         return torch.device(device)
 
+    def set_precision(self, precision: str) -> None:
+        """NOT in the reference: "f32" (default, exact) or "f16" (the f16-operand / f32-accumulate throughput mode) for all three nets."""
+        if precision not in ("f32", "f16"):
+            raise ValueError("precision must be 'f32' or 'f16'")
+        self.generator_precision = self.detector_precision = self.locator_precision = precision
+
     def _need(self, name: str) -> HipNet:
         net = getattr(self.model, name)
         if net is None:
@@ -91,7 +101,7 @@ class WaveVerify:
     @torch.no_grad()
     def embed_batch(self, audio: torch.Tensor, message: torch.Tensor) -> torch.Tensor:
         """audio [B,1,T] (or [B,T]); message [B,16] or [1,16] (0/1) -> watermarked [B,1,T]."""
-        return self._need("generator").generator(audio, message, add_input=True)
+        return self._need("generator").generator(audio, message, add_input=True, precision=self.generator_precision)
 
     @torch.no_grad()
     def detect_batch(self, audio: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -102,7 +112,7 @@ class WaveVerify:
     @torch.no_grad()
     def locate_batch(self, audio: torch.Tensor) -> torch.Tensor:
         """-> sigmoid(locator logits) [B, T]."""
-        return torch.sigmoid(self._need("locator").locator(audio)).squeeze(1)
+        return torch.sigmoid(self._need("locator").locator(audio, precision=self.locator_precision)).squeeze(1)
 
     # ------------------------------------------------------------------ reference file API
     def embed(self, audio_path: Union[str, Path], watermark_id: Union[WatermarkID, str, int],

@@ -488,17 +488,20 @@ int pack_model(wv_model* m) {
             }
             m->h16.push_back(std::move(st));
         }
-        if (U.err == WV_OK && ((C == m->specs[S].n_fft && C == 1024 && m->specs[S].hop == 320) ||      // spec_post as one launch as well (the default
-                               (2 * C == m->specs[S].n_fft && C == 128 && m->specs[S].hop == 32))) {    // generator / detector; the default locator)
+        if (U.err == WV_OK && C % 16 == 0) {
+            // spec_post on the f16 pipe as well: in one launch where the scale is one of spec16's (the default generator / detector: 1024 points,
+            // hop 320; the default locator: 256 points, hop 32, 128 channels), else the exact STFT kernel + the 1x1 on the f16 pipe
             wv_model::H16Stage st;
             const int n_fft = m->specs[S].n_fft;
             st.spec = U.h16(U.host("encoder.spec_post.layer.conv.conv.weight"), nullptr, C, m->specs[S].F, 1);
-            auto ov = m->stft_override.find("encoder.spec_post.spec.weight");
-            const std::vector<float> basis = ov != m->stft_override.end() ? ov->second : make_basis(n_fft);
-            std::vector<uint16_t> q4[4];
-            wv::H16Weight w4[4];
-            wv::pack_stft16(basis.data(), n_fft, q4, w4);
-            st.cosw = U.h16_up(q4[0], w4[0]); st.sinw = U.h16_up(q4[1], w4[1]); st.cosl = U.h16_up(q4[2], w4[2]); st.sinl = U.h16_up(q4[3], w4[3]);
+            if ((C == n_fft && C == 1024 && m->specs[S].hop == 320) || (2 * C == n_fft && C == 128 && m->specs[S].hop == 32)) {
+                auto ov = m->stft_override.find("encoder.spec_post.spec.weight");
+                const std::vector<float> basis = ov != m->stft_override.end() ? ov->second : make_basis(n_fft);
+                std::vector<uint16_t> q4[4];
+                wv::H16Weight w4[4];
+                wv::pack_stft16(basis.data(), n_fft, q4, w4);
+                st.cosw = U.h16_up(q4[0], w4[0]); st.sinw = U.h16_up(q4[1], w4[1]); st.cosl = U.h16_up(q4[2], w4[2]); st.sinl = U.h16_up(q4[3], w4[3]);
+            }
             // conv_post (ELU -> depth-wise k -> 1x1 + bias, seanet.py:797-823) as one dense conv: W[m][i][k] = pw[m][k] * dw[k][i];
             // the head's composed weight wc[D][nb * hop] transposed into A fragments [nb * hop][D]
             {
@@ -1088,42 +1091,54 @@ static int run_encoder_stages_f16(wv_model* m, const float* x, const float* film
     }
     *post_done = false; *latent_done = false; *Fr_out = Tl;
     if ((int)m->h16.size() > S) {
-        // spec_post (seanet.py:781-795) on the f16 pipe as well: x from the c8 buffer, x' = x + scale * (W @ P) out in f32 for conv_post.
-        // (x sits in R[cur]; when that is R[0] the f32 result, twice the bytes, goes through R[1] and is copied over.)
+        // spec_post (seanet.py:781-795) on the f16 pipe as well: x' = x + scale * (W @ P) from the c8 buffer R[cur], out as ELU(x') in c8 (for
+        // the composed conv_post) or as f32 [B, C, Tl] in the stream buffer r[0] (for the exact conv_post; when x sits in R[0] the f32
+        // result, twice the bytes, goes through R[1] and is copied over).
         wv::prof::set_role("enc16.spec_post");
         const SpecLayer& sp = m->specs[S];
         const wv_model::H16Stage& hs = m->h16[S];
-        wv::Spec16Args f{};
-        f.wav = x; f.cosw = hs.cosw; f.sinw = hs.sinw; f.cosl = hs.cosl; f.sinl = hs.sinl; f.pw = hs.spec; f.resid = R[cur]; f.Y = nullptr; f.Yact = nullptr;
-        f.Yf32 = (float*)R[cur ^ 1];
-        f.out_scale = sp.scale; f.act_scale = 0.f; f.c1 = 0.5f * 0.6931471805599453f * sp.inv_std; f.c0 = -sp.mean * sp.inv_std;
-        f.B = B; f.T = T; f.Tf = Tl; f.n_fft = sp.n_fft; f.hop = sp.hop;
         if ((T + sp.hop - 1) / sp.hop != Tl) return fail(WV_EINVAL, "internal: STFT frame count != feature length");
-        const int D = c.dimension;
-        if (tail == H16_TAIL_LATENT && hs.post.wq && c.last_kernel_size <= 16) {
-            // ELU(x') in c8 -> conv_post as one composed conv (f32 out)
-            f.Yf32 = nullptr; f.Yact = A0; f.act_scale = 1.f;
-            const hipError_t e1 = wv::launch_spec16(f, st);
-            if (e1 == hipSuccess) {
-                wv::prof::set_role("enc16.conv_post");
-                wv::Conv16Args g{};
-                g.X = A0; g.w = hs.post; g.bias = m->post_b; g.resid = nullptr; g.Y = nullptr; g.Yact = nullptr; g.Yf32 = (float*)(ws + L.off_lat);
-                g.out_scale = 1.f; g.act_scale = 0.f; g.B = B; g.M = D; g.Tin = Tl; g.Tout = Tl; g.ks = c.last_kernel_size; g.stride = 1;
-                g.pad = c.last_kernel_size - 1;
-                LAUNCH(wv::launch_conv16(g, st));
-                *post_done = true; *latent_done = true;
-                return WV_OK;
-            }
-            if (e1 != hipErrorNotSupported) return fail(WV_EHIP, std::string("launch_spec16 (post): ") + hipGetErrorString(e1));
-            f.Yf32 = (float*)R[cur ^ 1]; f.Yact = nullptr; f.act_scale = 0.f;
+        const bool latent = tail == H16_TAIL_LATENT && hs.post.wq && c.last_kernel_size <= 16;
+        float* f32out = latent ? nullptr : (float*)R[cur ^ 1];
+        bool done = false;
+        if (hs.cosw.wq) {
+            wv::Spec16Args f{};
+            f.wav = x; f.cosw = hs.cosw; f.sinw = hs.sinw; f.cosl = hs.cosl; f.sinl = hs.sinl; f.pw = hs.spec; f.resid = R[cur]; f.Y = nullptr;
+            f.Yact = latent ? A0 : nullptr; f.Yf32 = f32out;
+            f.out_scale = sp.scale; f.act_scale = latent ? 1.f : 0.f; f.c1 = 0.5f * 0.6931471805599453f * sp.inv_std; f.c0 = -sp.mean * sp.inv_std;
+            f.B = B; f.T = T; f.Tf = Tl; f.n_fft = sp.n_fft; f.hop = sp.hop;
+            const hipError_t fe = wv::launch_spec16(f, st);
+            if (fe == hipSuccess) done = true;
+            else if (fe != hipErrorNotSupported) return fail(WV_EHIP, std::string("launch_spec16 (post): ") + hipGetErrorString(fe));
         }
-        const hipError_t fe = wv::launch_spec16(f, st);
-        if (fe == hipSuccess) {
+        if (!done && (size_t)B * round_up_int(sp.F, 16) * Tl * 2 <= L.act * 4 && (size_t)B * sp.F * Tl <= L.spec) {
+            // any other scale: the exact path's STFT kernel -> P in HBM -> f16 copy -> the 1x1 + add as a k = 1 conv
+            wv::StftArgs sa{};
+            sa.wav = x; sa.basis_t = sp.basis_t; sa.basis_q = sp.basis_q; sa.side = sp.side; sa.P = P; sa.B = B; sa.T = T;
+            sa.Tf = Tl; sa.n_fft = sp.n_fft; sa.hop = sp.hop; sa.F = sp.F; sa.Mp = sp.Mp; sa.mean = sp.mean; sa.inv_std = sp.inv_std;
+            LAUNCH(wv::launch_stft_logmag(sa, st));
+            LAUNCH(wv::launch_f32_to_c8(P, P16, B, sp.F, Tl, 1.f, 0, st));
+            wv::Conv16Args q{};
+            q.X = P16; q.w = hs.spec; q.bias = nullptr; q.resid = R[cur]; q.Y = nullptr; q.Yact = latent ? A0 : nullptr; q.Yf32 = f32out;
+            q.out_scale = sp.scale; q.act_scale = latent ? 1.f : 0.f; q.B = B; q.M = C; q.Tin = Tl; q.Tout = Tl; q.ks = 1; q.stride = 1; q.pad = 0;
+            LAUNCH(wv::launch_conv16(q, st));
+            done = true;
+        }
+        if (done && latent) {
+            wv::prof::set_role("enc16.conv_post");
+            wv::Conv16Args g{};
+            g.X = A0; g.w = hs.post; g.bias = m->post_b; g.resid = nullptr; g.Y = nullptr; g.Yact = nullptr; g.Yf32 = (float*)(ws + L.off_lat);
+            g.out_scale = 1.f; g.act_scale = 0.f; g.B = B; g.M = c.dimension; g.Tin = Tl; g.Tout = Tl; g.ks = c.last_kernel_size; g.stride = 1;
+            g.pad = c.last_kernel_size - 1;
+            LAUNCH(wv::launch_conv16(g, st));
+            *post_done = true; *latent_done = true;
+            return WV_OK;
+        }
+        if (done) {
             if ((cur ^ 1) != 0) LAUNCH(hipMemcpyAsync(R[0], R[1], (size_t)B * C * Tl * sizeof(float), hipMemcpyDeviceToDevice, st));
             *post_done = true;
             return WV_OK;
         }
-        if (fe != hipErrorNotSupported) return fail(WV_EHIP, std::string("launch_spec16 (post): ") + hipGetErrorString(fe));
         LAUNCH(wv::launch_c8_to_f32(R[cur], (float*)R[cur ^ 1], B, C, Tl, st));     // the exact path's spec_post takes it from here
         if ((cur ^ 1) != 0) LAUNCH(hipMemcpyAsync(R[0], R[1], (size_t)B * C * Tl * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
