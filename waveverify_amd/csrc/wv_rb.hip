@@ -107,52 +107,36 @@ __device__ __forceinline__ float rb_dpp_next(float v) {        // lane i <- lane
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
-// 5-tap stencil from the accumulators: y[e] = bias + sum_i w[i] * H[NT*q + e + i]  (taps ascending, as K1).  Columns past the lane's
-// own NT come from the next lane (NT = 4) or the next two (NT = 2: one shifted copy, then the same DPP multiply-add on it).
+// 5-tap stencil from the accumulators: y[e] = bias + sum_i w[i] * H[NT*q + e + i] (taps ascending, as K1), for a PAIR of rows
+// (accumulator registers r, r + 1 = two adjacent channels) as packed-f32 multiply-adds: one
+// v_pk_fma_f32 does both rows, the neighbour lanes' columns come as shifted copies (compiler-visible DPP moves).  Taps in the same
+// ascending order, every multiply-add fused: the values of round 3's per-row stencil (whose neighbour taps were DPP operands of inline-asm
+// v_fmac_f32_dpp) bit for bit, 3.5 (NT = 4) / 4.5 (NT = 2) vector instructions per output instead of 5 / 6 -- measured even on time (+-1 %,
+// profiles/r04_rb_packed_stencil.txt) -- and no inline-asm cross-lane read is left for the compiler's hazard recogniser to miss.  tp: the pair's table row {w0a, w0b, w1a, w1b | w2a, w2b,
+// w3a, w3b | w4a, w4b, ba, bb} (built from the [C][8] table when the kernel copies it to LDS).
+__device__ __forceinline__ f32x2 rb_pair_next(f32x2 v) { return f32x2{rb_dpp_next(v.x), rb_dpp_next(v.y)}; }
 template <int NT>
-__device__ __forceinline__ void rb_stencil(const f32x16 (&acc)[NT], int r, const f32x4& w0, const f32x4& w1, float (&y)[NT]) {
-    const float w[5] = {w0.x, w0.y, w0.z, w0.w, w1.x};
-    float own[NT];
+__device__ __forceinline__ void rb_stencil2(const f32x16 (&acc)[NT], int r, const float* tp, f32x2 (&y)[NT]) {
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(tp), q1 = *reinterpret_cast<const f32x4*>(tp + 4), q2 = *reinterpret_cast<const f32x4*>(tp + 8);
+    const f32x2 w[5] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}, {q2.x, q2.y}};
+    const f32x2 bb{q2.z, q2.w};
+    f32x2 col[NT + 4];                                           // the lane's NT columns, then the 4 that follow them
 #pragma unroll
-    for (int e = 0; e < NT; ++e) own[e] = acc[e][r];
-    // The neighbour lanes' taps are DPP operands of the multiply-adds themselves (v_fmac_f32_dpp ... wave_shl:1: a fused multiply-add,
-    // rounds like fmaf).  They are inline asm: the compiler does not see that they read `own` / `sh` from ANOTHER lane and keeps no
-    // distance between a write of those registers (a copy out of an accumulator register, a reload, the shifted copy's v_mov_dpp) and
-    // the DPP read (2 wait states on gfx9; seen live: a 128-register build returned wrong values in one lane pair per row group,
-    // differently from run to run).  Each DPP sequence is therefore ONE asm statement that opens with the wait: whatever the
-    // compiler writes in front of the statement is two wait states old at the first cross-lane read, and it cannot put anything
-    // in between.  tools/dpp_hazard.py / tests/test_dpp_hazard.py check the shipped code objects for exactly this.
-#define WV_DPP_FMAC(y, hh, ww) "v_fmac_f32_dpp " y ", " hh ", " ww " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    for (int e = 0; e < NT; ++e) col[e] = f32x2{acc[e][r], acc[e][r + 1]};
     if constexpr (NT == 4) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = w1.y;
-#pragma unroll
-            for (int i = 0; i + e < 4; ++i) v = fmaf(w[i], own[e + i], v);
-            y[e] = v;
-        }
-        asm volatile("s_nop 1\n"
-                     WV_DPP_FMAC("%0", "%4", "%11")
-                     WV_DPP_FMAC("%1", "%4", "%10") WV_DPP_FMAC("%1", "%5", "%11")
-                     WV_DPP_FMAC("%2", "%4", "%9") WV_DPP_FMAC("%2", "%5", "%10") WV_DPP_FMAC("%2", "%6", "%11")
-                     WV_DPP_FMAC("%3", "%4", "%8") WV_DPP_FMAC("%3", "%5", "%9") WV_DPP_FMAC("%3", "%6", "%10") WV_DPP_FMAC("%3", "%7", "%11")
-                     : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])
-                     : "v"(own[0]), "v"(own[1]), "v"(own[2]), "v"(own[3]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
+        for (int e = 0; e < 4; ++e) col[4 + e] = rb_pair_next(col[e]);
     } else {
-        const float sh0 = rb_dpp_next(own[0]), sh1 = rb_dpp_next(own[1]);      // columns 2q + 2, 2q + 3 (compiler-visible DPP moves)
-        float v0 = fmaf(w[0], own[0], w1.y), v1 = fmaf(w[0], own[1], w1.y);
-        v0 = fmaf(w[1], own[1], v0);
-        asm volatile("s_nop 1\n"
-                     WV_DPP_FMAC("%1", "%2", "%6")
-                     WV_DPP_FMAC("%0", "%2", "%7") WV_DPP_FMAC("%1", "%3", "%7")
-                     WV_DPP_FMAC("%0", "%3", "%8")
-                     WV_DPP_FMAC("%1", "%4", "%8")
-                     WV_DPP_FMAC("%0", "%4", "%9") WV_DPP_FMAC("%1", "%5", "%9")
-                     : "+v"(v0), "+v"(v1)
-                     : "v"(own[0]), "v"(own[1]), "v"(sh0), "v"(sh1), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
-        y[0] = v0; y[1] = v1;
+        col[2] = rb_pair_next(col[0]); col[3] = rb_pair_next(col[1]);
+        col[4] = rb_pair_next(col[2]); col[5] = rb_pair_next(col[3]);
     }
-#undef WV_DPP_FMAC
+#pragma unroll
+    for (int e = 0; e < NT; ++e) {
+        f32x2 v = bb;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v = __builtin_elementwise_fma(w[i], col[e + i], v);
+        y[e] = v;
+    }
 }
 
 // One GEMM of the block: acc = W @ S over all C rows of the window.  A fragments: global chunk g in ar[g % NA], loaded AD chunks
@@ -205,7 +189,14 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
     const int T = p.T, ntiles = p.ntiles, num_t = p.num_t;
     const int row_bytes = T * 4, clip_bytes = C * T * 4;
 
-    for (int i = tid; i < C * 8; i += R::NTHREADS) { tab[i] = p.tab1[i]; tab[C * 8 + i] = p.tab2[i]; }
+    // the stencil tables [C][8] (taps, bias, 1, 0) into LDS in channel-PAIR layout [C / 2][12] (rb_stencil2), the two tables C * 8 floats apart
+    for (int i = tid; i < C * 8; i += R::NTHREADS) {
+        const int m = i >> 3, j = i & 7;
+        if (j < 6) {
+            const int d = (m >> 1) * 12 + 2 * (j < 5 ? j : 5) + (m & 1);
+            tab[d] = p.tab1[i]; tab[C * 8 + d] = p.tab2[i];
+        }
+    }
 
     // ---- A fragments: wq[k/4][Mp][4]; chunk c, lane half h: a0 = wq[4c + h][m], a1 = wq[4c + h + 2][m].  Buffer loads: one
     // per-lane byte offset, the chunk as a compile-time scalar offset (per-chunk 64-bit addresses, hoisted out of the tile loop by
@@ -227,7 +218,7 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
     const bool uw = NT * q < R::GS;                              // lanes that own u columns
     const int row0 = 32 * strip + 4 * h;
     const float* Bf = S + co + 4 * h * LD;                       // B rows of this lane's half, its columns
-    const float* Wrow1 = tab + row0 * 8;
+    const float* Wrow1 = tab + (row0 / 2) * 12;                  // pair table row of channel row0 (a multiple of 4)
     const float* Wrow2 = Wrow1 + C * 8;
     float* Urow = S + row0 * LD + co;
     float* Xrow = Urow + 8;
@@ -321,33 +312,29 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
             const __amdgpu_buffer_rsrc_t rH0 = uniform_rsrc((OUT & 4) ? p.sv_h0 + bo1 : p.X, (OUT & 4) ? clip_bytes : 0);
             const __amdgpu_buffer_rsrc_t rU = uniform_rsrc((OUT & 4) ? p.sv_u + bo1 : p.X, (OUT & 4) ? clip_bytes : 0);
             const int vh0 = sv_off(h0own, to0 - 8 + co), vu = sv_off(u_own, to0 - 4 + co);
-            f32x4 w0n = *reinterpret_cast<const f32x4*>(Wrow1), w1n = *reinterpret_cast<const f32x4*>(Wrow1 + 4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {                    // rows r, r + 1: channels cr, cr + 1
                 const int cr = (r & 3) + 8 * (r >> 2);
-                const f32x4 w0 = w0n, w1 = w1n;
-                if (r + 1 < 16) {
-                    const int cn = ((r + 1) & 3) + 8 * ((r + 1) >> 2);
-                    w0n = *reinterpret_cast<const f32x4*>(Wrow1 + cn * 8);
-                    w1n = *reinterpret_cast<const f32x4*>(Wrow1 + cn * 8 + 4);
-                }
-                float y[NT];
-                rb_stencil<NT>(acc, r, w0, w1, y);
-                ovec uv;
+                f32x2 y2[NT];
+                rb_stencil2<NT>(acc, r, Wrow1 + (cr / 2) * 12, y2);
 #pragma unroll
-                for (int e = 0; e < NT; ++e) uv[e] = elu1(y[e] * 1.f);
-                if (uw) *reinterpret_cast<ovec*>(Urow + cr * LD) = uv;
-                if constexpr ((OUT & 4) != 0) {
-                    ovec hv, ur;                                 // the first half's output BEFORE the second half's ELU: what its backward differentiates
+                for (int k = 0; k < 2; ++k) {
+                    ovec uv;
 #pragma unroll
-                    for (int e = 0; e < NT; ++e) { hv[e] = acc[e][r]; ur[e] = y[e]; }
-                    const int o0 = vh0 == RB_OOB ? RB_OOB : vh0 + cr * row_bytes, o1 = vu == RB_OOB ? RB_OOB : vu + cr * row_bytes;
-                    if constexpr (NT == 4) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, hv), rH0, o0, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, ur), rU, o1, 0, 0);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, hv), rH0, o0, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, ur), rU, o1, 0, 0);
+                    for (int e = 0; e < NT; ++e) uv[e] = elu1(y2[e][k] * 1.f);
+                    if (uw) *reinterpret_cast<ovec*>(Urow + (cr + k) * LD) = uv;
+                    if constexpr ((OUT & 4) != 0) {
+                        ovec hv, ur;                             // the first half's output BEFORE the second half's ELU: what its backward differentiates
+#pragma unroll
+                        for (int e = 0; e < NT; ++e) { hv[e] = acc[e][r + k]; ur[e] = y2[e][k]; }
+                        const int o0 = vh0 == RB_OOB ? RB_OOB : vh0 + (cr + k) * row_bytes, o1 = vu == RB_OOB ? RB_OOB : vu + (cr + k) * row_bytes;
+                        if constexpr (NT == 4) {
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, hv), rH0, o0, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, ur), rU, o1, 0, 0);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, hv), rH0, o0, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, ur), rU, o1, 0, 0);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -394,45 +381,42 @@ __global__ __launch_bounds__(R::NTHREADS) __attribute__((amdgpu_waves_per_eu(R::
             const int vh1 = sv_off(u_own, to0 - 4 + co);
             // what is left of the next window (the rows the last quarter of GEMM 2 still read), ahead of the stores below
             refill(next, R::PARTS > 1 ? 16 * (NCH - NCH / R::PARTS) : 0, C);
-            f32x4 w0n = *reinterpret_cast<const f32x4*>(Wrow2), w1n = *reinterpret_cast<const f32x4*>(Wrow2 + 4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cr = (r & 3) + 8 * (r >> 2);
-                const f32x4 w0 = w0n, w1 = w1n;
-                if (r + 1 < 16) {
-                    const int cn = ((r + 1) & 3) + 8 * ((r + 1) >> 2);
-                    w0n = *reinterpret_cast<const f32x4*>(Wrow2 + cn * 8);
-                    w1n = *reinterpret_cast<const f32x4*>(Wrow2 + cn * 8 + 4);
-                }
-                float v[NT];
-                rb_stencil<NT>(acc, r, w0, w1, v);
-                ovec y;
+            for (int r = 0; r < 16; r += 2) {
+                const int cr0 = (r & 3) + 8 * (r >> 2);
+                f32x2 v2[NT];
+                rb_stencil2<NT>(acc, r, Wrow2 + (cr0 / 2) * 12, v2);
 #pragma unroll
-                for (int e = 0; e < NT; ++e) y[e] = fmaf(v[e], oscale, X[r][e]);
-                const int off = voff0 + cr * row_bytes;
-                if constexpr ((OUT & 4) != 0) {
-                    ovec hv, vv;
+                for (int k = 0; k < 2; ++k) {
+                    const int cr = cr0 + k;
+                    ovec y;
 #pragma unroll
-                    for (int e = 0; e < NT; ++e) { hv[e] = acc[e][r]; vv[e] = v[e]; }
-                    const int o1 = vh1 == RB_OOB ? RB_OOB : vh1 + cr * row_bytes;
-                    if constexpr (NT == 4) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, hv), rH1, o1, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, vv), rV, off, 0, 0);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, hv), rH1, o1, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, vv), rV, off, 0, 0);
+                    for (int e = 0; e < NT; ++e) y[e] = fmaf(v2[e][k], oscale, X[r + k][e]);
+                    const int off = voff0 + cr * row_bytes;
+                    if constexpr ((OUT & 4) != 0) {
+                        ovec hv, vv;
+#pragma unroll
+                        for (int e = 0; e < NT; ++e) { hv[e] = acc[e][r + k]; vv[e] = v2[e][k]; }
+                        const int o1 = vh1 == RB_OOB ? RB_OOB : vh1 + cr * row_bytes;
+                        if constexpr (NT == 4) {
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, hv), rH1, o1, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, vv), rV, off, 0, 0);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, hv), rH1, o1, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, vv), rV, off, 0, 0);
+                        }
                     }
-                }
-                if constexpr ((OUT & 1) != 0) {
-                    if constexpr (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
-                }
-                if constexpr ((OUT & 2) != 0) {
-                    ovec a;
+                    if constexpr ((OUT & 1) != 0) {
+                        if constexpr (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, y), rY, off, 0, 0);
+                    }
+                    if constexpr ((OUT & 2) != 0) {
+                        ovec a;
 #pragma unroll
-                    for (int e = 0; e < NT; ++e) a[e] = elu1(y[e] * p.act_scale);
-                    if constexpr (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, a), rA, off, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, a), rA, off, 0, 0);
+                        for (int e = 0; e < NT; ++e) a[e] = elu1(y[e] * p.act_scale);
+                        if constexpr (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, a), rA, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, a), rA, off, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
