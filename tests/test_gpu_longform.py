@@ -57,6 +57,21 @@ def test_thirty_second_clip_locator_vs_oracle(nets):
     assert O.miou((lo16 > 0.5).astype(int), (ref > 0.5).astype(int)) >= 0.995
 
 
+def test_thirty_second_clips_in_the_f16_mode(nets):
+    """configs[3] through the f16-operand mode (the c8 activations of a 30 s clip run to 92 MB per clip and stage): the watermarked audio
+    within the 1e-4 bar of the exact path, the same bits, a ragged length too."""
+    for B, T in ((3, 480000), (2, 479999)):
+        x, msg = synthetic_clips(B, T, seed=35)
+        xt, mt = torch.from_numpy(x).cuda(), torch.from_numpy(msg).cuda()
+        wm = nets["generator"].generator(xt, mt, add_input=True)
+        wm16 = nets["generator"].generator(xt, mt, add_input=True, precision="f16")
+        assert torch.isfinite(wm16).all() and float((wm16 - wm).abs().max()) <= 1e-4
+        mp, mp16 = nets["detector"].detector_mean_prob(wm), nets["detector"].detector_mean_prob(wm16, precision="f16")
+        assert float((mp - mp16).abs().max()) <= 1e-3 and torch.equal(mp >= 0.5, mp16 >= 0.5)
+        del wm, wm16
+        torch.cuda.empty_cache()
+
+
 def test_thirty_second_clip_prefix_property(nets):
     """30 s at 16 kHz (T = 480000).  Everything is causal up to the end of a hop frame, so the
     first L samples (L a multiple of 320) of every output equal the outputs on the L-sample prefix."""
