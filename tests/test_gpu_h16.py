@@ -687,3 +687,24 @@ def test_f16_mode_on_other_configurations(seed):
     assert dp <= 2e-2 and torch.equal((mp16 >= 0.5)[far], (mp >= 0.5)[far])
     lg, lg16 = L.locator(wm), L.locator(wm, precision="f16")
     assert float((lg - lg16).abs().max()) <= 0.03 * max(1.0, float(lg.abs().max()))
+
+
+def test_generator_f16_against_the_oracle_of_its_own_arithmetic(nets3):
+    """oracle/wv_oracle_h16.py restates the MODE's arithmetic on the CPU: the pinned torch port of the reference path with a round-to-f16
+    at every point where a kernel of the mode rounds (and float64 sums).  A whole net in f16 storage is its own noise amplifier -- one
+    activation that lands on the other side of a rounding boundary (f32 vs f64 sums) moves the output as much as the rounding noise itself
+    -- so GPU and oracle agree at the level at which both agree with the exact path (measured 3.7e-5 / 3.2e-5 / 3.6e-5), not tighter; a
+    rounding point in the wrong place or a misplaced log2(e) shows up at 1e-3 and more.  All three distances are held to north_star's 1e-4."""
+    from oracle import wv_oracle_h16 as O16
+    from oracle import wv_oracle_torch as OT
+    from waveverify_amd.config import default_config
+    from waveverify_amd.init import random_state_dict, synthetic_clips
+    cfg = default_config("generator")
+    net = OT.Net(cfg, random_state_dict(cfg, 0))
+    x_np, msg_np = synthetic_clips(2, 8000, seed=21)
+    ref16 = O16.embed(net, x_np, msg_np).numpy()
+    exact = OT.embed(net, x_np, msg_np).numpy()
+    got = nets3["generator"].generator(torch.from_numpy(x_np).cuda(), torch.from_numpy(msg_np).cuda(), add_input=True, precision="f16").cpu().numpy()
+    d_or, d_ex, o_ex = float(np.abs(got - ref16).max()), float(np.abs(got - exact).max()), float(np.abs(ref16 - exact).max())
+    print(f"f16 mode: GPU vs its oracle {d_or:.2e}; GPU vs exact {d_ex:.2e}; oracle vs exact {o_ex:.2e}")
+    assert d_ex <= 1e-4 and o_ex <= 1e-4 and d_or <= 1e-4, (d_or, d_ex, o_ex)
