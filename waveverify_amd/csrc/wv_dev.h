@@ -58,6 +58,57 @@ struct RowPairLoader {
     }
 };
 
+// The same B operand with the INPUT window in LDS (wv_k1.hip, LDR 6 / 7; per-clip tiles, K a whole number of chunks, Tin % 4 == 0): the
+// rows a[k][ls .. ls + LWP) of a chunk arrive by LDS-DMA (coalesced, each piece once per workgroup; frames outside [0, Tin) read zeros =
+// the causal padding and the trimmed tail), and a thread builds its 2 (k) x 4 (t) micro-tile from two LDS reads per channel instead of
+// narrow global gathers with clamps and selects.  Only the taps still come from global memory (two aligned float4 per channel, L2-resident).
+// The values are ConvTrPair's: B[k][t] = fmaf(a[k][l - 1], w[k][ph + r], a[k][l] * w[k][ph]).
+template <int RM>                                               // RM = 4: r % 4 == 0 (the four times share l); RM = 2: r == 2
+struct ConvTrLds {
+    static constexpr int NRAW = RM == 4 ? 16 : 8;
+    const float* ct_w; int K, ratio, c0, LWP, ls, km;           // ls: first frame of the window (a multiple of 4, <= the tile's first l - 1); km: chunk depth - 1
+    const float* Rcur;                                          // this chunk's rows in LDS: [BKC][LWP]
+    int lrel, ph0;
+    __device__ __forceinline__ void init(int cg) {
+        const int t = max(c0 + 4 * cg, 0);                      // (columns at t < 0 -- the halo of a clip's first tile -- meet zero taps downstream)
+        const int l = t / ratio;
+        ph0 = t - l * ratio;
+        lrel = l - ls;
+    }
+    template <bool FAST = false>
+    __device__ __forceinline__ void fetch2(int k0, float (&raw)[NRAW]) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* w = ct_w + (size_t)(k0 + i) * 2 * ratio;
+            float* r = raw + i * (NRAW / 2);
+            if (RM == 4) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + ph0), w1 = *reinterpret_cast<const f32x4*>(w + ph0 + ratio);
+                r[0] = w0.x; r[1] = w0.y; r[2] = w0.z; r[3] = w0.w; r[4] = w1.x; r[5] = w1.y; r[6] = w1.z; r[7] = w1.w;
+            } else {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w);               // (w0[0], w0[1], w1[0], w1[1])
+                r[0] = wv.x; r[1] = wv.y; r[2] = wv.z; r[3] = wv.w;
+            }
+        }
+    }
+    template <bool FAST = false>
+    __device__ __forceinline__ void finish2(int k0, const float (&raw)[NRAW], float (&o)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* r = raw + i * (NRAW / 2);
+            const float* a = Rcur + ((k0 + i) & km) * LWP + lrel;
+            if (RM == 4) {
+                const float xa = a[0], xb = a[-1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * i + e] = fmaf(xb, r[4 + e], xa * r[e]);
+            } else {
+                const float am = a[-1], a0 = a[0], a1 = a[1];
+                o[4 * i + 0] = fmaf(am, r[2], a0 * r[0]); o[4 * i + 1] = fmaf(am, r[3], a0 * r[1]);
+                o[4 * i + 2] = fmaf(a0, r[2], a1 * r[0]); o[4 * i + 3] = fmaf(a0, r[3], a1 * r[1]);
+            }
+        }
+    }
+};
+
 // log-magnitude feature of one STFT bin (modules/conv.py:1078, seanet.py:487-494):
 //   (log(max(sqrt(max(re^2 + im^2, 1e-12)), 1e-5)) - mean) / std.
 // sqrt(max(p, 1e-12)) >= 1e-6 and the outer clamp at 1e-5 = sqrt(1e-10) supersedes the inner one, so this is

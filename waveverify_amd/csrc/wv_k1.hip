@@ -494,6 +494,9 @@ template <> struct LdrSel<2> { typedef ConvTrPair<4> type; };
 template <> struct LdrSel<3> { typedef ConvTrPair<2> type; };
 template <> struct LdrSel<4> { typedef ConvTrPair<1> type; };
 template <> struct LdrSel<5> { typedef ConvTrPair<0> type; };
+template <> struct LdrSel<6> { typedef ConvTrLds<4> type; };        // upsample unit, input window through LDS (per-clip tiles)
+template <> struct LdrSel<7> { typedef ConvTrLds<2> type; };
+template <class C> constexpr int k1_lwp(int ldr) { return ldr == 7 ? (C::BN / 2 + 6 + 3) / 4 * 4 : (C::BN / 4 + 6 + 3) / 4 * 4; }   // LDS row length of the input window (frames)
 
 // One workgroup per (m-tile, time-tile, clip); the 1-D grid is mapped XCD-aware (decode_tile, wv_dev.h): the
 // m-tiles of one activation window are adjacent on one XCD, whose L2 then fetches the window once.
@@ -540,6 +543,7 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
     const int ti0 = to0 * p.stride - p.pad - p.off;
     const float* Xb = p.X + (size_t)b * K * p.Tin;
 
+    constexpr int LWP = LDR >= 6 ? k1_lwp<C>(LDR) : 4;           // LDS row length of the upsample unit's input window (LDR 6 / 7)
     Epi epi;
     epi.begin(p, table, m0, b, to0, gflat);
     DmaRows<C> db{};
@@ -564,8 +568,29 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
             c0 = t - 4 * cg; ncols = inb ? p.Tin : 0; tout = inb ? p.Tout : 0;
         }
         if constexpr (LDR == 1) lb = LB{Xt, K, p.Tin, ncols, c0, p.pre_scale, p.pre_elu, nullptr, 0, false, false};
+        else if constexpr (LDR >= 6) {
+            const int lfirst = max(c0, 0) / p.ratio;
+            lb = LB{p.ct_w, K, p.ratio, c0, LWP, ((lfirst - 1) & ~3), C::BKC - 1, nullptr, 0, 0};
+        }
         else lb = LB{Xt, p.ct_w, p.ct_wt, K, p.pw.Kp, p.Tin, tout, c0, p.ratio, p.pre_scale, p.pre_elu, 0, 0, {}, {}};
     }
+    // LDR 6 / 7: the input window of a chunk ([BKC rows][LWP frames] from frame lb.ls) by LDS-DMA into one of two buffers behind the row table
+    float* Rbuf = table + Epi::TABLE_FLOATS;
+    auto issue_rows = [&](int c, int buf) {
+        if constexpr (LDR >= 6) {
+            constexpr int PPR = LWP / 4, NPIECE = C::BKC * PPR, NINST = (NPIECE + 63) / 64, PER = (NINST + C::WM - 1) / C::WM;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int inst = wave + i * C::WM;
+                const int q = inst * 64 + lane;
+                const int row = q / PPR, f = lb.ls + 4 * (q - row * PPR);
+                const bool inr = f >= 0 && f < p.Tin;            // Tin % 4 == 0 and ls % 4 == 0: a piece is all inside or all outside
+                const float* src = inr ? Xb + (size_t)(c * C::BKC + min(row, C::BKC - 1)) * p.Tin + f : g_zero16;
+                if (inst < NINST && q < NPIECE)
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Rbuf + (size_t)buf * C::BKC * LWP + inst * 256), 16, 0, 0);
+            }
+        }
+    };
 
     auto issue = [&](int c, int st) {
         f32x4* S = S4 + st * C::STAGE4;
@@ -573,6 +598,7 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
         if constexpr (!REG) db.issue(c, S + C::A4, wave);
     };
     auto fetch = [&](int c) {
+        if constexpr (LDR >= 6) { if (c + 1 < nchunks) issue_rows(c + 1, (c + 1) & 1); }   // the window of the chunk after this one (its buffer was read by the last commit)
         if constexpr (REG) {
 #pragma unroll
             for (int r = 0; r < C::B_PER; ++r) {
@@ -582,6 +608,7 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
         }
     };
     auto commit = [&](int c, int st) {
+        if constexpr (LDR >= 6) lb.Rcur = Rbuf + (size_t)(c & 1) * C::BKC * LWP;
         if constexpr (REG) {
             f32x4* Bq = S4 + st * C::STAGE4 + C::A4;
 #pragma unroll
@@ -610,6 +637,12 @@ __global__ __launch_bounds__(C::NTHREADS, LDR >= 2 ? (C::B_PER > 1 ? 2 : 3) : 4)
         for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
     issue(0, 0);
     if constexpr (NS == 2) {
+        if constexpr (LDR >= 6) {
+            // Window pipeline: fetch(c) requests the rows of chunk c + 1 while chunk c - 1 computes, commit(c + 1) reads them one barrier
+            // later.  Here: chunk 0's rows, waited for and made visible, before the first commit.
+            issue_rows(0, 0);
+            __syncthreads();
+        }
         if constexpr (REG) { lb.init(cg); fetch(0); commit(0, 0); }
         __syncthreads();                                       // first chunk landed, table visible
     } else {
@@ -680,7 +713,8 @@ bool k1_supported(const PwDwArgs& a) {
 
 template <class C, int EPI, int LDR, int RES, int NS = 2>
 static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
-    const size_t smem = NS * (size_t)C::STAGE4 * 16 + (size_t)K1Epi<C, EPI, RES>::TABLE_FLOATS * sizeof(float);
+    const size_t smem = NS * (size_t)C::STAGE4 * 16 + (size_t)K1Epi<C, EPI, RES>::TABLE_FLOATS * sizeof(float) +
+                        (LDR >= 6 ? (size_t)2 * C::BKC * k1_lwp<C>(LDR) * sizeof(float) : 0);
     static_assert(C::WM * 4 * C::HLD <= 2 * C::STAGE4 * 4, "strips alias the stages");
     a.num_m = (a.pw.M + C::BM - 1) / C::BM;
     a.num_t = (a.Tout + a.tto - 1) / a.tto;
@@ -696,7 +730,7 @@ static hipError_t k1_run(PwDwArgs a, hipStream_t s, const char* base) {
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     std::string name;
     if (prof::enabled())
-        name = std::string(base) + "<" + std::to_string(C::BM) + "," + std::to_string(C::BN) + (LDR == 0 ? (NS == 3 ? ",dma3" : ",dma") : ",reg") + (a.flat ? ",flat>" : ">");
+        name = std::string(base) + "<" + std::to_string(C::BM) + "," + std::to_string(C::BN) + (LDR == 0 ? (NS == 3 ? ",dma3" : ",dma") : (LDR >= 6 ? ",win" : ",reg")) + (a.flat ? ",flat>" : ">");
     const double M = a.pw.M, K = a.pw.K, Bd = a.B;
     const double outs = (a.Y ? 1.0 : 0.0) + (a.Yact ? 1.0 : 0.0) + (a.resid ? 1.0 : 0.0);
     const double flops = a.ct_w ? 2.0 * Bd * a.Tout * K * (M + 2.0) : 2.0 * Bd * M * (K * a.Tin + (double)a.ks * a.Tout);
@@ -711,6 +745,13 @@ template <class C, int EPI, int RES>
 static hipError_t k1_pick_ldr(const PwDwArgs& a, hipStream_t s) {
     if (a.ct_w) {
         if constexpr (EPI == 0 && RES == 0) {
+#ifndef K1_NO_LDS_UPSAMPLE
+            // per-clip tiles of an already activated input in whole chunks: the input window through LDS (ConvTrLds)
+            if (!a.flat && a.pre_scale == 1.f && !a.pre_elu && a.pw.K % C::BKC == 0 && a.Tin % 4 == 0 && a.Tout == a.Tin * a.ratio && C::BM <= 128) {
+                if (a.ratio % 4 == 0) return k1_run<C, 0, 6, false>(a, s, "convtr_pw_lds");
+                if (a.ratio == 2) return k1_run<C, 0, 7, false>(a, s, "convtr_pw_lds");
+            }
+#endif
             if (a.ratio % 4 == 0) return k1_run<C, 0, 2, false>(a, s, "convtr_pw");
             if (a.ratio == 2) return k1_run<C, 0, 3, false>(a, s, "convtr_pw");
             return k1_run<C, 0, 5, false>(a, s, "convtr_pw");
